@@ -1,0 +1,112 @@
+/*
+ * lol_oracle.h — CPU oracle for loltracer's per-pixel ray-march path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a scalar-C restatement of
+ * /root/reference/naive_renderer.c (+ sdf.h, float.h, vec.h), used as the
+ * checker for the HIP renderer.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's `cpu_baseline` leg may load it; the product (loltracer_amd/,
+ * include/lol_gpu.h) never links or calls anything in oracle/.
+ *
+ * Pinning: the reference ships no tests or golden images.  The
+ * restatement is pinned by (1) the five whole-frame XRGB8888 hashes the survey
+ * recorded from the unmodified naive_renderer.c, checked in
+ * tests/test_oracle.py, and (2) oracle/_ref — the reference's own SDL-free
+ * headers (float.h, vec.h, sdf.h) and scene.c compiled where they lie and
+ * compared bit-for-bit with the primitives here (oracle/ref_harness.c).
+ * naive_renderer.c itself cannot be compiled in this image (it includes
+ * <SDL.h> through renderer.h and SDL2 is absent), see DESIGN.md.
+ */
+#ifndef LOL_ORACLE_H
+#define LOL_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "lol_scene.h"   /* data types only (include/), no product code is linked */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Work counters summed over the rendered pixels (SURVEY.md §8d "algorithmic flops"). */
+typedef struct lol_oracle_counters {
+	uint64_t pixels;
+	uint64_t sdf_evals;        /* calls of sdf()                      naive_renderer.c:31 */
+	uint64_t node_evals;       /* calls of get_obj_dist()             naive_renderer.c:11 */
+	uint64_t march_steps;      /* iterations of get_intersection loop naive_renderer.c:56 */
+	uint64_t shadow_steps;     /* iterations of softshadow loop       naive_renderer.c:80 */
+	uint64_t miss_pixels;      /* id == 0 after the march */
+} lol_oracle_counters;
+
+/* Per-pixel probe of the intermediate values (for debugging parity failures). */
+typedef struct lol_oracle_probe {
+	float    rd[3];
+	float    hit_dist;
+	uint32_t hit_id;
+	uint32_t march_steps;
+	float    normal[3];
+	float    shadow[LOL_MAX_LIGHTS];
+	uint32_t shadow_steps[LOL_MAX_LIGHTS];
+	float    rgb_linear[3];    /* get_light() result, before gamma */
+	float    rgb[3];           /* after gamma */
+	uint32_t xrgb;
+} lol_oracle_probe;
+
+/*
+ * Render rows [y0, y1) of a w×h frame of `scene` seen from `cam`
+ * (naive_renderer.c:207-236).  max_steps is MAX_STEPS of get_intersection
+ * (256 in the reference, naive_renderer.c:49).
+ *   xrgb   : h rows of `pitch_bytes`; pixel (x,y) at xrgb + y*pitch + 4*x,
+ *            value r<<16|g<<8|b (renderer.h:17-22 with an XRGB8888 surface)
+ *   rgb    : optional w*h*3 floats, post-gamma pre-quantisation, row-major
+ *   steps  : optional w*h uint16 pairs {march, shadow-total} per pixel
+ *   ctr    : optional counters, accumulated (caller zeroes)
+ */
+void lol_oracle_render_rows(const lol_scene* scene, const lol_camera* cam,
+                            int w, int h, int max_steps, int y0, int y1,
+                            void* xrgb, size_t pitch_bytes, float* rgb,
+                            uint16_t* steps, lol_oracle_counters* ctr);
+
+/*
+ * Whole frame on `threads` workers that claim rows from one atomic counter,
+ * the reference's scheduling (naive_renderer.c:216, main.c:189-194).
+ */
+void lol_oracle_render_frame(const lol_scene* scene, const lol_camera* cam,
+                             int w, int h, int max_steps, int threads,
+                             void* xrgb, size_t pitch_bytes, float* rgb,
+                             lol_oracle_counters* ctr);
+
+/* Rows y = y0 + k*stride < y_end only (bounded sample for the CPU baseline). */
+void lol_oracle_render_sample(const lol_scene* scene, const lol_camera* cam,
+                              int w, int h, int max_steps, int threads,
+                              int y0, int y_end, int stride,
+                              void* xrgb, size_t pitch_bytes,
+                              lol_oracle_counters* ctr);
+
+void lol_oracle_probe_pixel(const lol_scene* scene, const lol_camera* cam,
+                            int w, int h, int max_steps, int x, int y,
+                            lol_oracle_probe* out);
+
+/* sdf(p) alone: returns distance, stores the 1-based object id (0 = none). */
+float lol_oracle_sdf(const lol_scene* scene, float px, float py, float pz, uint32_t* id);
+
+/* Primitives exported for the oracle/_ref cross-check (float.h, vec.h, sdf.h). */
+float lol_oracle_minf(float a, float b);
+float lol_oracle_maxf(float a, float b);
+float lol_oracle_clamp(float v, float lo, float hi);
+float lol_oracle_sminf(float a, float b, float k);
+float lol_oracle_v3dot(const float a[3], const float b[3]);
+float lol_oracle_v3len(const float a[3]);
+void  lol_oracle_v3normalize(const float a[3], float out[3]);
+void  lol_oracle_v3cross(const float a[3], const float b[3], float out[3]);
+void  lol_oracle_v3clamp(const float a[3], float lo, float hi, float out[3]);
+float lol_oracle_sd_sphere(const float p[3], float r);
+float lol_oracle_sd_round_box(const float p[3], const float b[3], float r);
+
+/* FNV-1a-style hash over 32-bit pixels, row-major, skipping row padding
+ * (the survey's known-answer hash). */
+uint64_t lol_oracle_hash_xrgb(const void* xrgb, int w, int h, size_t pitch_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
