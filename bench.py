@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py — Mpixels/s of the gfx950 sphere-tracer on BASELINE.json's configs.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|orbit]
+
+A step = one frame of the hot path (camera ray → march → normal → shadows/Phong → gamma →
+XRGB8888) rendered from the scene already resident on the device, into a device framebuffer.
+
+  N = 1   workload "c3": tests/golden/scenes/scene4.lol, 3840x2160, 256 march steps — the config
+          BASELINE.json's metric is quoted on.
+  N > 1   workload "c4": scene4.lol, 7680x4320, rows band-interleaved over the N ranks (one process
+          per GPU), each rank renders its bands, then ONE RCCL gather to rank 0 which un-interleaves
+          them into the final framebuffer.  Total work is fixed as N grows → "scaling": "strong".
+  orbit   256-frame camera orbit of scene4 at 3840x2160, frames striped over ranks, no collective.
+
+The JSON line carries `roofline` (HBM-write roofline named by BASELINE.json: 4 B per pixel over the
+render kernel's average launch duration measured with HIP events on the launch stream) and
+`cpu_baseline` (the CPU oracle — a bit-faithful port of naive_renderer.c — on the host cores, on a
+bounded row sample of the same frame).  This path is VALU-bound, not HBM-bound; `valu` gives the
+fraction of the unfused-FP32 issue peak, with flops/pixel counted by the oracle on sample rows.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from loltracer_amd import gpu, multi, scene as S
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s spec
+VALU_PEAK_TOPS = 78.6           # 157.3 TFLOP/s FMA peak / 2: unfused FP32 ops (no FMA in this path)
+BYTES_PER_PIXEL = 4             # one XRGB8888 store per pixel
+
+WORKLOADS = {
+    "c2": dict(scene="scene", w=1920, h=1080, max_steps=128),
+    "c3": dict(scene="scene4", w=3840, h=2160, max_steps=256),
+    "c4": dict(scene="scene4", w=7680, h=4320, max_steps=256),
+    "orbit": dict(scene="scene4", w=3840, h=2160, max_steps=256, frames=256),
+}
+
+
+def orbit_camera(i: int, n: int = 256) -> S.Camera:
+    """Frame i of the scene4 orbit: doubles on the host, rounded to float."""
+    cx, cy, cz = 0.0, 1.0, -6.0
+    R = math.sqrt(85.0)
+    th = math.atan2(-2.0, 9.0) + 2.0 * math.pi * i / n
+    px, py, pz = cx + R * math.sin(th), cy + 5.0, cz + R * math.cos(th)
+    dx, dy, dz = cx - px, cy - py, cz - pz
+    inv = 1.0 / math.sqrt(dx * dx + dy * dy + dz * dz)
+    cam = S.Camera()
+    cam.point = S.V3(px, py, pz)
+    cam.direction = S.V3(dx * inv, dy * inv, dz * inv)
+    cam.fov = float(np.float32(np.float32(150.0) / np.float32(180.0) * np.pi))
+    return cam
+
+
+def flops_per_sdf(prog: S.Program) -> float:
+    """Unfused FP32 ops of one sdf() evaluation (sphere 10, smin 13, rbox ~22, plane 1, top 2)."""
+    cost = {S.OP_SPHERE: 10, S.OP_RBOX: 22, S.OP_PLANE: 1, S.OP_SMIN: 13, S.OP_SMIN_R: 13, S.OP_TOP: 2}
+    return float(sum(cost[prog.ops[i].op] for i in range(prog.n_ops)))
+
+
+def cpu_baseline(sc: S.Scene, cfg: dict, target_s: float = 15.0):
+    """Time the CPU oracle on all host cores over a bounded, evenly spread row sample of the frame."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    w, h, ms = cfg["w"], cfg["h"], cfg["max_steps"]
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:                                              # a container's CPU quota, when it has one
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(math.ceil(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    lib = O.lib()
+    buf = np.zeros((h, w), dtype=np.uint32)
+
+    def run(stride):
+        ctr = O.Counters()
+        t0 = time.perf_counter()
+        lib.lol_oracle_render_sample(sc.ptr, C.byref(sc.c.camera), w, h, ms, cores, 0, h, stride,
+                                     buf.ctypes.data, w * 4, C.byref(ctr))
+        return time.perf_counter() - t0, ctr
+
+    probe_stride = max(1, h // 32)
+    t_probe, c_probe = run(probe_stride)
+    rate = c_probe.pixels / max(t_probe, 1e-9)
+    want_px = rate * target_s
+    stride = max(1, int(math.ceil(w * h / max(want_px, 1.0))))
+    t, ctr = run(stride)
+    return dict(value=ctr.pixels / t / 1e6, unit="Mpixels/s", cores=cores, kind="port",
+                sample=f"every {stride}th row of the {w}x{h} frame ({ctr.pixels} px, {t:.1f} s, "
+                       f"{cores} threads claiming rows from an atomic counter)"), ctr
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=None, choices=list(WORKLOADS))
+    ap.add_argument("--band-rows", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        args.gpus = world
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: there is no CPU rendering path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    name = args.workload or ("c3" if world == 1 else "c4")
+    cfg = WORKLOADS[name]
+    w, h, max_steps = cfg["w"], cfg["h"], cfg["max_steps"]
+    sc = S.Scene.parse_file(os.path.join(ROOT, "tests", "golden", "scenes", cfg["scene"] + ".lol"))
+    r = gpu.Renderer(local_rank)
+    r.prepare(sc)                                     # render_prepare: flatten + upload once
+    # A side stream: its handle is non-NULL (NULL means "the context's own stream" in lol_gpu.h), and
+    # torch.cuda.Event / the nccl gather below are ordered on whatever stream is current.
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(side)
+    stream = side.cuda_stream
+    assert stream, "expected a non-NULL HIP stream handle"
+
+    orbit = name == "orbit"
+    if orbit:
+        band, rows, n_local = h, None, h
+        frames_total = cfg["frames"]
+        my_frames = list(range(rank, frames_total, world))
+        cams = [sc.frame_camera(w, h, orbit_camera(i, frames_total)) for i in my_frames]
+    else:
+        band = args.band_rows or (multi.choose_band_rows(h, world) if world > 1 else h)
+        if world > 1 and (band <= 0 or h % (band * world)):
+            raise SystemExit(f"cannot split {h} rows evenly over {world} ranks")
+        rows = gpu.Rows(band, world, rank) if world > 1 else None
+        n_local = gpu.part_rows(h, rows)
+        cams = [sc.frame_camera(w, h)]
+
+    local = torch.zeros((n_local, w), dtype=torch.int32, device=dev)
+    staging = frame = None
+    if world > 1 and not orbit and rank == 0:
+        staging = torch.empty((world, n_local, w), dtype=torch.int32, device=dev)
+        frame = torch.empty((h, w), dtype=torch.int32, device=dev)
+
+    kernel_ms = []
+
+    def step(i, timed):
+        fc = cams[i % len(cams)]
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        r.render_into(local.data_ptr(), w, h, max_steps, rows=rows, stream=stream, frame_camera=fc)
+        if timed:
+            e1.record()
+            kernel_ms.append((e0, e1))
+        if world > 1 and not orbit:
+            multi.gather_frame(local, h, band, out=frame, staging=staging)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    steps = args.steps
+    if orbit:
+        steps = len(cams)                             # one pass over this rank's stripe of the orbit
+    for i in range(args.warmup):
+        step(i, False)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i, True)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    k_ms = [a.elapsed_time(b) for a, b in kernel_ms]
+    k_avg = sum(k_ms) / max(len(k_ms), 1)
+    px_per_launch = n_local * w
+    if orbit:
+        total_px = cfg["frames"] * w * h              # all ranks together render each frame once
+        steps_reported = cfg["frames"]
+    else:
+        total_px = steps * w * h
+        steps_reported = steps
+    value = total_px / dt / 1e6
+
+    if rank == 0:
+        achieved = px_per_launch * BYTES_PER_PIXEL / (k_avg * 1e-3) / 1e9
+        out = {
+            "metric": "Mpixels/s at 3840x2160, <=256 march steps; max |pixel delta| vs naive_renderer.c",
+            "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": steps_reported,
+            "warmup": args.warmup, "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak" if orbit else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{name}: tests/golden/scenes/{cfg['scene']}.lol {w}x{h}, {max_steps} march steps"
+                                   + (f", {cfg['frames']}-frame orbit striped over ranks" if orbit else
+                                      (f", rows in bands of {band} interleaved over {world} ranks + RCCL gather to rank 0"
+                                       if world > 1 else ", one kernel launch per frame")),
+                       "width": w, "height": h, "max_steps": max_steps, "band_rows": band,
+                       "kernel": r.kernel_name()},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
+                         "kernel_ms_avg": round(k_avg, 4), "pixels_per_launch": px_per_launch,
+                         "bytes_per_pixel": BYTES_PER_PIXEL,
+                         "note": "north_star names the HBM-write roofline; the path is FP32-VALU-bound, see `valu`"},
+        }
+        if world == 1 and not args.no_cpu_baseline and not orbit:
+            base, ctr = cpu_baseline(sc, cfg)
+            out["cpu_baseline"] = base
+            fpp = (ctr.sdf_evals * flops_per_sdf(r.program) + ctr.march_steps * 9 + ctr.shadow_steps * 12) / ctr.pixels
+            kernel_mpix = px_per_launch / (k_avg * 1e-3) / 1e6
+            tops = kernel_mpix * 1e6 * fpp / 1e12
+            out["valu"] = {"flops_per_pixel": round(fpp, 1), "sdf_evals_per_pixel": round(ctr.sdf_evals / ctr.pixels, 2),
+                           "achieved": round(tops, 3), "peak": VALU_PEAK_TOPS, "unit": "Tops/s (unfused FP32)",
+                           "frac": round(tops / VALU_PEAK_TOPS, 4)}
+        print(json.dumps(out), flush=True)
+
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

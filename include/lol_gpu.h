@@ -1,0 +1,117 @@
+/*
+ * lol_gpu.h — C ABI of the MI355X (gfx950) renderer for loltracer's per-pixel path.
+ *
+ * This is the drop-in boundary.  A C host that today links
+ * naive_renderer.c gets the same three renderer.h entry points from
+ * integration/hip_renderer.c, which is a thin adapter over the functions
+ * below; INTEGRATION.md shows the binding.  Plain pointers and sizes only: no
+ * C++ types, no exceptions, no torch.  Every function returns 0 on success or
+ * a negative lol_gpu_status; lol_gpu_error() gives the text of the last error
+ * of a context.
+ *
+ *   reference                                         here
+ *   ------------------------------------------------  ---------------------------
+ *   render_prepare()   renderer.h:25, main.c:161      lol_gpu_create + lol_gpu_upload_program
+ *   render_thread() pixel loop
+ *                      naive_renderer.c:207-236       lol_gpu_render_device / lol_gpu_render_host
+ *   render_destroy()   renderer.h:26, main.c:213      lol_gpu_destroy
+ *   row self-scheduling naive_renderer.c:216          the launch grid (+ `bands` for multi-GPU)
+ *
+ * There is no CPU fallback: every entry point fails with LOL_GPU_ERR_NO_DEVICE
+ * when no HIP device is usable.
+ */
+#ifndef LOL_GPU_H
+#define LOL_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "lol_scene.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lol_gpu lol_gpu;      /* one renderer context = one device + one scene */
+
+enum lol_gpu_status {
+	LOL_GPU_OK              =  0,
+	LOL_GPU_ERR_NO_DEVICE   = -1,
+	LOL_GPU_ERR_HIP         = -2,    /* a HIP runtime call failed; see lol_gpu_error() */
+	LOL_GPU_ERR_ARG         = -3,
+	LOL_GPU_ERR_NO_PROGRAM  = -4,
+	LOL_GPU_ERR_UNSUPPORTED = -5
+};
+
+/*
+ * Which rows of the frame one call renders, and where they land.
+ *
+ * The frame's rows are cut into bands of `band_rows`; band b belongs to part
+ * (b % n_parts).  A call renders the bands of `part` and writes them
+ * compactly: local row r = (b / n_parts) * band_rows + (y % band_rows) of the
+ * destination holds frame row y.  {band_rows = h, n_parts = 1, part = 0}
+ * is the whole frame in place.  This is the multi-GPU row-tile partition
+ * (SURVEY.md §8e): every rank renders its part and the parts are gathered.
+ */
+typedef struct lol_gpu_rows {
+	int32_t band_rows;
+	int32_t n_parts;
+	int32_t part;
+} lol_gpu_rows;
+
+/* Optional per-pixel diagnostics, all device pointers, each may be NULL.
+ * Indexed by local row like the pixel destination, `w` elements per row. */
+typedef struct lol_gpu_debug {
+	float*    rgb;        /* 3 floats per pixel: post-gamma, pre-quantisation colour  */
+	float*    hit_dist;   /* get_intersection().dist                                  */
+	uint32_t* hit_id;     /* get_intersection().id                                    */
+	uint32_t* steps;      /* low 16 bits: march steps; high 16 bits: shadow steps sum */
+} lol_gpu_debug;
+
+int  lol_gpu_device_count(void);
+int  lol_gpu_create(int device, lol_gpu** out);
+void lol_gpu_destroy(lol_gpu* ctx);
+const char* lol_gpu_error(const lol_gpu* ctx);
+
+/* Copy the flattened scene (lol_scene_flatten) to the device.  May be called
+ * again at any time; frames issued afterwards use the new program. */
+int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog);
+
+/* Number of local rows a part owns (for sizing destinations). */
+int lol_gpu_part_rows(int h, const lol_gpu_rows* rows);
+
+/*
+ * Launch one frame (or one part of it) asynchronously.
+ *   cam       per-frame camera constants (lol_frame_camera_init)
+ *   w, h      frame size in pixels; max_steps = MAX_STEPS of the primary march
+ *   rows      partition (NULL = whole frame)
+ *   dst       DEVICE pointer, XRGB8888 (r<<16|g<<8|b), `pitch_bytes` per local row
+ *   dbg       optional diagnostics (NULL in production)
+ *   stream    hipStream_t to launch on, as void*; NULL = the context's own stream
+ */
+int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h, int max_steps,
+                          const lol_gpu_rows* rows, void* dst, size_t pitch_bytes,
+                          const lol_gpu_debug* dbg, void* stream);
+
+/*
+ * Whole frame into a HOST surface (what render_thread does with surf->pixels,
+ * naive_renderer.c:233-235): renders into the context's device framebuffer,
+ * copies `h` rows of w*4 bytes honouring `pitch_bytes`, and waits.
+ */
+int lol_gpu_render_host(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h, int max_steps,
+                        void* host_pixels, size_t pitch_bytes);
+
+/* Wait for everything issued on the context's own stream. */
+int lol_gpu_sync(lol_gpu* ctx);
+
+/* Raw device memory helpers so a C host needs no HIP headers. */
+int lol_gpu_malloc(lol_gpu* ctx, size_t bytes, void** out);
+int lol_gpu_free(lol_gpu* ctx, void* ptr);
+int lol_gpu_memcpy_d2h(lol_gpu* ctx, void* host, const void* dev, size_t bytes);
+
+/* Name of the kernel a launch uses (for matching rocprofv3 kernel-trace rows). */
+const char* lol_gpu_kernel_name(const lol_gpu* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOL_GPU_H */

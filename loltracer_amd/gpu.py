@@ -1,0 +1,153 @@
+"""ctypes mirror of include/lol_gpu.h — the gfx950 renderer behind the renderer.h boundary.
+
+`Renderer` plays the role of the reference's renderer plug-in
+(render_prepare / render_thread / render_destroy, renderer.h:24-26):
+    r = Renderer(device=0); r.prepare(scene)        # render_prepare
+    r.render_into(dev_ptr, w, h, max_steps=256)     # one frame of render_thread
+    r.close()                                       # render_destroy
+All rendering happens in liblol_gpu.so (HIP).  There is no CPU path: if the
+library or a device is missing this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import scene as S
+
+LOL_GPU_OK = 0
+_STATUS = {0: "ok", -1: "no HIP device", -2: "HIP runtime error", -3: "bad argument",
+           -4: "no scene program uploaded", -5: "unsupported"}
+
+
+class Rows(C.Structure):
+    """lol_gpu_rows: band-interleaved row partition (multi-GPU row tiles)."""
+    _fields_ = [("band_rows", C.c_int32), ("n_parts", C.c_int32), ("part", C.c_int32)]
+
+
+class Debug(C.Structure):
+    _fields_ = [("rgb", C.c_void_p), ("hit_dist", C.c_void_p), ("hit_id", C.c_void_p), ("steps", C.c_void_p)]
+
+
+class GpuError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"lol_gpu: {_STATUS.get(status, status)}: {message}")
+        self.status = status
+
+
+_lib = None
+
+
+def gpu_lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        path = os.path.join(S.LIB_DIR, "liblol_gpu.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: the HIP extension was not built "
+                               "(run __graft_entry__.build()); there is no CPU fallback")
+        lib = C.CDLL(path)
+        P = C.POINTER
+        vp = C.c_void_p
+        lib.lol_gpu_device_count.argtypes = []
+        lib.lol_gpu_device_count.restype = C.c_int
+        lib.lol_gpu_create.argtypes = [C.c_int, P(vp)]
+        lib.lol_gpu_create.restype = C.c_int
+        lib.lol_gpu_destroy.argtypes = [vp]
+        lib.lol_gpu_destroy.restype = None
+        lib.lol_gpu_error.argtypes = [vp]
+        lib.lol_gpu_error.restype = C.c_char_p
+        lib.lol_gpu_upload_program.argtypes = [vp, P(S.Program)]
+        lib.lol_gpu_upload_program.restype = C.c_int
+        lib.lol_gpu_part_rows.argtypes = [C.c_int, P(Rows)]
+        lib.lol_gpu_part_rows.restype = C.c_int
+        lib.lol_gpu_render_device.argtypes = [vp, P(S.FrameCamera), C.c_int, C.c_int, C.c_int, P(Rows),
+                                              vp, C.c_size_t, P(Debug), vp]
+        lib.lol_gpu_render_device.restype = C.c_int
+        lib.lol_gpu_render_host.argtypes = [vp, P(S.FrameCamera), C.c_int, C.c_int, C.c_int, vp, C.c_size_t]
+        lib.lol_gpu_render_host.restype = C.c_int
+        lib.lol_gpu_sync.argtypes = [vp]
+        lib.lol_gpu_sync.restype = C.c_int
+        lib.lol_gpu_malloc.argtypes = [vp, C.c_size_t, P(vp)]
+        lib.lol_gpu_malloc.restype = C.c_int
+        lib.lol_gpu_free.argtypes = [vp, vp]
+        lib.lol_gpu_free.restype = C.c_int
+        lib.lol_gpu_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+        lib.lol_gpu_memcpy_d2h.restype = C.c_int
+        lib.lol_gpu_kernel_name.argtypes = [vp]
+        lib.lol_gpu_kernel_name.restype = C.c_char_p
+        _lib = lib
+    return _lib
+
+
+EXPORTED_SYMBOLS = [
+    "lol_gpu_device_count", "lol_gpu_create", "lol_gpu_destroy", "lol_gpu_error", "lol_gpu_upload_program",
+    "lol_gpu_part_rows", "lol_gpu_render_device", "lol_gpu_render_host", "lol_gpu_sync", "lol_gpu_malloc",
+    "lol_gpu_free", "lol_gpu_memcpy_d2h", "lol_gpu_kernel_name",
+]
+
+
+def part_rows(h: int, rows: Rows | None) -> int:
+    return gpu_lib().lol_gpu_part_rows(h, C.byref(rows) if rows is not None else None)
+
+
+class Renderer:
+    def __init__(self, device: int = 0):
+        self._lib = gpu_lib()
+        self._ctx = C.c_void_p()
+        st = self._lib.lol_gpu_create(device, C.byref(self._ctx))
+        if st != LOL_GPU_OK:
+            self._ctx = C.c_void_p()
+            raise GpuError(st, f"lol_gpu_create(device={device}) failed")
+        self.scene: S.Scene | None = None
+        self.program: S.Program | None = None
+
+    def _check(self, st: int):
+        if st != LOL_GPU_OK:
+            raise GpuError(st, self._lib.lol_gpu_error(self._ctx).decode())
+
+    # render_prepare (renderer.h:25): flatten + upload the scene
+    def prepare(self, scene: S.Scene):
+        self.scene = scene
+        self.program = scene.flatten()
+        self._check(self._lib.lol_gpu_upload_program(self._ctx, C.byref(self.program)))
+
+    def upload_program(self, program: S.Program):
+        self.program = program
+        self._check(self._lib.lol_gpu_upload_program(self._ctx, C.byref(program)))
+
+    def render_into(self, dst_ptr: int, w: int, h: int, max_steps: int = 256, camera: S.Camera | None = None,
+                    rows: Rows | None = None, pitch_bytes: int | None = None, debug: Debug | None = None,
+                    stream: int | None = None, frame_camera: S.FrameCamera | None = None):
+        """Asynchronously render (a part of) a frame into device memory at dst_ptr."""
+        fc = frame_camera if frame_camera is not None else self.scene.frame_camera(w, h, camera)
+        self._check(self._lib.lol_gpu_render_device(
+            self._ctx, C.byref(fc), w, h, max_steps,
+            C.byref(rows) if rows is not None else None,
+            C.c_void_p(dst_ptr), pitch_bytes if pitch_bytes is not None else w * 4,
+            C.byref(debug) if debug is not None else None,
+            C.c_void_p(stream) if stream else None))
+
+    def render_host(self, host_ptr: int, w: int, h: int, max_steps: int = 256, camera: S.Camera | None = None,
+                    pitch_bytes: int | None = None):
+        """What render_thread does with surf->pixels: whole frame into a host surface, synchronous."""
+        fc = self.scene.frame_camera(w, h, camera)
+        self._check(self._lib.lol_gpu_render_host(self._ctx, C.byref(fc), w, h, max_steps, C.c_void_p(host_ptr),
+                                                  pitch_bytes if pitch_bytes is not None else w * 4))
+
+    def sync(self):
+        self._check(self._lib.lol_gpu_sync(self._ctx))
+
+    def kernel_name(self) -> str:
+        return self._lib.lol_gpu_kernel_name(self._ctx).decode()
+
+    # render_destroy (renderer.h:26)
+    def close(self):
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self._lib.lol_gpu_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

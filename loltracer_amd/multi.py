@@ -1,0 +1,94 @@
+"""Row-tile partition of one frame over the ranks of a node, assembled with a gather.
+
+The reference parallelises a frame by letting workers claim scan-lines from an
+atomic counter (naive_renderer.c:216, main.c:189-194): every pixel is
+independent.  Across GPUs the same independence is used statically: the frame's
+rows are cut into bands of `band_rows`, band b goes to rank b % world (fine
+interleave, so sky rows and blob rows are spread evenly), each rank renders its
+bands compactly (include/lol_gpu.h, lol_gpu_rows) and one gather over
+RCCL/xGMI brings the parts to rank 0, which un-interleaves them.  One process
+per GPU; torch.distributed is only the transport.
+
+Everything here is device-agnostic (tensors in, tensors out) so the same code
+runs under gloo on CPU in the tests and under nccl (= RCCL) on MI355X.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def choose_band_rows(h: int, world: int, preferred: int = 8) -> int:
+    """Largest band <= preferred with h % (band * world) == 0, so all parts are equal; 0 if none."""
+    for band in range(min(preferred, max(h // world, 1)), 0, -1):
+        if h % (band * world) == 0:
+            return band
+    return 0
+
+
+def part_rows(h: int, band_rows: int, world: int, rank: int) -> int:
+    bands = (h + band_rows - 1) // band_rows
+    n = 0
+    for b in range(rank, bands, world):
+        n += min(band_rows, h - b * band_rows)
+    return n
+
+
+def frame_rows_of_part(h: int, band_rows: int, world: int, rank: int) -> torch.Tensor:
+    """Frame row index of every local row of `rank` (the inverse of the kernel's row mapping)."""
+    bands = (h + band_rows - 1) // band_rows
+    ys = []
+    for b in range(rank, bands, world):
+        y0 = b * band_rows
+        ys.extend(range(y0, min(y0 + band_rows, h)))
+    return torch.tensor(ys, dtype=torch.long)
+
+
+def assemble(parts: torch.Tensor, h: int, band_rows: int) -> torch.Tensor:
+    """[world, rows_per_part, w] gathered parts → [h, w] frame (equal parts)."""
+    world, rpp, w = parts.shape
+    assert rpp * world == h and rpp % band_rows == 0
+    nb = rpp // band_rows
+    # parts[r, b, i] is frame row (b*world + r)*band + i
+    return parts.view(world, nb, band_rows, w).permute(1, 0, 2, 3).reshape(h, w)
+
+
+def gather_frame(local: torch.Tensor, h: int, band_rows: int, group=None, dst: int = 0,
+                 out: Optional[torch.Tensor] = None, staging: Optional[torch.Tensor] = None
+                 ) -> Optional[torch.Tensor]:
+    """Gather every rank's compact part [rows_per_part, w] to `dst` and return the [h, w] frame there.
+
+    `staging` ([world, rows_per_part, w], on dst) and `out` ([h, w]) can be preallocated so the
+    timed loop allocates nothing.
+    """
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        return local
+    rpp, w = local.shape
+    if rank == dst:
+        if staging is None:
+            staging = torch.empty((world, rpp, w), dtype=local.dtype, device=local.device)
+        dist.gather(local, [staging[i] for i in range(world)], dst=dst, group=group)
+        frame = assemble(staging, h, band_rows)
+        if out is not None:
+            out.copy_(frame)
+            return out
+        return frame.contiguous()
+    dist.gather(local, None, dst=dst, group=group)
+    return None
+
+
+def render_frame_distributed(render_part: Callable[[int, int, int], torch.Tensor], w: int, h: int,
+                             band_rows: int, group=None, dst: int = 0, out=None, staging=None):
+    """render_part(band_rows, world, rank) → this rank's compact [rows, w] int32 tensor; returns the frame on dst."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if world > 1 and h % (band_rows * world) != 0:
+        raise ValueError(f"h={h} must be a multiple of band_rows*world={band_rows * world}")
+    local = render_part(band_rows, world, rank)
+    if world == 1:
+        return local
+    return gather_frame(local, h, band_rows, group=group, dst=dst, out=out, staging=staging)
