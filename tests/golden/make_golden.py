@@ -1,0 +1,296 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures.  Run in the build container (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+Outputs (all DATA — inputs and expected outputs, no reference source text):
+
+  ref_primitives.json   inputs → outputs of the REFERENCE's own float.h / vec.h / sdf.h functions,
+                        obtained by calling oracle/_ref/liblol_ref.so (those headers compiled where
+                        they lie in /root/reference, see oracle/Makefile `ref`).  Bit patterns as hex.
+  ref_scenes.json       what the REFERENCE's scene.c builders produce for the four example scenes:
+                        the .lol text is walked by the small independent parser below (mirroring the
+                        grammar actions of scene-parser.y:99-145) and every block is handed to
+                        scene.c's *_from_definition_list through liblol_ref.so; the resulting
+                        struct scene is dumped field by field (floats as hex bit patterns).
+  oracle_frames.npz     XRGB8888 frames + float RGB of the CPU ORACLE (not of the reference:
+                        naive_renderer.c cannot be built here) — regression fixtures that
+                        pin the oracle's output across toolchains / on the GPU box.
+"""
+import ctypes as C
+import json
+import os
+import re
+import struct
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "liblol_ref.so")
+
+# enum property / enum components of the reference (scene.h:7-35), as plain numbers
+PROPS = ["shininess", "diffuse", "specular", "ambient", "color", "point", "direction", "fov",
+         "diffuse_intensity", "specular_intensity", "radius", "material", "point2", "y", "smoothness", "a", "b"]
+TYPES = ["ambient", "camera", "point_light", "sphere", "box", "plane", "smooth_union"]
+
+
+def f2h(x):
+    return "%08x" % struct.unpack("<I", struct.pack("<f", x))[0]
+
+
+def h2f(h):
+    return struct.unpack("<f", struct.pack("<I", int(h, 16)))[0]
+
+
+def load_ref():
+    ref = C.CDLL(REF_SO)
+    f, f3, vp = C.c_float, C.POINTER(C.c_float), C.c_void_p
+    sig = {
+        "ref_minf": ([f, f], f), "ref_maxf": ([f, f], f), "ref_clamp": ([f, f, f], f),
+        "ref_lerp": ([f, f, f], f), "ref_sminf": ([f, f, f], f),
+        "ref_v3dot": ([f3, f3], f), "ref_v3len": ([f3], f), "ref_v3normalize": ([f3, f3], None),
+        "ref_v3cross": ([f3, f3, f3], None), "ref_v3clamp": ([f3, f, f, f3], None),
+        "ref_v3pow": ([f3, f, f3], None),
+        "ref_sd_sphere": ([f3, f], f), "ref_sd_box": ([f3, f3], f), "ref_sd_round_box": ([f3, f3, f], f),
+        "ref_deflist_new": ([], vp), "ref_deflist_add_num": ([vp, C.c_int, f], None),
+        "ref_deflist_add_list": ([vp, C.c_int, f3, C.c_int], None),
+        "ref_deflist_add_id": ([vp, C.c_int, C.c_size_t], None),
+        "ref_deflist_add_obj": ([vp, C.c_int, C.c_int, vp], None),
+        "ref_scene_new": ([], vp), "ref_scene_free": ([vp], None),
+        "ref_scene_add_component": ([vp, C.c_int, vp], None), "ref_scene_add_material": ([vp, vp], None),
+        "ref_scene_validate_materials": ([vp], C.c_int), "ref_scene_counts": ([vp, C.c_int], C.c_size_t),
+        "ref_scene_camera": ([vp, f3], None), "ref_scene_ambient": ([vp, f3], None),
+        "ref_scene_material": ([vp, C.c_size_t, f3], None), "ref_scene_light": ([vp, C.c_size_t, f3], None),
+        "ref_scene_object": ([vp, C.c_size_t], vp),
+        "ref_object_fields": ([vp, C.POINTER(C.c_int), C.POINTER(C.c_size_t), f3, f3, f3, f3,
+                               C.POINTER(vp), C.POINTER(vp)], None),
+        "ref_sizeof": ([C.c_int], C.c_size_t),
+    }
+    for name, (args, res) in sig.items():
+        fn = getattr(ref, name)
+        fn.argtypes, fn.restype = args, res
+    return ref
+
+
+# ------------------------------------------------------------------ primitives
+
+def gen_primitives(ref):
+    rng = np.random.default_rng(20261003)
+    special = [0.0, -0.0, float("inf"), -float("inf"), float("nan"), 1.0, -1.0, 0.5, 1e-3, 100.0,
+               1e-40, -1e-40, 3.0e38, 1.17549435e-38, 0.001, 50.0, 3.0, 2.2]
+
+    def rf():
+        r = rng.random()
+        if r < 0.2:
+            return float(np.float32(special[rng.integers(len(special))]))
+        if r < 0.75:
+            return float(np.float32(rng.normal() * 10.0 ** int(rng.integers(-3, 3))))
+        return float(np.array([rng.integers(0, 2 ** 32)], dtype=np.uint32).view(np.float32)[0])
+
+    def v3():
+        return [rf(), rf(), rf()]
+
+    A3 = C.c_float * 3
+    out = {k: [] for k in ("minf", "maxf", "clamp", "lerp", "sminf", "v3dot", "v3len", "v3normalize",
+                           "v3cross", "v3clamp", "sd_sphere", "sd_box", "sd_round_box")}
+    for _ in range(400):
+        a, b, c = rf(), rf(), rf()
+        out["minf"].append([f2h(a), f2h(b), f2h(ref.ref_minf(a, b))])
+        out["maxf"].append([f2h(a), f2h(b), f2h(ref.ref_maxf(a, b))])
+        out["clamp"].append([f2h(a), f2h(b), f2h(c), f2h(ref.ref_clamp(a, b, c))])
+        out["lerp"].append([f2h(a), f2h(b), f2h(c), f2h(ref.ref_lerp(a, b, c))])
+        out["sminf"].append([f2h(a), f2h(b), f2h(c), f2h(ref.ref_sminf(a, b, c))])
+        # realistic smooth-min inputs too: distances of a few units, k = 3 (scene4)
+        x, y = float(np.float32(rng.normal() * 4)), float(np.float32(rng.normal() * 4))
+        out["sminf"].append([f2h(x), f2h(y), f2h(3.0), f2h(ref.ref_sminf(x, y, 3.0))])
+        p, q = v3(), v3()
+        P, Q, O3 = A3(*p), A3(*q), A3()
+        out["v3dot"].append([[f2h(v) for v in p], [f2h(v) for v in q], f2h(ref.ref_v3dot(P, Q))])
+        out["v3len"].append([[f2h(v) for v in p], f2h(ref.ref_v3len(P))])
+        ref.ref_v3normalize(P, O3)
+        out["v3normalize"].append([[f2h(v) for v in p], [f2h(v) for v in O3]])
+        ref.ref_v3cross(P, Q, O3)
+        out["v3cross"].append([[f2h(v) for v in p], [f2h(v) for v in q], [f2h(v) for v in O3]])
+        ref.ref_v3clamp(P, 0.0, 1.0, O3)
+        out["v3clamp"].append([[f2h(v) for v in p], f2h(0.0), f2h(1.0), [f2h(v) for v in O3]])
+        out["sd_sphere"].append([[f2h(v) for v in p], f2h(a), f2h(ref.ref_sd_sphere(P, a))])
+        out["sd_box"].append([[f2h(v) for v in p], [f2h(v) for v in q], f2h(ref.ref_sd_box(P, Q))])
+        out["sd_round_box"].append([[f2h(v) for v in p], [f2h(v) for v in q], f2h(a),
+                                    f2h(ref.ref_sd_round_box(P, Q, a))])
+    return out
+
+
+# ---------------------------------------------- independent .lol walker → ref builders
+
+TOKEN_RE = re.compile(
+    r"(?P<nl>\n)|(?P<ws>[ \r\t]+)|(?P<num>[-.0-9]+)|(?P<id>#[0-9]+)|"
+    r"(?P<kw>materials|scene|ambient|camera|point-light|point_light|sphere|box|plane|smooth_union|smooth-union|"
+    r"shininess|diffuse_intensity|diffuse-intensity|diffuse|specular_intensity|specular-intensity|specular|color|"
+    r"point2|point|direction|fov|radius|material|smoothness|y|a|b)|(?P<p>[,(){}=])|(?P<junk>.)", re.S)
+
+
+def tokens(text):
+    # Python's alternation is first-match, so longer keywords are listed before their prefixes
+    for m in TOKEN_RE.finditer(text):
+        k = m.lastgroup
+        if k in ("nl", "ws", "junk"):
+            continue
+        yield k, m.group()
+
+
+class Walker:
+    def __init__(self, ref, text):
+        self.ref, self.toks, self.i = ref, list(tokens(text)), 0
+
+    def peek(self):
+        return self.toks[self.i] if self.i < len(self.toks) else ("eof", "")
+
+    def take(self, val=None):
+        k, v = self.peek()
+        assert val is None or v == val, (val, k, v)
+        self.i += 1
+        return k, v
+
+    @staticmethod
+    def norm(name):
+        return name.replace("-", "_")
+
+    def deflist(self):
+        dl = self.ref.ref_deflist_new()
+        while True:
+            _, prop = self.take()
+            pid = PROPS.index(self.norm(prop))
+            self.take("=")
+            k, v = self.peek()
+            if k == "num":
+                self.take()
+                self.ref.ref_deflist_add_num(dl, pid, C.c_float(float(np.float32(v))))
+            elif k == "id":
+                self.take()
+                self.ref.ref_deflist_add_id(dl, pid, int(v[1:]))
+            elif v == "(":
+                self.take()
+                nums = []
+                while True:
+                    nums.append(float(np.float32(self.take()[1])))
+                    if self.peek()[1] == ",":
+                        self.take()
+                        continue
+                    break
+                self.take(")")
+                arr = (C.c_float * len(nums))(*nums)
+                self.ref.ref_deflist_add_list(dl, pid, arr, len(nums))
+            else:
+                _, t = self.take()
+                self.take("{")
+                inner = self.deflist()
+                self.take("}")
+                self.ref.ref_deflist_add_obj(dl, pid, TYPES.index(self.norm(t)), inner)
+            if self.peek()[1] == ",":
+                self.take()
+                continue
+            return dl
+
+    def run(self):
+        ref = self.ref
+        sc = ref.ref_scene_new()
+        self.take("materials"); self.take("{")
+        while True:
+            self.take("{")
+            ref.ref_scene_add_material(sc, self.deflist())
+            self.take("}")
+            if self.peek()[1] == ",":
+                self.take()
+                continue
+            break
+        self.take("}")
+        self.take("scene"); self.take("{")
+        while True:
+            _, t = self.take()
+            self.take("{")
+            ref.ref_scene_add_component(sc, TYPES.index(self.norm(t)), self.deflist())
+            self.take("}")
+            if self.peek()[1] == ",":
+                self.take()
+                continue
+            break
+        self.take("}")
+        assert self.peek()[0] == "eof"
+        return sc
+
+
+def dump_object(ref, optr):
+    t, m = C.c_int(), C.c_size_t()
+    pt, half = (C.c_float * 3)(), (C.c_float * 3)()
+    rad, smooth = C.c_float(), C.c_float()
+    a, b = C.c_void_p(), C.c_void_p()
+    ref.ref_object_fields(optr, C.byref(t), C.byref(m), pt, C.cast(C.byref(rad), C.POINTER(C.c_float)), half,
+                          C.cast(C.byref(smooth), C.POINTER(C.c_float)), C.byref(a), C.byref(b))
+    d = {"type": TYPES[t.value], "material": m.value, "point": [f2h(v) for v in pt], "radius": f2h(rad.value),
+         "half_extent": [f2h(v) for v in half], "smoothness": f2h(smooth.value)}
+    if a.value:
+        d["a"] = dump_object(ref, a)
+        d["b"] = dump_object(ref, b)
+    return d
+
+
+def dump_scene(ref, sc):
+    cam, amb = (C.c_float * 7)(), (C.c_float * 3)()
+    ref.ref_scene_camera(sc, cam)
+    ref.ref_scene_ambient(sc, amb)
+    out = {"camera": [f2h(v) for v in cam], "ambient": [f2h(v) for v in amb], "materials": [], "lights": [],
+           "objects": [], "valid_materials": int(ref.ref_scene_validate_materials(sc))}
+    for i in range(ref.ref_scene_counts(sc, 0)):
+        m = (C.c_float * 10)()
+        ref.ref_scene_material(sc, i, m)
+        out["materials"].append([f2h(v) for v in m])
+    for i in range(ref.ref_scene_counts(sc, 1)):
+        l = (C.c_float * 9)()
+        ref.ref_scene_light(sc, i, l)
+        out["lights"].append([f2h(v) for v in l])
+    for i in range(ref.ref_scene_counts(sc, 2)):
+        out["objects"].append(dump_object(ref, ref.ref_scene_object(sc, i)))
+    return out
+
+
+def main():
+    if not os.path.exists(REF_SO):
+        raise SystemExit("oracle/_ref/liblol_ref.so missing: run `make -C oracle ref` where /root/reference exists")
+    ref = load_ref()
+
+    with open(os.path.join(HERE, "ref_primitives.json"), "w") as f:
+        json.dump({"source": "reference float.h/vec.h/sdf.h via oracle/_ref/liblol_ref.so", "vectors": gen_primitives(ref)},
+                  f, separators=(",", ":"))
+
+    scenes = {}
+    for name in ("scene", "scene2", "scene3", "scene4"):
+        text = open(os.path.join(HERE, "scenes", name + ".lol")).read()
+        sc = Walker(ref, text).run()
+        scenes[name] = dump_scene(ref, sc)
+        ref.ref_scene_free(sc)
+    sizes = dict(zip(["material", "light", "object", "camera", "scene", "vector"], [ref.ref_sizeof(i) for i in range(6)]))
+    with open(os.path.join(HERE, "ref_scenes.json"), "w") as f:
+        json.dump({"source": "reference scene.c builders via oracle/_ref/liblol_ref.so", "abi_sizes": sizes,
+                   "scenes": scenes}, f, indent=1)
+
+    import oracle_lib as O
+    from loltracer_amd import scene as S
+    frames = {}
+    for name, w, h in (("scene", 64, 36), ("scene2", 64, 36), ("scene3", 64, 36), ("scene4", 64, 36),
+                       ("scene", 256, 256), ("scene4", 256, 256)):
+        sc = S.Scene.parse_file(os.path.join(HERE, "scenes", name + ".lol"))
+        x, rgb, _ = O.render(sc, w, h, threads=8, want_rgb=True)
+        frames[f"{name}_{w}x{h}_xrgb"] = x
+        if w == 64:
+            frames[f"{name}_{w}x{h}_rgb"] = rgb
+    np.savez_compressed(os.path.join(HERE, "oracle_frames.npz"), **frames)
+    print("wrote ref_primitives.json, ref_scenes.json, oracle_frames.npz")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,53 @@
+"""The C-ABI libraries load and export every symbol the headers declare (no compute, no GPU)."""
+import ctypes as C
+import os
+import re
+
+from loltracer_amd import gpu, scene as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lol_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_lol_gpu_exports_every_declared_symbol():
+    lib = C.CDLL(os.path.join(S.LIB_DIR, "liblol_gpu.so"))
+    names = declared("lol_gpu.h")
+    assert set(names) == set(gpu.EXPORTED_SYMBOLS)
+    for n in names:
+        assert getattr(lib, n) is not None
+
+
+def test_lol_scene_exports_every_declared_symbol():
+    lib = C.CDLL(os.path.join(S.LIB_DIR, "liblol_scene.so"))
+    names = declared("lol_scene.h")
+    assert "lol_scene_parse_file" in names and "lol_scene_flatten" in names
+    for n in names:
+        assert getattr(lib, n) is not None
+
+
+def test_struct_sizes_match_the_headers():
+    # the Python mirrors must match the C layouts (lol_op is 10 dwords, see lol_scene.h)
+    assert C.sizeof(S.Op) == 40 and C.sizeof(S.Light) == 36 and C.sizeof(S.Material) == 40
+    assert C.sizeof(S.Node) == 48 and C.sizeof(S.FrameCamera) == 56
+    assert C.sizeof(S.Program) == 5 * 4 + 12 + 40 * 256 + 36 * 16 + 40 * 64 + 4 * 256
+
+
+def test_part_rows_is_pure_host_logic():
+    assert gpu.part_rows(2160, None) == 2160
+    assert [gpu.part_rows(4320, gpu.Rows(4, 8, r)) for r in range(8)] == [540] * 8
+    assert [gpu.part_rows(20, gpu.Rows(8, 2, r)) for r in range(2)] == [12, 8]
+    assert gpu.part_rows(10, gpu.Rows(0, 1, 0)) == -1
+
+
+def test_no_gpu_is_a_loud_error_not_a_fallback():
+    import pytest
+    if gpu.gpu_lib().lol_gpu_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(gpu.GpuError) as e:
+        gpu.Renderer(0)
+    assert e.value.status == -1

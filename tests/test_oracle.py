@@ -1,0 +1,157 @@
+"""The CPU oracle against everything that pins it (no GPU needed).
+
+1. tests/golden/ref_primitives.json — outputs of the REFERENCE's own float.h / vec.h / sdf.h
+   (compiled in place as oracle/_ref) on 400+ inputs per function, incl. NaN / inf / ±0 / denormals:
+   the oracle's restated primitives must agree bit for bit.
+2. Known answers recorded by the survey from the unmodified naive_renderer.c:
+   centre / corner pixels and the per-pixel work counters (sdf evaluations, march steps, shadow steps).
+   The survey's whole-frame hashes are NOT reproduced by this oracle (see test below and DESIGN.md).
+3. tests/golden/oracle_frames.npz — regression frames of the oracle itself (pins it across toolchains).
+"""
+import ctypes as C
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from loltracer_amd import scene as S
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PRIM = json.load(open(os.path.join(HERE, "golden", "ref_primitives.json")))["vectors"]
+
+
+def h2f(h):
+    return struct.unpack("<f", struct.pack("<I", int(h, 16)))[0]
+
+
+def f2h(x):
+    return "%08x" % struct.unpack("<I", struct.pack("<f", x))[0]
+
+
+def same(got, want_hex):
+    w = h2f(want_hex)
+    if w != w:
+        return got != got
+    return f2h(got) == want_hex
+
+
+def a3(hs):
+    return (C.c_float * 3)(*[h2f(h) for h in hs])
+
+
+@pytest.mark.parametrize("fn", ["minf", "maxf"])
+def test_minmax_match_reference(fn):
+    f = getattr(O.lib(), "lol_oracle_" + fn)
+    for a, b, want in PRIM[fn]:
+        assert same(f(h2f(a), h2f(b)), want), (fn, a, b)
+
+
+@pytest.mark.parametrize("fn", ["clamp", "sminf"])
+def test_ternary_match_reference(fn):
+    f = getattr(O.lib(), "lol_oracle_" + fn)
+    for a, b, c, want in PRIM[fn]:
+        assert same(f(h2f(a), h2f(b), h2f(c)), want), (fn, a, b, c)
+
+
+def test_vector_primitives_match_reference():
+    l = O.lib()
+    out = (C.c_float * 3)()
+    for p, q, want in PRIM["v3dot"]:
+        assert same(l.lol_oracle_v3dot(a3(p), a3(q)), want)
+    for p, want in PRIM["v3len"]:
+        assert same(l.lol_oracle_v3len(a3(p)), want)
+    for p, want in PRIM["v3normalize"]:
+        l.lol_oracle_v3normalize(a3(p), out)
+        assert all(same(o, w) for o, w in zip(out, want)), p
+    for p, q, want in PRIM["v3cross"]:
+        l.lol_oracle_v3cross(a3(p), a3(q), out)
+        assert all(same(o, w) for o, w in zip(out, want))
+    for p, lo, hi, want in PRIM["v3clamp"]:
+        l.lol_oracle_v3clamp(a3(p), h2f(lo), h2f(hi), out)
+        assert all(same(o, w) for o, w in zip(out, want))
+
+
+def test_sdf_primitives_match_reference():
+    l = O.lib()
+    for p, r, want in PRIM["sd_sphere"]:
+        assert same(l.lol_oracle_sd_sphere(a3(p), h2f(r)), want)
+    for p, b, r, want in PRIM["sd_round_box"]:
+        assert same(l.lol_oracle_sd_round_box(a3(p), a3(b), h2f(r)), want)
+
+
+def test_sse_minmax_semantics_spelled_out():
+    l = O.lib()
+    nan = float("nan")
+    assert l.lol_oracle_minf(1.0, nan) != l.lol_oracle_minf(1.0, nan)      # second operand on NaN
+    assert l.lol_oracle_minf(nan, 1.0) == 1.0
+    assert f2h(l.lol_oracle_minf(0.0, -0.0)) == "80000000"                 # second operand on equal
+    assert f2h(l.lol_oracle_maxf(-0.0, 0.0)) == "00000000"
+    assert l.lol_oracle_clamp(nan, 0.0, 1.0) == 0.0                         # clamp(NaN) → lo
+    out = (C.c_float * 3)()
+    l.lol_oracle_v3clamp((C.c_float * 3)(nan, -5.0, 5.0), 0.0, 1.0, out)
+    assert list(out) == [1.0, 0.0, 1.0]                                     # v3clamp(NaN) → hi
+
+
+# ---- survey known answers -----------------------------------------
+
+def test_survey_known_pixels(scenes):
+    x, _, _ = O.render(scenes["scene"], 256, 256, threads=4)
+    assert x[128, 128] == 0x000018
+    x4, _, _ = O.render(scenes["scene4"], 256, 256, threads=4)
+    assert x4[128, 128] == 0xB6D8CA and x4[0, 0] == 0
+
+
+@pytest.mark.parametrize("name,w,h,sdf_per_px", [("scene", 256, 256, 35.0), ("scene", 480, 270, 39.1),
+                                                 ("scene4", 256, 256, 84.3)])
+def test_survey_work_counters(scenes, name, w, h, sdf_per_px):
+    _, _, c = O.render(scenes[name], w, h, threads=4, want_counters=True)
+    assert round(c.sdf_evals / c.pixels, 1) == sdf_per_px
+    assert c.sdf_evals == c.march_steps + c.shadow_steps + 4 * c.pixels
+    nodes = {"scene": 4, "scene4": 10}[name]
+    assert c.node_evals == nodes * c.sdf_evals
+
+
+def test_survey_frame_hashes_are_not_reproduced(scenes):
+    """Recorded honestly: the survey's FNV hashes of whole frames (scenes entered by hand there) do not
+    match this oracle's frames, although the known pixels and work counters above do.  If this test ever
+    starts failing (= a hash matches), upgrade it to an equality pin."""
+    survey = {("scene", 256, 256): 0x0BB4455C37481D40, ("scene4", 256, 256): 0x33D944995ECB6BAB}
+    for (name, w, h), want in survey.items():
+        x, _, _ = O.render(scenes[name], w, h, threads=4)
+        assert O.hash_xrgb(x) != want
+
+
+# ---- regression frames of the oracle ---------------------------------------------------------------
+
+def test_oracle_regression_frames(scenes):
+    gold = np.load(os.path.join(HERE, "golden", "oracle_frames.npz"))
+    for key in gold.files:
+        if not key.endswith("_xrgb"):
+            continue
+        name, size = key.split("_")[0], key.split("_")[1]
+        w, h = (int(v) for v in size.split("x"))
+        x, rgb, _ = O.render(scenes[name], w, h, threads=4, want_rgb=True)
+        assert np.array_equal(x, gold[key]), key
+        rk = key.replace("_xrgb", "_rgb")
+        if rk in gold.files:
+            assert np.array_equal(rgb.view(np.uint32), gold[rk].view(np.uint32)), rk
+
+
+def test_threads_and_row_ranges_agree(scenes):
+    sc = scenes["scene4"]
+    a, _, _ = O.render(sc, 96, 54, threads=1)
+    b, _, _ = O.render(sc, 96, 54, threads=7)
+    c, _, _ = O.render_rows(sc, 96, 54, 10, 20)
+    assert np.array_equal(a, b) and np.array_equal(a[10:20], c[10:20]) and not c[:10].any()
+
+
+def test_max_steps_zero_and_empty_scene():
+    sc = S.Scene.parse_string("materials { { shininess = 2, diffuse = (1,1,1), specular = (1,1,1), ambient = (1,1,1) } }"
+                              " scene { ambient { color = (0.5, 0.25, 0.125) } }")
+    x, rgb, c = O.render(sc, 8, 4, want_rgb=True, want_counters=True)
+    # no objects: sdf = +inf, miss material #0, ambient * mat.ambient, gamma
+    want = np.power(np.array([0.5, 0.25, 0.125], dtype=np.float32), np.float32(1 / 2.2))
+    assert np.allclose(rgb[0, 0], want, atol=1e-6) and c.miss_pixels == 32
