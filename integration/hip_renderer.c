@@ -1,0 +1,106 @@
+/*
+ * hip_renderer.c — loltracer renderer plug-in backed by the MI355X kernel.
+ *
+ * Implements the three entry points of the reference's renderer.h:24-26 with
+ * the same protocol as naive_renderer.c:195-247, so it links in its place
+ * (`make hip`):
+ *
+ *   render_prepare  once, main thread, workers already parked on the entry
+ *                   semaphore (main.c:147-161): create the GPU context,
+ *                   flatten the scene, upload it.  Renderer flags start at
+ *                   argv[3] (main.c:223-242): --device N, --max-steps N.
+ *   render_thread   every worker: wait entry → return 0 if exiting → work →
+ *                   post exit exactly once (naive_renderer.c:203-205,238).
+ *                   The reference's workers claim one row at a time with
+ *                   SDL_AtomicAdd(&current_line, 1); here the worker whose
+ *                   SDL_AtomicAdd(&current_line, height) returns 0 has claimed
+ *                   every row: it launches the frame on the GPU and copies it
+ *                   into surf->pixels honouring pitch; the others see
+ *                   current_line >= height and fall through.
+ *   render_destroy  once, after the workers were joined (main.c:166-171,213).
+ *
+ * Errors follow the reference's style: message on stderr, keep going
+ * (naive_renderer.c:26); there is no CPU rendering fallback — a failed frame
+ * leaves the surface untouched.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "hip_renderer_host.h"
+#include "lol_gpu.h"
+#include "lol_scene.h"
+
+struct hip_renderer {
+	lol_gpu*    gpu;
+	lol_program program;
+	int         max_steps;      /* MAX_STEPS, naive_renderer.c:49 */
+	int         ready;
+};
+
+void render_prepare(struct render_data* data, int argc, const char* argv[]) {
+	struct hip_renderer* r = calloc(1, sizeof *r);
+	int device = 0;
+	HOST_PRIVATE(data) = r;
+	if (!r) { fprintf(stderr, "hip_renderer: out of memory\n"); return; }
+	r->max_steps = 256;
+	for (int i = 3; i + 1 < argc; i++) {
+		if (!strcmp(argv[i], "--device")) device = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "--max-steps")) r->max_steps = atoi(argv[++i]);
+	}
+
+	const lol_scene* scene = HOST_SCENE_TO_LOL(data->scene);
+	int st = scene ? lol_scene_flatten(scene, &r->program) : LOL_ERR_NOMEM;
+#ifdef LOL_HOST_SDL
+	lol_scene_free((lol_scene*)scene);      /* the converted copy; the program holds everything */
+#endif
+	if (st != LOL_OK) { fprintf(stderr, "hip_renderer: cannot flatten scene: %s\n", lol_status_str(st)); return; }
+
+	st = lol_gpu_create(device, &r->gpu);
+	if (st != LOL_GPU_OK) { fprintf(stderr, "hip_renderer: no usable HIP device %d (status %d)\n", device, st); return; }
+	st = lol_gpu_upload_program(r->gpu, &r->program);
+	if (st != LOL_GPU_OK) { fprintf(stderr, "hip_renderer: %s\n", lol_gpu_error(r->gpu)); return; }
+	r->ready = 1;
+}
+
+int render_thread(void* ptr) {
+	struct render_data* data = ptr;
+
+	for (;;) {
+		HOST_SEM_WAIT(frame_entry_barrier);
+		if (HOST_ATOMIC_GET(&exiting))
+			return 0;
+
+		host_surface* surf = data->surf;
+		const int width = surf->w, height = surf->h;
+
+		/* claim all rows at once; exactly one worker gets 0 back */
+		if (height > 0 && HOST_ATOMIC_ADD(&current_line, height) == 0) {
+			struct hip_renderer* r = HOST_PRIVATE(data);
+			if (!r || !r->ready) {
+				fprintf(stderr, "hip_renderer: not initialised, frame skipped\n");
+			} else if (HOST_SURF_BPP(surf) != 4) {
+				fprintf(stderr, "hip_renderer: only 32-bit surfaces are supported\n");
+			} else {
+				lol_camera cam;
+				lol_frame_camera fc;
+				HOST_SCENE_CAMERA(data->scene, &cam);   /* the host moves the camera between frames (main.c:180) */
+				lol_frame_camera_init(&fc, &cam, width, height);
+				int st = lol_gpu_render_host(r->gpu, &fc, width, height, r->max_steps,
+				                             surf->pixels, (size_t)surf->pitch);
+				if (st != LOL_GPU_OK)
+					fprintf(stderr, "hip_renderer: %s\n", lol_gpu_error(r->gpu));
+			}
+		}
+
+		HOST_SEM_POST(frame_exit_barrier);
+	}
+}
+
+void render_destroy(struct render_data* data) {
+	struct hip_renderer* r = HOST_PRIVATE(data);
+	if (!r) return;
+	lol_gpu_destroy(r->gpu);
+	free(r);
+	HOST_PRIVATE(data) = NULL;
+}

@@ -20,6 +20,7 @@ def _built():
     """Make sure the in-tree libraries exist (the prebuilt .so files travel with the repo snapshot)."""
     need = [os.path.join(ROOT, "loltracer_amd", "lib", "liblol_scene.so"),
             os.path.join(ROOT, "loltracer_amd", "lib", "liblol_gpu.so"),
+            os.path.join(ROOT, "loltracer_amd", "lib", "lol_headless"),
             os.path.join(ROOT, "oracle", "liblol_oracle.so")]
     if not all(os.path.exists(p) for p in need):
         import __graft_entry__ as g

@@ -1,0 +1,66 @@
+"""The C host side of the drop-in: integration/lol_headless.c drives integration/hip_renderer.c
+(render_prepare / render_thread / render_destroy) with main.c's semaphore protocol."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "loltracer_amd", "lib", "lol_headless")
+SCENE4 = os.path.join(ROOT, "tests", "golden", "scenes", "scene4.lol")
+
+
+def read_ppm(path):
+    data = open(path, "rb").read()
+    parts = data.split(b"\n", 3)
+    assert parts[0] == b"P6"
+    w, h = (int(v) for v in parts[1].split())
+    return np.frombuffer(parts[3], dtype=np.uint8).reshape(h, w, 3)
+
+
+def test_protocol_completes_and_fails_loudly_without_a_gpu(tmp_path):
+    from loltracer_amd import gpu
+    if gpu.gpu_lib().lol_gpu_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    p = subprocess.run([HOST, "3", SCENE4, "--size", "32x16", "--frames", "2"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0                      # the frame barrier protocol still balances
+    assert "no usable HIP device" in p.stderr and "frame skipped" in p.stderr
+    assert "Frame 2" in p.stdout and "Cerrando" in p.stdout
+
+
+def test_bad_scene_is_reported():
+    bad = os.path.join(ROOT, "tests", "golden", "scenes", "missing.lol")
+    p = subprocess.run([HOST, "1", bad], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 1 and "cannot open scene file" in p.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads", [1, 5])
+def test_c_host_renders_through_the_plugin(tmp_path, scenes, threads):
+    out = tmp_path / "f.ppm"
+    w, h = 160, 90
+    p = subprocess.run([HOST, str(threads), SCENE4, "--size", f"{w}x{h}", "--frames", "3", "--out", str(out)],
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    assert "hip_renderer" not in p.stderr
+    img = read_ppm(out).astype(np.int32)
+    ox, _, _ = O.render(scenes["scene4"], w, h, threads=4)
+    want = np.stack([(ox >> 16) & 0xFF, (ox >> 8) & 0xFF, ox & 0xFF], axis=-1).astype(np.int32)
+    assert np.abs(img - want).max() <= 1
+    assert "Frame 3" in p.stdout
+
+
+@pytest.mark.gpu
+def test_c_host_max_steps_flag(tmp_path, scenes):
+    out = tmp_path / "f.ppm"
+    w, h = 96, 54
+    p = subprocess.run([HOST, "2", SCENE4, "--size", f"{w}x{h}", "--out", str(out), "--max-steps", "9"],
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    img = read_ppm(out).astype(np.int32)
+    ox, _, _ = O.render(scenes["scene4"], w, h, max_steps=9, threads=4)
+    want = np.stack([(ox >> 16) & 0xFF, (ox >> 8) & 0xFF, ox & 0xFF], axis=-1).astype(np.int32)
+    assert np.abs(img - want).max() <= 1
