@@ -108,8 +108,22 @@ int lol_gpu_malloc(lol_gpu* ctx, size_t bytes, void** out);
 int lol_gpu_free(lol_gpu* ctx, void* ptr);
 int lol_gpu_memcpy_d2h(lol_gpu* ctx, void* host, const void* dev, size_t bytes);
 
-/* Name of the kernel a launch uses (for matching rocprofv3 kernel-trace rows). */
+/* Name of the kernel a launch uses (for matching rocprofv3 kernel-trace rows):
+ * "lol_render_spec" (scene-specialised, compiled by hipRTC at upload) or "render_interp". */
 const char* lol_gpu_kernel_name(const lol_gpu* ctx);
+
+/*
+ * Scene specialisation (the GPU analogue of the reference's tracing JIT, whose render_prepare
+ * compiles the scene's SDF to x86 — tracing_jit_renderer.dasc:416-434).  lol_gpu_upload_program()
+ * generates the scene's SDF as straight-line HIP and compiles it with hipRTC; when that is
+ * disabled (set_specialize(ctx, 0) before the upload, or LOL_GPU_SPECIALIZE=0) or fails, frames
+ * are rendered by the ahead-of-time interpreter kernel instead — same bits either way.
+ */
+int         lol_gpu_set_specialize(lol_gpu* ctx, int enable);
+const char* lol_gpu_specialize_log(const lol_gpu* ctx);
+/* No device needed: writes <out_base>.hip (generated source) and <out_base>.co (code object for `arch`). */
+int         lol_gpu_compile_offline(const lol_program* prog, const char* arch, const char* out_base,
+                                    char* log, size_t logcap);
 
 #ifdef __cplusplus
 }

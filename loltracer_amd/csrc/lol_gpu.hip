@@ -1,18 +1,43 @@
 /*
- * lol_gpu.hip — C ABI (include/lol_gpu.h) over the gfx950 render kernel (lol_kernel.h).
+ * lol_gpu.hip — C ABI (include/lol_gpu.h) over the gfx950 render kernels (lol_kernel.h).
  *
  * Host side of the drop-in: context = {device, stream, device copy of the
- * flattened scene, a device framebuffer for the host-surface path}.  No CPU
- * rendering path exists here; without a HIP device every call fails.
+ * flattened scene, the scene-specialised kernel, a device framebuffer for the
+ * host-surface path}.  No CPU rendering path exists here; without a HIP device
+ * every call fails.
+ *
+ * Two kernels render the same bits:
+ *  - render_interp<STACK>   compiled ahead of time; interprets the op list from LDS;
+ *  - lol_render_spec        compiled by hipRTC in lol_gpu_upload_program() from
+ *    lol_kernel.h + a generated SpecSdf::eval() — the scene's SDF as straight-line
+ *    code with immediates (the GPU analogue of tracing_jit_renderer.dasc:76-216,
+ *    whose render_prepare JIT-compiles the scene the same way).  Used when the
+ *    compile succeeds (LOL_GPU_SPECIALIZE=0 or lol_gpu_set_specialize(ctx,0)
+ *    keep the interpreter).
  */
 #include "lol_gpu.h"
 #include "lol_kernel.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
+#include <vector>
+
+/* lol_kernel.h's text, embedded at build time (csrc/Makefile: lol_kernel_src.inc) for hipRTC */
+#include "lol_kernel_src.inc"
+
+static_assert(sizeof(lol_op) == lol::OP_DWORDS * 4, "lol_op layout");
+static_assert(sizeof(lol_light) == lol::LIGHT_DWORDS * 4, "lol_light layout");
+static_assert(sizeof(lol_material) == lol::MATERIAL_DWORDS * 4, "lol_material layout");
+static_assert(sizeof(lol_frame_camera) == sizeof(lol::Cam), "lol_frame_camera layout");
+static_assert(offsetof(lol_op, f) == 8 && offsetof(lol_op, id) == 4, "lol_op fields");
+static_assert(LOL_OP_SPHERE == lol::OP_SPHERE && LOL_OP_RBOX == lol::OP_RBOX && LOL_OP_PLANE == lol::OP_PLANE &&
+              LOL_OP_SMIN == lol::OP_SMIN && LOL_OP_SMIN_R == lol::OP_SMIN_R && LOL_OP_TOP == lol::OP_TOP, "opcodes");
 
 struct lol_gpu {
 	int          device = -1;
@@ -22,7 +47,12 @@ struct lol_gpu {
 	bool         have_prog = false;
 	uint32_t*    d_frame = nullptr;      /* framebuffer for lol_gpu_render_host */
 	size_t       frame_bytes = 0;
-	char         err[256] = { 0 };
+	int          want_spec = 1;
+	hipModule_t  spec_module = nullptr;
+	hipFunction_t spec_fn = nullptr;
+	std::string  spec_log;
+	char         err[512] = { 0 };
+	char         kernel_name[64] = "render_interp";
 };
 
 namespace {
@@ -42,9 +72,135 @@ int fail(lol_gpu* ctx, int status, const char* what, hipError_t e = hipSuccess) 
 	} while (0)
 
 template <int STACK>
-hipError_t launch(const lol::Launch& L, dim3 grid, size_t lds, hipStream_t s) {
-	hipLaunchKernelGGL(lol::render_kernel<STACK>, grid, dim3(lol::BLOCK), lds, s, L);
+hipError_t launch_interp(const lol::Launch& L, dim3 grid, size_t lds, hipStream_t s) {
+	hipLaunchKernelGGL(lol::render_interp<STACK>, grid, dim3(lol::BLOCK), lds, s, L);
 	return hipGetLastError();
+}
+
+/* ------------------------------------------------- scene → HIP source (the "JIT") */
+
+std::string fbits(float v) {
+	uint32_t u;
+	memcpy(&u, &v, 4);
+	char b[48];
+	snprintf(b, sizeof b, "__builtin_bit_cast(float, 0x%08xu)", u);
+	return b;
+}
+
+/* Emits SpecSdf::eval(): one SSA temporary per op, same operation order as the interpreter. */
+std::string generate_source(const lol_program& P) {
+	std::string s;
+	s += "#include \"lol_kernel.h\"\n";
+	s += "namespace lol {\n";
+	s += "struct SpecSdf {\n";
+	s += "\t__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id) const {\n";
+	s += "\t\tbest = __builtin_inff(); best_id = 0u;\n";
+	std::vector<int> stack;
+	int t = 0;
+	char line[512];
+	for (uint32_t i = 0; i < P.n_ops; i++) {
+		const lol_op& o = P.ops[i];
+		switch (o.op) {
+		case LOL_OP_SPHERE:
+			snprintf(line, sizeof line, "\t\tconst float t%d = sd_sphere(p, %s, %s, %s, %s);\n", t,
+			         fbits(o.f[0]).c_str(), fbits(o.f[1]).c_str(), fbits(o.f[2]).c_str(), fbits(o.f[3]).c_str());
+			s += line; stack.push_back(t++); break;
+		case LOL_OP_RBOX:
+			snprintf(line, sizeof line, "\t\tconst float t%d = sd_round_box(p, %s, %s, %s, %s, %s, %s, %s);\n", t,
+			         fbits(o.f[0]).c_str(), fbits(o.f[1]).c_str(), fbits(o.f[2]).c_str(), fbits(o.f[3]).c_str(),
+			         fbits(o.f[4]).c_str(), fbits(o.f[5]).c_str(), fbits(o.f[6]).c_str());
+			s += line; stack.push_back(t++); break;
+		case LOL_OP_PLANE:
+			snprintf(line, sizeof line, "\t\tconst float t%d = p.y - %s;\n", t, fbits(o.f[0]).c_str());
+			s += line; stack.push_back(t++); break;
+		case LOL_OP_SMIN: case LOL_OP_SMIN_R: {
+			int top = stack.back(); stack.pop_back();
+			int under = stack.back(); stack.pop_back();
+			int a = o.op == LOL_OP_SMIN ? under : top, b = o.op == LOL_OP_SMIN ? top : under;
+			snprintf(line, sizeof line, "\t\tconst float t%d = sminf_(t%d, t%d, %s);\n", t, a, b, fbits(o.f[0]).c_str());
+			s += line; stack.push_back(t++); break;
+		}
+		case LOL_OP_TOP: {
+			int d = stack.back(); stack.pop_back();
+			snprintf(line, sizeof line, "\t\tif (t%d < best) { best = t%d; best_id = %uu; }\n", d, d, o.id);
+			s += line; break;
+		}
+		}
+	}
+	s += "\t}\n};\n";
+	s += "}  // namespace lol\n";
+	s += "extern \"C\" __global__ __launch_bounds__(lol::BLOCK) void lol_render_spec(const lol::Launch L) {\n";
+	s += "\textern __shared__ lol::u32 lds[];\n";
+	s += "\tlol::stage_common(L, lds);\n";
+	s += "\t__syncthreads();\n";
+	s += "\tlol::SpecSdf sdf;\n";
+	s += "\tlol::render_pixels(L, sdf, lds);\n";
+	s += "}\n";
+	return s;
+}
+
+/* hipRTC: generated source + lol_kernel.h → code object for `arch`.  Needs no device. */
+bool compile_spec(const lol_program& P, const std::string& arch, std::vector<char>& code, std::string& log,
+                  std::string* src_out = nullptr) {
+	std::string src = generate_source(P);
+	if (src_out) *src_out = src;
+	const char* hdr_src[] = { LOL_KERNEL_H_TEXT };
+	const char* hdr_name[] = { "lol_kernel.h" };
+	hiprtcProgram prog = nullptr;
+	if (hiprtcCreateProgram(&prog, src.c_str(), "lol_render_spec.hip", 1, hdr_src, hdr_name) != HIPRTC_SUCCESS) {
+		log = "hiprtcCreateProgram failed";
+		return false;
+	}
+	std::string arch_opt = "--offload-arch=" + arch;
+	/* -ffp-contract=off: no FMA contraction (the reference has none); the rest are hipcc's defaults made explicit */
+	const char* opts[] = { arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math" };
+	hiprtcResult r = hiprtcCompileProgram(prog, (int)(sizeof opts / sizeof opts[0]), opts);
+	size_t log_size = 0;
+	hiprtcGetProgramLogSize(prog, &log_size);
+	log.clear();
+	if (log_size > 1) { log.resize(log_size); hiprtcGetProgramLog(prog, &log[0]); }
+	if (r != HIPRTC_SUCCESS) {
+		log = std::string("hipRTC: ") + hiprtcGetErrorString(r) + "\n" + log;
+		hiprtcDestroyProgram(&prog);
+		return false;
+	}
+	size_t code_size = 0;
+	hiprtcGetCodeSize(prog, &code_size);
+	code.resize(code_size);
+	hiprtcGetCode(prog, code.data());
+	hiprtcDestroyProgram(&prog);
+	return true;
+}
+
+/* Compile + load the specialised kernel for ctx's program.  On failure the context keeps the interpreter. */
+bool specialise(lol_gpu* ctx) {
+	if (ctx->spec_module) { (void)hipModuleUnload(ctx->spec_module); ctx->spec_module = nullptr; ctx->spec_fn = nullptr; }
+	snprintf(ctx->kernel_name, sizeof ctx->kernel_name, "render_interp");
+	ctx->spec_log.clear();
+	const char* env = getenv("LOL_GPU_SPECIALIZE");
+	if (!ctx->want_spec || (env && env[0] == '0')) return false;
+
+	hipDeviceProp_t prop;
+	std::string arch = "gfx950";
+	if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.gcnArchName[0]) {
+		std::string name = prop.gcnArchName;             /* e.g. "gfx950:sramecc+:xnack-" */
+		arch = name.substr(0, name.find(':'));
+	}
+	std::vector<char> code;
+	if (!compile_spec(ctx->h_prog, arch, code, ctx->spec_log)) return false;
+	if (hipModuleLoadData(&ctx->spec_module, code.data()) != hipSuccess) {
+		ctx->spec_log = "hipModuleLoadData failed";
+		ctx->spec_module = nullptr;
+		return false;
+	}
+	if (hipModuleGetFunction(&ctx->spec_fn, ctx->spec_module, "lol_render_spec") != hipSuccess) {
+		ctx->spec_log = "lol_render_spec not found in the compiled module";
+		(void)hipModuleUnload(ctx->spec_module);
+		ctx->spec_module = nullptr; ctx->spec_fn = nullptr;
+		return false;
+	}
+	snprintf(ctx->kernel_name, sizeof ctx->kernel_name, "lol_render_spec");
+	return true;
 }
 
 }  // namespace
@@ -81,12 +237,21 @@ void lol_gpu_destroy(lol_gpu* ctx) {
 	if (!ctx) return;
 	if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
 	if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+	if (ctx->spec_module) (void)hipModuleUnload(ctx->spec_module);
 	if (ctx->d_prog) (void)hipFree(ctx->d_prog);
 	if (ctx->d_frame) (void)hipFree(ctx->d_frame);
 	delete ctx;
 }
 
 const char* lol_gpu_error(const lol_gpu* ctx) { return ctx ? ctx->err : "null context"; }
+
+int lol_gpu_set_specialize(lol_gpu* ctx, int enable) {
+	if (!ctx) return LOL_GPU_ERR_ARG;
+	ctx->want_spec = enable ? 1 : 0;
+	return LOL_GPU_OK;
+}
+
+const char* lol_gpu_specialize_log(const lol_gpu* ctx) { return ctx ? ctx->spec_log.c_str() : ""; }
 
 int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog) {
 	if (!ctx || !prog) return LOL_GPU_ERR_ARG;
@@ -120,6 +285,7 @@ int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog) {
 	LOL_HIP(ctx, hipMemcpy(ctx->d_prog, prog, sizeof *prog, hipMemcpyHostToDevice));
 	ctx->h_prog = *prog;
 	ctx->have_prog = true;
+	specialise(ctx);
 	return LOL_GPU_OK;
 }
 
@@ -155,14 +321,19 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 
 	lol::Launch L;
 	memset(&L, 0, sizeof L);
-	L.cam = *cam;
+	memcpy(&L.cam, cam, sizeof L.cam);
 	L.fw = (float)w; L.fh = (float)h;
 	L.w = w; L.h = h; L.max_steps = max_steps;
 	L.n_rows = n_rows;
 	L.band_rows = R->band_rows; L.n_parts = R->n_parts; L.part = R->part;
-	L.n_ops = ctx->h_prog.n_ops; L.n_lights = ctx->h_prog.n_lights;
-	L.n_materials = ctx->h_prog.n_materials; L.n_roots = ctx->h_prog.n_roots;
-	L.prog = ctx->d_prog;
+	const lol_program& P = ctx->h_prog;
+	L.n_ops = P.n_ops; L.n_lights = P.n_lights; L.n_materials = P.n_materials; L.n_roots = P.n_roots;
+	const char* base = reinterpret_cast<const char*>(ctx->d_prog);
+	L.ops           = reinterpret_cast<const uint32_t*>(base + offsetof(lol_program, ops));
+	L.lights        = reinterpret_cast<const uint32_t*>(base + offsetof(lol_program, lights));
+	L.materials     = reinterpret_cast<const uint32_t*>(base + offsetof(lol_program, materials));
+	L.root_material = reinterpret_cast<const uint32_t*>(base + offsetof(lol_program, root_material));
+	L.ambient[0] = P.ambient_color.x; L.ambient[1] = P.ambient_color.y; L.ambient[2] = P.ambient_color.z;
 	L.dst = static_cast<uint32_t*>(dst);
 	L.pitch_px = (uint32_t)(pitch_bytes / 4);
 	if (dbg) {
@@ -171,14 +342,20 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	}
 
 	dim3 grid((w + lol::TILE_W - 1) / lol::TILE_W, (n_rows + lol::TILE_H - 1) / lol::TILE_H);
-	size_t lds = lol::lds_bytes(L);
+	size_t common = (size_t)lol::common_lds_dwords(P.n_lights, P.n_materials, P.n_roots) * 4;
 	hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
 	LOL_HIP(ctx, hipSetDevice(ctx->device));
 	hipError_t e;
-	uint32_t need = ctx->h_prog.max_stack;
-	if (need <= 2)      e = launch<2>(L, grid, lds, s);
-	else if (need <= 4) e = launch<4>(L, grid, lds, s);
-	else                e = launch<LOL_MAX_STACK>(L, grid, lds, s);
+	if (ctx->spec_fn) {
+		void* args[] = { &L };
+		e = hipModuleLaunchKernel(ctx->spec_fn, grid.x, grid.y, 1, lol::BLOCK, 1, 1, (unsigned)common, s, args, nullptr);
+	} else {
+		size_t lds = common + (size_t)P.n_ops * lol::OP_DWORDS * 4;
+		uint32_t need = P.max_stack;
+		if (need <= 2)      e = launch_interp<2>(L, grid, lds, s);
+		else if (need <= 4) e = launch_interp<4>(L, grid, lds, s);
+		else                e = launch_interp<LOL_MAX_STACK>(L, grid, lds, s);
+	}
 	if (e != hipSuccess) return fail(ctx, LOL_GPU_ERR_HIP, "kernel launch", e);
 	return LOL_GPU_OK;
 }
@@ -232,9 +409,22 @@ int lol_gpu_memcpy_d2h(lol_gpu* ctx, void* host, const void* dev, size_t bytes) 
 	return LOL_GPU_OK;
 }
 
-const char* lol_gpu_kernel_name(const lol_gpu* ctx) {
-	(void)ctx;
-	return "render_kernel";
+const char* lol_gpu_kernel_name(const lol_gpu* ctx) { return ctx ? ctx->kernel_name : ""; }
+
+/* Offline use (tests, ISA inspection; needs no device): compile the scene-specialised kernel for
+ * `arch` and write `<out_base>.hip` (generated source) and `<out_base>.co` (code object). */
+int lol_gpu_compile_offline(const lol_program* prog, const char* arch, const char* out_base, char* log, size_t logcap) {
+	if (!prog || !arch) return LOL_GPU_ERR_ARG;
+	std::vector<char> code;
+	std::string lg, src;
+	bool ok = compile_spec(*prog, arch, code, lg, &src);
+	if (log && logcap) snprintf(log, logcap, "%s", lg.c_str());
+	if (out_base && out_base[0]) {
+		std::string base = out_base;
+		if (FILE* f = fopen((base + ".hip").c_str(), "w")) { fputs(src.c_str(), f); fclose(f); }
+		if (ok) if (FILE* f = fopen((base + ".co").c_str(), "wb")) { fwrite(code.data(), 1, code.size(), f); fclose(f); }
+	}
+	return ok ? LOL_GPU_OK : LOL_GPU_ERR_UNSUPPORTED;
 }
 
 }  // extern "C"

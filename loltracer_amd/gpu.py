@@ -75,6 +75,12 @@ def gpu_lib() -> C.CDLL:
         lib.lol_gpu_memcpy_d2h.restype = C.c_int
         lib.lol_gpu_kernel_name.argtypes = [vp]
         lib.lol_gpu_kernel_name.restype = C.c_char_p
+        lib.lol_gpu_set_specialize.argtypes = [vp, C.c_int]
+        lib.lol_gpu_set_specialize.restype = C.c_int
+        lib.lol_gpu_specialize_log.argtypes = [vp]
+        lib.lol_gpu_specialize_log.restype = C.c_char_p
+        lib.lol_gpu_compile_offline.argtypes = [P(S.Program), C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
+        lib.lol_gpu_compile_offline.restype = C.c_int
         _lib = lib
     return _lib
 
@@ -82,8 +88,18 @@ def gpu_lib() -> C.CDLL:
 EXPORTED_SYMBOLS = [
     "lol_gpu_device_count", "lol_gpu_create", "lol_gpu_destroy", "lol_gpu_error", "lol_gpu_upload_program",
     "lol_gpu_part_rows", "lol_gpu_render_device", "lol_gpu_render_host", "lol_gpu_sync", "lol_gpu_malloc",
-    "lol_gpu_free", "lol_gpu_memcpy_d2h", "lol_gpu_kernel_name",
+    "lol_gpu_free", "lol_gpu_memcpy_d2h", "lol_gpu_kernel_name", "lol_gpu_set_specialize",
+    "lol_gpu_specialize_log", "lol_gpu_compile_offline",
 ]
+
+
+def compile_offline(program: S.Program, out_base: str, arch: str = "gfx950") -> str:
+    """hipRTC-compile the scene-specialised kernel without a device; returns the compiler log."""
+    log = C.create_string_buffer(1 << 16)
+    st = gpu_lib().lol_gpu_compile_offline(C.byref(program), arch.encode(), os.fsencode(out_base), log, len(log))
+    if st != LOL_GPU_OK:
+        raise GpuError(st, "hipRTC compile failed:\n" + log.value.decode(errors="replace"))
+    return log.value.decode(errors="replace")
 
 
 def part_rows(h: int, rows: Rows | None) -> int:
@@ -91,13 +107,14 @@ def part_rows(h: int, rows: Rows | None) -> int:
 
 
 class Renderer:
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, specialize: bool = True):
         self._lib = gpu_lib()
         self._ctx = C.c_void_p()
         st = self._lib.lol_gpu_create(device, C.byref(self._ctx))
         if st != LOL_GPU_OK:
             self._ctx = C.c_void_p()
             raise GpuError(st, f"lol_gpu_create(device={device}) failed")
+        self._lib.lol_gpu_set_specialize(self._ctx, 1 if specialize else 0)
         self.scene: S.Scene | None = None
         self.program: S.Program | None = None
 
@@ -139,6 +156,9 @@ class Renderer:
 
     def kernel_name(self) -> str:
         return self._lib.lol_gpu_kernel_name(self._ctx).decode()
+
+    def specialize_log(self) -> str:
+        return self._lib.lol_gpu_specialize_log(self._ctx).decode(errors="replace")
 
     # render_destroy (renderer.h:26)
     def close(self):

@@ -51,3 +51,18 @@ def test_no_gpu_is_a_loud_error_not_a_fallback():
     with pytest.raises(gpu.GpuError) as e:
         gpu.Renderer(0)
     assert e.value.status == -1
+
+
+def test_scene_specialised_kernel_compiles_without_a_device(tmp_path, scenes):
+    """hipRTC cross-compiles the generated straight-line SDF for gfx950 (no GPU needed)."""
+    import subprocess
+    for name in ("scene", "scene4"):
+        base = str(tmp_path / name)
+        gpu.compile_offline(scenes[name].flatten(), base)
+        src = open(base + ".hip").read()
+        assert "lol_render_spec" in src and "sd_sphere" in src
+        assert os.path.getsize(base + ".co") > 1000
+    src4 = open(str(tmp_path / "scene4") + ".hip").read()
+    assert src4.count("sminf_(") == 4 and src4.count("sd_sphere(") == 5 and "best_id = 2u" in src4
+    # constants are emitted as exact bit patterns: sphere radius 0.5 and smoothness 3
+    assert "0x3f000000u" in src4 and "0x40400000u" in src4

@@ -25,9 +25,11 @@ def torch_cuda():
     return torch
 
 
-@pytest.fixture(scope="module")
-def renderer(torch_cuda):
-    r = gpu.Renderer(0)
+@pytest.fixture(scope="module", params=[True, False], ids=["spec", "interp"])
+def renderer(torch_cuda, request):
+    """Both kernels: the hipRTC scene-specialised one and the ahead-of-time LDS interpreter."""
+    r = gpu.Renderer(0, specialize=request.param)
+    r.want_kernel = "lol_render_spec" if request.param else "render_interp"
     yield r
     r.close()
 
@@ -43,6 +45,7 @@ def gpu_render(torch, r, sc, w, h, max_steps=256, rows=None, camera=None, pitch_
     steps = torch.zeros((n_rows, w), dtype=torch.int32, device=dev)
     dbg = gpu.Debug(rgb.data_ptr(), dist.data_ptr(), hid.data_ptr(), steps.data_ptr())
     r.prepare(sc)
+    assert r.kernel_name() == getattr(r, "want_kernel", r.kernel_name()), r.specialize_log()
     r.render_into(frame.data_ptr(), w, h, max_steps, camera=camera, rows=rows, pitch_bytes=pitch_px * 4,
                   debug=dbg, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
