@@ -119,11 +119,21 @@ const char* lol_gpu_kernel_name(const lol_gpu* ctx);
  * disabled (set_specialize(ctx, 0) before the upload, or LOL_GPU_SPECIALIZE=0) or fails, frames
  * are rendered by the ahead-of-time interpreter kernel instead — same bits either way.
  */
+/* enable: 0 = interpreter only; 1 = specialise, with the proven-exact shortcuts; 3 = specialise without them */
 int         lol_gpu_set_specialize(lol_gpu* ctx, int enable);
 const char* lol_gpu_specialize_log(const lol_gpu* ctx);
-/* No device needed: writes <out_base>.hip (generated source) and <out_base>.co (code object for `arch`). */
+/*
+ * The specialised kernel may replace sqrt and the smooth-min division x/k by cheaper sequences
+ * (lol_kernel.h "fast exact paths").  Each is used only after the device has run ALL 2^32 float
+ * inputs through it and through the plain expression and found no difference; this call runs
+ * those checks directly and returns the mismatch counts (0 = proven; ~0 = could not run).
+ */
+int         lol_gpu_verify_fast_paths(lol_gpu* ctx, float k, unsigned long long* sqrt_mismatches,
+                                      unsigned long long* div_mismatches);
+/* No device needed: writes <out_base>.hip (generated source) and <out_base>.co (code object for `arch`).
+ * assume_fast != 0 generates the shortcuts without proof — for ISA inspection only, never for rendering. */
 int         lol_gpu_compile_offline(const lol_program* prog, const char* arch, const char* out_base,
-                                    char* log, size_t logcap);
+                                    int assume_fast, char* log, size_t logcap);
 
 #ifdef __cplusplus
 }

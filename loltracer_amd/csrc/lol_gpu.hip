@@ -26,6 +26,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 /* lol_kernel.h's text, embedded at build time (csrc/Makefile: lol_kernel_src.inc) for hipRTC */
@@ -51,6 +52,10 @@ struct lol_gpu {
 	hipModule_t  spec_module = nullptr;
 	hipFunction_t spec_fn = nullptr;
 	std::string  spec_log;
+	int          want_fast = 1;          /* allow the proven-exact shortcuts in the specialised kernel */
+	int          sqrt_verified = -1;     /* -1 not run, 0 failed, 1 proven on this device */
+	std::vector<std::pair<uint32_t, bool>> div_verified;   /* k bits → proven */
+	unsigned long long* d_bad = nullptr; /* mismatch counter of the verification kernels */
 	char         err[512] = { 0 };
 	char         kernel_name[64] = "render_interp";
 };
@@ -77,6 +82,52 @@ hipError_t launch_interp(const lol::Launch& L, dim3 grid, size_t lds, hipStream_
 	return hipGetLastError();
 }
 
+/* --------------------------------------------- exhaustive proofs of the fast paths
+ * Each kernel feeds all 2^32 float bit patterns through the shortcut and through the plain
+ * expression it replaces and counts the inputs on which they differ (same bits, or both NaN,
+ * count as equal).  A shortcut is generated into the specialised kernel only when the count is 0
+ * on the device that will run it. */
+__device__ __forceinline__ bool same_float(float a, float b) {
+	return __builtin_bit_cast(uint32_t, a) == __builtin_bit_cast(uint32_t, b) || (a != a && b != b);
+}
+constexpr unsigned VERIFY_BLOCKS = 65536, VERIFY_THREADS = 256, VERIFY_ITERS = 256;   /* product = 2^32 */
+
+__global__ __launch_bounds__(VERIFY_THREADS) void verify_sqrt_kernel(unsigned long long* bad) {
+	uint32_t base = blockIdx.x * VERIFY_THREADS + threadIdx.x;
+	unsigned n = 0;
+	for (uint32_t it = 0; it < VERIFY_ITERS; it++) {
+		float x = __builtin_bit_cast(float, base + it * (VERIFY_BLOCKS * VERIFY_THREADS));
+		/* sqrt_fast is only ever given a sum of squares (len2): never negative.  Below 2^-96 callers
+		 * take the plain path.  Everything else — 0, [2^-96, inf], NaN — must agree. */
+		bool excluded = x < 0.f || (x > 0.f && x < lol::SQRT_FAST_MIN);
+		if (!excluded && !same_float(lol::sqrt_fast(x), __builtin_sqrtf(x))) n++;
+	}
+	if (n) atomicAdd(bad, (unsigned long long)n);
+}
+
+__global__ __launch_bounds__(VERIFY_THREADS) void verify_div_kernel(float k, float rk, unsigned long long* bad) {
+	uint32_t base = blockIdx.x * VERIFY_THREADS + threadIdx.x;
+	unsigned n = 0;
+	for (uint32_t it = 0; it < VERIFY_ITERS; it++) {
+		float x = __builtin_bit_cast(float, base + it * (VERIFY_BLOCKS * VERIFY_THREADS));
+		if (!same_float(lol::smin_h_fast(x, k, rk), lol::smin_h_exact(x, k))) n++;
+	}
+	if (n) atomicAdd(bad, (unsigned long long)n);
+}
+
+/* returns mismatch count, or ~0ull when the check itself could not run */
+unsigned long long run_verify(lol_gpu* ctx, bool is_sqrt, float k) {
+	if (!ctx->d_bad && hipMalloc(reinterpret_cast<void**>(&ctx->d_bad), sizeof(unsigned long long)) != hipSuccess)
+		return ~0ull;
+	unsigned long long bad = 0;
+	if (hipMemcpy(ctx->d_bad, &bad, sizeof bad, hipMemcpyHostToDevice) != hipSuccess) return ~0ull;
+	if (is_sqrt) hipLaunchKernelGGL(verify_sqrt_kernel, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, ctx->d_bad);
+	else hipLaunchKernelGGL(verify_div_kernel, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, k, 1.0f / k, ctx->d_bad);
+	if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return ~0ull;
+	if (hipMemcpy(&bad, ctx->d_bad, sizeof bad, hipMemcpyDeviceToHost) != hipSuccess) return ~0ull;
+	return bad;
+}
+
 /* ------------------------------------------------- scene → HIP source (the "JIT") */
 
 std::string fbits(float v) {
@@ -87,28 +138,39 @@ std::string fbits(float v) {
 	return b;
 }
 
-/* Emits SpecSdf::eval(): one SSA temporary per op, same operation order as the interpreter. */
-std::string generate_source(const lol_program& P) {
-	std::string s;
-	s += "#include \"lol_kernel.h\"\n";
-	s += "namespace lol {\n";
-	s += "struct SpecSdf {\n";
-	s += "\t__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id) const {\n";
+/* Which proven-exact shortcuts the generated code may use (see lol_kernel.h "fast exact paths"). */
+struct FastPaths {
+	bool sqrt_ok = false;                 /* sqrt_fast verified on this device */
+	std::vector<float> div_ok;            /* smoothness constants k whose smin_h_fast verified */
+	bool has(float k) const {
+		for (float v : div_ok) if (memcmp(&v, &k, 4) == 0) return true;
+		return false;
+	}
+};
+
+/* Emits one `struct <name>` with eval(): one SSA temporary per op, same operation order as the interpreter. */
+void emit_sdf(std::string& s, const lol_program& P, const char* name, const FastPaths* fast) {
+	char line[640];
+	const bool fsqrt = fast && fast->sqrt_ok;
+	snprintf(line, sizeof line, "struct %s {\n\tu32 tiny = 0x7f800000u;\n", name);
+	s += line;
+	s += "\t__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id) {\n";
 	s += "\t\tbest = __builtin_inff(); best_id = 0u;\n";
 	std::vector<int> stack;
 	int t = 0;
-	char line[512];
 	for (uint32_t i = 0; i < P.n_ops; i++) {
 		const lol_op& o = P.ops[i];
 		switch (o.op) {
 		case LOL_OP_SPHERE:
-			snprintf(line, sizeof line, "\t\tconst float t%d = sd_sphere(p, %s, %s, %s, %s);\n", t,
-			         fbits(o.f[0]).c_str(), fbits(o.f[1]).c_str(), fbits(o.f[2]).c_str(), fbits(o.f[3]).c_str());
+			snprintf(line, sizeof line, "\t\tconst float t%d = sd_sphere%s(p, %s, %s, %s, %s%s);\n", t, fsqrt ? "_fast" : "",
+			         fbits(o.f[0]).c_str(), fbits(o.f[1]).c_str(), fbits(o.f[2]).c_str(), fbits(o.f[3]).c_str(),
+			         fsqrt ? ", tiny" : "");
 			s += line; stack.push_back(t++); break;
 		case LOL_OP_RBOX:
-			snprintf(line, sizeof line, "\t\tconst float t%d = sd_round_box(p, %s, %s, %s, %s, %s, %s, %s);\n", t,
+			snprintf(line, sizeof line, "\t\tconst float t%d = sd_round_box%s(p, %s, %s, %s, %s, %s, %s, %s%s);\n", t,
+			         fsqrt ? "_fast" : "",
 			         fbits(o.f[0]).c_str(), fbits(o.f[1]).c_str(), fbits(o.f[2]).c_str(), fbits(o.f[3]).c_str(),
-			         fbits(o.f[4]).c_str(), fbits(o.f[5]).c_str(), fbits(o.f[6]).c_str());
+			         fbits(o.f[4]).c_str(), fbits(o.f[5]).c_str(), fbits(o.f[6]).c_str(), fsqrt ? ", tiny" : "");
 			s += line; stack.push_back(t++); break;
 		case LOL_OP_PLANE:
 			snprintf(line, sizeof line, "\t\tconst float t%d = p.y - %s;\n", t, fbits(o.f[0]).c_str());
@@ -117,7 +179,11 @@ std::string generate_source(const lol_program& P) {
 			int top = stack.back(); stack.pop_back();
 			int under = stack.back(); stack.pop_back();
 			int a = o.op == LOL_OP_SMIN ? under : top, b = o.op == LOL_OP_SMIN ? top : under;
-			snprintf(line, sizeof line, "\t\tconst float t%d = sminf_(t%d, t%d, %s);\n", t, a, b, fbits(o.f[0]).c_str());
+			if (fast && fast->has(o.f[0]))
+				snprintf(line, sizeof line, "\t\tconst float t%d = sminf_fastdiv(t%d, t%d, %s, %s);\n", t, a, b,
+				         fbits(o.f[0]).c_str(), fbits(1.0f / o.f[0]).c_str());
+			else
+				snprintf(line, sizeof line, "\t\tconst float t%d = sminf_(t%d, t%d, %s);\n", t, a, b, fbits(o.f[0]).c_str());
 			s += line; stack.push_back(t++); break;
 		}
 		case LOL_OP_TOP: {
@@ -128,21 +194,45 @@ std::string generate_source(const lol_program& P) {
 		}
 	}
 	s += "\t}\n};\n";
+}
+
+/*
+ * The kernel shades every pixel with the fast SDF; a wave in which any squared length fell below
+ * SQRT_FAST_MIN (a sample within 2^-48 of a sphere centre) shades its pixels again with the plain
+ * SDF, so the shortcut never decides a result.
+ */
+std::string generate_source(const lol_program& P, const FastPaths* fast) {
+	std::string s;
+	s += "#include \"lol_kernel.h\"\n";
+	s += "namespace lol {\n";
+	emit_sdf(s, P, "SpecSdfExact", nullptr);
+	const bool any_fast = fast && (fast->sqrt_ok || !fast->div_ok.empty());
+	if (any_fast) emit_sdf(s, P, "SpecSdfFast", fast);
 	s += "}  // namespace lol\n";
 	s += "extern \"C\" __global__ __launch_bounds__(lol::BLOCK) void lol_render_spec(const lol::Launch L) {\n";
 	s += "\textern __shared__ lol::u32 lds[];\n";
 	s += "\tlol::stage_common(L, lds);\n";
 	s += "\t__syncthreads();\n";
-	s += "\tlol::SpecSdf sdf;\n";
-	s += "\tlol::render_pixels(L, sdf, lds);\n";
+	if (any_fast) {
+		s += "\tlol::SpecSdfFast fast;\n";
+		s += "\tlol::Pixel P = lol::shade_pixel(L, fast, lds);\n";
+		s += "\tif (__ballot(fast.tiny < lol::SQRT_FAST_MIN_BITS) != 0) {\n";
+		s += "\t\tlol::SpecSdfExact exact;\n";
+		s += "\t\tP = lol::shade_pixel(L, exact, lds);\n";
+		s += "\t}\n";
+	} else {
+		s += "\tlol::SpecSdfExact exact;\n";
+		s += "\tlol::Pixel P = lol::shade_pixel(L, exact, lds);\n";
+	}
+	s += "\tlol::store_pixel(L, P, lds);\n";
 	s += "}\n";
 	return s;
 }
 
 /* hipRTC: generated source + lol_kernel.h → code object for `arch`.  Needs no device. */
-bool compile_spec(const lol_program& P, const std::string& arch, std::vector<char>& code, std::string& log,
-                  std::string* src_out = nullptr) {
-	std::string src = generate_source(P);
+bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string& arch, std::vector<char>& code,
+                  std::string& log, std::string* src_out = nullptr) {
+	std::string src = generate_source(P, fast);
 	if (src_out) *src_out = src;
 	const char* hdr_src[] = { LOL_KERNEL_H_TEXT };
 	const char* hdr_name[] = { "lol_kernel.h" };
@@ -186,8 +276,33 @@ bool specialise(lol_gpu* ctx) {
 		std::string name = prop.gcnArchName;             /* e.g. "gfx950:sramecc+:xnack-" */
 		arch = name.substr(0, name.find(':'));
 	}
+	/* prove the shortcuts on this device before generating them */
+	FastPaths fast;
+	const char* fenv = getenv("LOL_GPU_FAST");
+	std::string note;
+	if (ctx->want_fast && !(fenv && fenv[0] == '0')) {
+		if (ctx->sqrt_verified < 0) ctx->sqrt_verified = run_verify(ctx, true, 0.f) == 0 ? 1 : 0;
+		fast.sqrt_ok = ctx->sqrt_verified == 1;
+		for (uint32_t i = 0; i < ctx->h_prog.n_ops; i++) {
+			const lol_op& o = ctx->h_prog.ops[i];
+			if (o.op != LOL_OP_SMIN && o.op != LOL_OP_SMIN_R) continue;
+			uint32_t kb;
+			memcpy(&kb, &o.f[0], 4);
+			bool known = false, ok = false;
+			for (auto& e : ctx->div_verified) if (e.first == kb) { known = true; ok = e.second; }
+			if (!known) {
+				ok = run_verify(ctx, false, o.f[0]) == 0;
+				ctx->div_verified.emplace_back(kb, ok);
+			}
+			if (ok && !fast.has(o.f[0])) fast.div_ok.push_back(o.f[0]);
+		}
+		char b[160];
+		snprintf(b, sizeof b, "fast paths proven on device: sqrt=%d, smin divisors=%zu\n", (int)fast.sqrt_ok, fast.div_ok.size());
+		note = b;
+	}
 	std::vector<char> code;
-	if (!compile_spec(ctx->h_prog, arch, code, ctx->spec_log)) return false;
+	if (!compile_spec(ctx->h_prog, &fast, arch, code, ctx->spec_log)) return false;
+	ctx->spec_log = note + ctx->spec_log;
 	if (hipModuleLoadData(&ctx->spec_module, code.data()) != hipSuccess) {
 		ctx->spec_log = "hipModuleLoadData failed";
 		ctx->spec_module = nullptr;
@@ -240,6 +355,7 @@ void lol_gpu_destroy(lol_gpu* ctx) {
 	if (ctx->spec_module) (void)hipModuleUnload(ctx->spec_module);
 	if (ctx->d_prog) (void)hipFree(ctx->d_prog);
 	if (ctx->d_frame) (void)hipFree(ctx->d_frame);
+	if (ctx->d_bad) (void)hipFree(ctx->d_bad);
 	delete ctx;
 }
 
@@ -248,6 +364,18 @@ const char* lol_gpu_error(const lol_gpu* ctx) { return ctx ? ctx->err : "null co
 int lol_gpu_set_specialize(lol_gpu* ctx, int enable) {
 	if (!ctx) return LOL_GPU_ERR_ARG;
 	ctx->want_spec = enable ? 1 : 0;
+	ctx->want_fast = enable >= 2 || enable == 1 ? 1 : 0;
+	if (enable == 3) ctx->want_fast = 0;          /* 3 = specialise, but without the fast exact paths */
+	return LOL_GPU_OK;
+}
+
+/* Run the exhaustive (all 2^32 inputs) equivalence checks directly: mismatch counts out. */
+int lol_gpu_verify_fast_paths(lol_gpu* ctx, float k, unsigned long long* sqrt_mismatches,
+                              unsigned long long* div_mismatches) {
+	if (!ctx) return LOL_GPU_ERR_ARG;
+	LOL_HIP(ctx, hipSetDevice(ctx->device));
+	if (sqrt_mismatches) *sqrt_mismatches = run_verify(ctx, true, 0.f);
+	if (div_mismatches) *div_mismatches = run_verify(ctx, false, k);
 	return LOL_GPU_OK;
 }
 
@@ -413,11 +541,19 @@ const char* lol_gpu_kernel_name(const lol_gpu* ctx) { return ctx ? ctx->kernel_n
 
 /* Offline use (tests, ISA inspection; needs no device): compile the scene-specialised kernel for
  * `arch` and write `<out_base>.hip` (generated source) and `<out_base>.co` (code object). */
-int lol_gpu_compile_offline(const lol_program* prog, const char* arch, const char* out_base, char* log, size_t logcap) {
+int lol_gpu_compile_offline(const lol_program* prog, const char* arch, const char* out_base, int assume_fast,
+                            char* log, size_t logcap) {
 	if (!prog || !arch) return LOL_GPU_ERR_ARG;
 	std::vector<char> code;
 	std::string lg, src;
-	bool ok = compile_spec(*prog, arch, code, lg, &src);
+	FastPaths fast;
+	if (assume_fast) {                 /* ISA inspection only: pretend every shortcut was proven */
+		fast.sqrt_ok = true;
+		for (uint32_t i = 0; i < prog->n_ops; i++)
+			if ((prog->ops[i].op == LOL_OP_SMIN || prog->ops[i].op == LOL_OP_SMIN_R) && !fast.has(prog->ops[i].f[0]))
+				fast.div_ok.push_back(prog->ops[i].f[0]);
+	}
+	bool ok = compile_spec(*prog, &fast, arch, code, lg, &src);
 	if (log && logcap) snprintf(log, logcap, "%s", lg.c_str());
 	if (out_base && out_base[0]) {
 		std::string base = out_base;

@@ -111,6 +111,62 @@ __device__ __forceinline__ float sd_round_box(V3 p, float cx, float cy, float cz
 	return len(cq) + minf_(maxf_(q.x, maxf_(q.y, q.z)), 0.f) - r;
 }
 
+/* ---------------------------------------------------------------- fast exact paths
+ * Used only by the hipRTC-specialised kernel, and only after lol_gpu.hip has PROVED them
+ * equal to the plain expressions by running every one of the 2^32 float inputs through
+ * both on the device (verify_sqrt_kernel / verify_div_kernel): same bits or both NaN.
+ *
+ * sqrt_fast: v_sqrt_f32 (1 ulp) + the +-1 ulp residual test hipcc's own expansion of a
+ * correctly rounded sqrt uses, minus its input scaling and class fix-up.  Exact for
+ * x == 0, x >= 2^-96, inf and NaN (v_sqrt_f32 flushes denormal inputs, so smaller positive x
+ * are NOT covered); its only argument is a sum of squares, never negative.  Callers flag
+ * 0 <= x < SQRT_FAST_MIN and redo the whole pixel through the plain path. */
+constexpr float SQRT_FAST_MIN = 0x1p-96f;
+__device__ __forceinline__ float sqrt_fast(float x) {
+	float r = __builtin_amdgcn_sqrtf(x);
+	int ri = __builtin_bit_cast(int, r);
+	float rm = __builtin_bit_cast(float, ri - 1), rp = __builtin_bit_cast(float, ri + 1);
+	float em = __builtin_fmaf(-rm, r, x);
+	float ep = __builtin_fmaf(-rp, r, x);
+	r = em <= 0.f ? rm : r;
+	r = ep > 0.f ? rp : r;
+	return r;
+}
+/* x / k for a scene constant k with rk = 1/k: product, one residual correction, then the
+ * hardware's special-case fix-up.  sminf_fastdiv() is what gets verified (over all x). */
+__device__ __forceinline__ float div_const(float x, float k, float rk) {
+	float q = x * rk;
+	float r = __builtin_fmaf(-q, k, x);
+	q = __builtin_fmaf(r, rk, q);
+	return __builtin_amdgcn_div_fixupf(q, k, x);
+}
+__device__ __forceinline__ float smin_h_exact(float x, float k) { return clampf_(.5f + x / k, 0.f, 1.f); }
+__device__ __forceinline__ float smin_h_fast(float x, float k, float rk) { return clampf_(.5f + div_const(x, k, rk), 0.f, 1.f); }
+/* sminf with the division replaced; x = .5f*(b-a) exactly as in sminf_ */
+__device__ __forceinline__ float sminf_fastdiv(float a, float b, float k, float rk) {
+	float h = smin_h_fast(.5f * (b - a), k, rk);
+	return (b + (a - b) * h) - k * h * (1.f - h);
+}
+/* sd_sphere on the fast sqrt.  `tiny` keeps the unsigned minimum of the squared lengths' bit
+ * patterns (for non-negative floats the bit order is the value order; NaN sorts above inf), so
+ * one compare against SQRT_FAST_MIN at the end of an evaluation covers every sqrt in it. */
+constexpr u32 SQRT_FAST_MIN_BITS = 0x0f800000u;      /* 2^-96 */
+__device__ __forceinline__ u32 umin_(u32 a, u32 b) { return a < b ? a : b; }
+__device__ __forceinline__ float sd_sphere_fast(V3 p, float cx, float cy, float cz, float r, u32& tiny) {
+	V3 q = { p.x - cx, p.y - cy, p.z - cz };
+	float l2 = len2(q);
+	tiny = umin_(tiny, __builtin_bit_cast(u32, l2));
+	return sqrt_fast(l2) - r;
+}
+__device__ __forceinline__ float sd_round_box_fast(V3 p, float cx, float cy, float cz, float bx, float by, float bz, float r, u32& tiny) {
+	V3 q = { __builtin_fabsf(p.x - cx) - bx, __builtin_fabsf(p.y - cy) - by, __builtin_fabsf(p.z - cz) - bz };
+	V3 cq = { maxf_(q.x, 0.f), maxf_(q.y, 0.f), maxf_(q.z, 0.f) };
+	float l2 = len2(cq);
+	/* inside the box l2 is exactly 0, which sqrt_fast handles: only 0 < l2 < 2^-96 needs the plain path */
+	tiny = umin_(tiny, l2 == 0.f ? 0x7f800000u : __builtin_bit_cast(u32, l2));
+	return sqrt_fast(l2) + minf_(maxf_(q.x, maxf_(q.y, q.z)), 0.f) - r;
+}
+
 /* ------------------------------------------------------------ SDF interpreter
  * Runs the post-order program (lol_scene.h) for one point per lane.  `ops`
  * points into LDS; every lane reads the same address, and the opcode is moved
@@ -121,7 +177,7 @@ struct Interp {
 	const u32* ops;      /* LDS */
 	u32        n_ops;
 
-	__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id) const {
+	__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id) {
 		float s[STACK];
 #pragma unroll
 		for (int i = 0; i < STACK; i++) s[i] = 0.f;
@@ -162,7 +218,7 @@ struct Hit { float dist; u32 id; u32 steps; };
 
 /* get_intersection, naive_renderer.c:48-69 */
 template <class Sdf>
-__device__ __forceinline__ Hit march(const Sdf& sdf, V3 ro, V3 rd, int max_steps) {
+__device__ __forceinline__ Hit march(Sdf& sdf, V3 ro, V3 rd, int max_steps) {
 	const float EPSILON = 0.001f, MAX_DIST = 100.f;
 	float dist = 0.f;
 	u32 id = 0, steps = 0;
@@ -186,7 +242,7 @@ __device__ __forceinline__ Hit march(const Sdf& sdf, V3 ro, V3 rd, int max_steps
 /* in_shadow + softshadow, naive_renderer.c:73-100.  dir/light_dist come from the caller,
  * which needs the same normalize(light - p) for the Phong term. */
 template <class Sdf>
-__device__ __forceinline__ float soft_shadow(const Sdf& sdf, V3 p, V3 dir, float max_dist, u32& steps) {
+__device__ __forceinline__ float soft_shadow(Sdf& sdf, V3 p, V3 dir, float max_dist, u32& steps) {
 	V3 ro = add(p, dir);
 	float res = 1.f, t = 0.f;
 	bool alive = true;
@@ -207,7 +263,7 @@ __device__ __forceinline__ float soft_shadow(const Sdf& sdf, V3 p, V3 dir, float
 
 /* get_normal, naive_renderer.c:114-125: k0=(1,-1,-1) k1=(-1,-1,1) k2=(-1,1,-1) k3=(1,1,1) */
 template <class Sdf>
-__device__ __forceinline__ V3 normal_at(const Sdf& sdf, V3 p, float dist) {
+__device__ __forceinline__ V3 normal_at(Sdf& sdf, V3 p, float dist) {
 	const float h = dist / 100.f;
 	const float nh = -1.f * h;       /* v3scale(k, h) multiplies; -1*h == -h bit for bit */
 	float s0, s1, s2, s3; u32 unused;
@@ -229,16 +285,17 @@ __host__ __device__ inline u32 common_lds_dwords(u32 n_lights, u32 n_materials, 
 	return n_lights * LIGHT_DWORDS + n_materials * MATERIAL_DWORDS + n_roots + TILE_W * TILE_H;
 }
 
+struct Pixel { u32 px; V3 rgb; Hit hit; u32 shadow_steps; };
+
 /*
- * The per-pixel body, naive_renderer.c:217-235.  `lds` = lights | materials | root_material | out tile;
- * the caller has already synchronised the block after staging.
+ * The per-pixel body, naive_renderer.c:217-235, for the pixel this lane owns.
+ * `lds` = lights | materials | root_material | out tile (already staged and synchronised).
  */
 template <class Sdf>
-__device__ __forceinline__ void render_pixels(const Launch& L, const Sdf& sdf, u32* lds) {
-	u32* l_light = lds;
-	u32* l_mat   = l_light + L.n_lights * LIGHT_DWORDS;
-	u32* l_rootm = l_mat + L.n_materials * MATERIAL_DWORDS;
-	u32* l_tile  = l_rootm + L.n_roots;
+__device__ __forceinline__ Pixel shade_pixel(const Launch& L, Sdf& sdf, const u32* lds) {
+	const u32* l_light = lds;
+	const u32* l_mat   = l_light + L.n_lights * LIGHT_DWORDS;
+	const u32* l_rootm = l_mat + L.n_materials * MATERIAL_DWORDS;
 
 	/* lane → pixel: wave k covers an 8x8 patch at columns 8k.. of the 32x8 tile */
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -297,25 +354,29 @@ __device__ __forceinline__ void render_pixels(const Launch& L, const Sdf& sdf, u
 	const float g = 1.f / 2.2f;
 	c = { powf(c.x, g), powf(c.y, g), powf(c.z, g) };
 	u32 px = ((u32)(c.x * 255.f) & 0xFFu) << 16 | ((u32)(c.y * 255.f) & 0xFFu) << 8 | ((u32)(c.z * 255.f) & 0xFFu);
+	return { px, c, hit, shadow_steps };
+}
 
+/* Write the lane's pixel (and the optional diagnostics).  Every thread of the block must call this. */
+__device__ __forceinline__ void store_pixel(const Launch& L, const Pixel& P, u32* lds) {
+	u32* l_tile = lds + L.n_lights * LIGHT_DWORDS + L.n_materials * MATERIAL_DWORDS + L.n_roots;
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int tx = wave * 8 + (lane & 7), ty = lane >> 3;
 	const int gx = blockIdx.x * TILE_W + tx, gr = blockIdx.y * TILE_H + ty;
 	if (gx < L.w && gr < L.n_rows) {
 		unsigned long long o = (unsigned long long)gr * L.w + gx;
-		if (L.dbg_rgb) { L.dbg_rgb[o * 3 + 0] = c.x; L.dbg_rgb[o * 3 + 1] = c.y; L.dbg_rgb[o * 3 + 2] = c.z; }
-		if (L.dbg_hit_dist) L.dbg_hit_dist[o] = hit.dist;
-		if (L.dbg_hit_id) L.dbg_hit_id[o] = hit.id;
-		if (L.dbg_steps) L.dbg_steps[o] = (hit.steps & 0xFFFFu) | (shadow_steps << 16);
+		if (L.dbg_rgb) { L.dbg_rgb[o * 3 + 0] = P.rgb.x; L.dbg_rgb[o * 3 + 1] = P.rgb.y; L.dbg_rgb[o * 3 + 2] = P.rgb.z; }
+		if (L.dbg_hit_dist) L.dbg_hit_dist[o] = P.hit.dist;
+		if (L.dbg_hit_id) L.dbg_hit_id[o] = P.hit.id;
+		if (L.dbg_steps) L.dbg_steps[o] = (P.hit.steps & 0xFFFFu) | (P.shadow_steps << 16);
 	}
-
 	/* through LDS so a wave stores two full 128-byte row segments */
-	l_tile[ty * TILE_W + tx] = px;
+	l_tile[ty * TILE_W + tx] = P.px;
 	__syncthreads();
-	{
-		const int sx = threadIdx.x & (TILE_W - 1), sy = threadIdx.x >> 5;
-		const int ox = blockIdx.x * TILE_W + sx, orow = blockIdx.y * TILE_H + sy;
-		if (ox < L.w && orow < L.n_rows)
-			L.dst[(unsigned long long)orow * L.pitch_px + ox] = l_tile[sy * TILE_W + sx];
-	}
+	const int sx = threadIdx.x & (TILE_W - 1), sy = threadIdx.x >> 5;
+	const int ox = blockIdx.x * TILE_W + sx, orow = blockIdx.y * TILE_H + sy;
+	if (ox < L.w && orow < L.n_rows)
+		L.dst[(unsigned long long)orow * L.pitch_px + ox] = l_tile[sy * TILE_W + sx];
 }
 
 /* stage lights | materials | root_material into `lds` (no barrier) */
@@ -339,7 +400,8 @@ void render_interp(const Launch L) {
 	stage_common(L, l_common);
 	__syncthreads();
 	Interp<STACK> sdf{ l_ops, L.n_ops };
-	render_pixels(L, sdf, l_common);
+	Pixel P = shade_pixel(L, sdf, l_common);
+	store_pixel(L, P, l_common);
 }
 
 }  // namespace lol

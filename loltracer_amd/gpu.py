@@ -79,8 +79,10 @@ def gpu_lib() -> C.CDLL:
         lib.lol_gpu_set_specialize.restype = C.c_int
         lib.lol_gpu_specialize_log.argtypes = [vp]
         lib.lol_gpu_specialize_log.restype = C.c_char_p
-        lib.lol_gpu_compile_offline.argtypes = [P(S.Program), C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
+        lib.lol_gpu_compile_offline.argtypes = [P(S.Program), C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]
         lib.lol_gpu_compile_offline.restype = C.c_int
+        lib.lol_gpu_verify_fast_paths.argtypes = [vp, C.c_float, P(C.c_ulonglong), P(C.c_ulonglong)]
+        lib.lol_gpu_verify_fast_paths.restype = C.c_int
         _lib = lib
     return _lib
 
@@ -89,14 +91,15 @@ EXPORTED_SYMBOLS = [
     "lol_gpu_device_count", "lol_gpu_create", "lol_gpu_destroy", "lol_gpu_error", "lol_gpu_upload_program",
     "lol_gpu_part_rows", "lol_gpu_render_device", "lol_gpu_render_host", "lol_gpu_sync", "lol_gpu_malloc",
     "lol_gpu_free", "lol_gpu_memcpy_d2h", "lol_gpu_kernel_name", "lol_gpu_set_specialize",
-    "lol_gpu_specialize_log", "lol_gpu_compile_offline",
+    "lol_gpu_specialize_log", "lol_gpu_compile_offline", "lol_gpu_verify_fast_paths",
 ]
 
 
-def compile_offline(program: S.Program, out_base: str, arch: str = "gfx950") -> str:
+def compile_offline(program: S.Program, out_base: str, arch: str = "gfx950", assume_fast: bool = False) -> str:
     """hipRTC-compile the scene-specialised kernel without a device; returns the compiler log."""
     log = C.create_string_buffer(1 << 16)
-    st = gpu_lib().lol_gpu_compile_offline(C.byref(program), arch.encode(), os.fsencode(out_base), log, len(log))
+    st = gpu_lib().lol_gpu_compile_offline(C.byref(program), arch.encode(), os.fsencode(out_base),
+                                           1 if assume_fast else 0, log, len(log))
     if st != LOL_GPU_OK:
         raise GpuError(st, "hipRTC compile failed:\n" + log.value.decode(errors="replace"))
     return log.value.decode(errors="replace")
@@ -107,14 +110,14 @@ def part_rows(h: int, rows: Rows | None) -> int:
 
 
 class Renderer:
-    def __init__(self, device: int = 0, specialize: bool = True):
+    def __init__(self, device: int = 0, specialize: bool | int = True):
         self._lib = gpu_lib()
         self._ctx = C.c_void_p()
         st = self._lib.lol_gpu_create(device, C.byref(self._ctx))
         if st != LOL_GPU_OK:
             self._ctx = C.c_void_p()
             raise GpuError(st, f"lol_gpu_create(device={device}) failed")
-        self._lib.lol_gpu_set_specialize(self._ctx, 1 if specialize else 0)
+        self._lib.lol_gpu_set_specialize(self._ctx, int(specialize))
         self.scene: S.Scene | None = None
         self.program: S.Program | None = None
 
@@ -156,6 +159,12 @@ class Renderer:
 
     def kernel_name(self) -> str:
         return self._lib.lol_gpu_kernel_name(self._ctx).decode()
+
+    def verify_fast_paths(self, k: float = 3.0):
+        """(sqrt mismatches, x/k mismatches) over all 2^32 float inputs; 0 means proven exact."""
+        a, b = C.c_ulonglong(), C.c_ulonglong()
+        self._check(self._lib.lol_gpu_verify_fast_paths(self._ctx, k, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def specialize_log(self) -> str:
         return self._lib.lol_gpu_specialize_log(self._ctx).decode(errors="replace")

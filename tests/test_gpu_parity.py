@@ -25,9 +25,9 @@ def torch_cuda():
     return torch
 
 
-@pytest.fixture(scope="module", params=[True, False], ids=["spec", "interp"])
+@pytest.fixture(scope="module", params=[1, 3, 0], ids=["spec", "spec-plain", "interp"])
 def renderer(torch_cuda, request):
-    """Both kernels: the hipRTC scene-specialised one and the ahead-of-time LDS interpreter."""
+    """All kernels: hipRTC scene-specialised (with and without the proven fast paths) and the AOT LDS interpreter."""
     r = gpu.Renderer(0, specialize=request.param)
     r.want_kernel = "lol_render_spec" if request.param else "render_interp"
     yield r
@@ -170,6 +170,33 @@ def test_full_size_sampled_rows_and_partition(torch_cuda, renderer, scenes):
         v = pg.reshape(-1, band, w)
         out.reshape(-1, n_parts, band, w)[:, part] = v
     assert np.array_equal(out, g["xrgb"])
+
+
+def test_fast_paths_are_proven_exhaustively(torch_cuda, scenes):
+    """All 2^32 float inputs: sqrt_fast == sqrtf (outside (0, 2^-96)) and clamp(.5 + x/k) via div_const == exact."""
+    r = gpu.Renderer(0)
+    for k in (3.0, 1.0, 0.1, 7.5, 1e-3, 1e20):
+        sq, dv = r.verify_fast_paths(k)
+        assert sq == 0, f"sqrt_fast differs from sqrtf on {sq} inputs"
+        assert dv == 0, f"smooth-min division by {k} differs on {dv} inputs"
+    r.prepare(scenes["scene4"])
+    assert "sqrt=1, smin divisors=1" in r.specialize_log()
+    r.close()
+
+
+def test_tiny_squared_length_takes_the_plain_path(torch_cuda, scenes):
+    """A camera placed exactly on a sphere centre makes |p-c|^2 == 0 < 2^-96 on the first march step of
+    every ray: the wave must re-shade through the plain SDF and still match the oracle."""
+    sc = scenes["scene4"]
+    cam = S.Camera()
+    cam.point = S.V3(0.0, 1.0, -6.0)          # centre of scene4's first sphere
+    cam.direction = S.V3(0.0, 0.0, -1.0)
+    cam.fov = float(np.float32(np.float32(90.0) / np.float32(180) * np.pi))
+    r = gpu.Renderer(0)
+    w, h = 64, 32
+    g = gpu_render(torch_cuda, r, sc, w, h, camera=cam)
+    check_against_oracle(g, sc, w, h, camera=cam)
+    r.close()
 
 
 def test_errors_are_loud(torch_cuda, scenes):
