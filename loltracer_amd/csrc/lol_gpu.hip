@@ -53,7 +53,7 @@ struct lol_gpu {
 	hipFunction_t spec_fn = nullptr;
 	std::string  spec_log;
 	int          want_fast = 1;          /* allow the proven-exact shortcuts in the specialised kernel */
-	int          sqrt_verified = -1;     /* -1 not run, 0 failed, 1 proven on this device */
+	int          sqrt_verified = -1;     /* -1 not run, 0 none proven, 1 sqrt_pm, 2 sqrt_gs proven on this device */
 	std::vector<std::pair<uint32_t, bool>> div_verified;   /* k bits → proven */
 	unsigned long long* d_bad = nullptr; /* mismatch counter of the verification kernels */
 	char         err[512] = { 0 };
@@ -92,15 +92,17 @@ __device__ __forceinline__ bool same_float(float a, float b) {
 }
 constexpr unsigned VERIFY_BLOCKS = 65536, VERIFY_THREADS = 256, VERIFY_ITERS = 256;   /* product = 2^32 */
 
+template <int KIND>
 __global__ __launch_bounds__(VERIFY_THREADS) void verify_sqrt_kernel(unsigned long long* bad) {
 	uint32_t base = blockIdx.x * VERIFY_THREADS + threadIdx.x;
 	unsigned n = 0;
 	for (uint32_t it = 0; it < VERIFY_ITERS; it++) {
 		float x = __builtin_bit_cast(float, base + it * (VERIFY_BLOCKS * VERIFY_THREADS));
-		/* sqrt_fast is only ever given a sum of squares (len2): never negative.  Below 2^-96 callers
-		 * take the plain path.  Everything else — 0, [2^-96, inf], NaN — must agree. */
-		bool excluded = x < 0.f || (x > 0.f && x < lol::SQRT_FAST_MIN);
-		if (!excluded && !same_float(lol::sqrt_fast(x), __builtin_sqrtf(x))) n++;
+		/* The fast roots are only ever given a sum of squares (len2): never negative.  A wave that saw
+		 * an argument outside [2^-96, inf) re-shades through the plain path (lol::Range), so the proof
+		 * obligation is exactly that interval plus NaN. */
+		bool in_domain = (x >= lol::SQRT_FAST_MIN && x < __builtin_inff()) || x != x;
+		if (in_domain && !same_float(lol::sqrt_fast<KIND>(x), __builtin_sqrtf(x))) n++;
 	}
 	if (n) atomicAdd(bad, (unsigned long long)n);
 }
@@ -116,12 +118,13 @@ __global__ __launch_bounds__(VERIFY_THREADS) void verify_div_kernel(float k, flo
 }
 
 /* returns mismatch count, or ~0ull when the check itself could not run */
-unsigned long long run_verify(lol_gpu* ctx, bool is_sqrt, float k) {
+unsigned long long run_verify(lol_gpu* ctx, int sqrt_kind, float k) {
 	if (!ctx->d_bad && hipMalloc(reinterpret_cast<void**>(&ctx->d_bad), sizeof(unsigned long long)) != hipSuccess)
 		return ~0ull;
 	unsigned long long bad = 0;
 	if (hipMemcpy(ctx->d_bad, &bad, sizeof bad, hipMemcpyHostToDevice) != hipSuccess) return ~0ull;
-	if (is_sqrt) hipLaunchKernelGGL(verify_sqrt_kernel, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, ctx->d_bad);
+	if (sqrt_kind == 2) hipLaunchKernelGGL(verify_sqrt_kernel<2>, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, ctx->d_bad);
+	else if (sqrt_kind == 1) hipLaunchKernelGGL(verify_sqrt_kernel<1>, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, ctx->d_bad);
 	else hipLaunchKernelGGL(verify_div_kernel, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, k, 1.0f / k, ctx->d_bad);
 	if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return ~0ull;
 	if (hipMemcpy(&bad, ctx->d_bad, sizeof bad, hipMemcpyDeviceToHost) != hipSuccess) return ~0ull;
@@ -140,7 +143,7 @@ std::string fbits(float v) {
 
 /* Which proven-exact shortcuts the generated code may use (see lol_kernel.h "fast exact paths"). */
 struct FastPaths {
-	bool sqrt_ok = false;                 /* sqrt_fast verified on this device */
+	int sqrt_kind = 0;                    /* 0 plain sqrtf; 1 sqrt_pm, 2 sqrt_gs — proven on this device */
 	std::vector<float> div_ok;            /* smoothness constants k whose smin_h_fast verified */
 	bool has(float k) const {
 		for (float v : div_ok) if (memcmp(&v, &k, 4) == 0) return true;
@@ -151,8 +154,10 @@ struct FastPaths {
 /* Emits one `struct <name>` with eval(): one SSA temporary per op, same operation order as the interpreter. */
 void emit_sdf(std::string& s, const lol_program& P, const char* name, const FastPaths* fast) {
 	char line[640];
-	const bool fsqrt = fast && fast->sqrt_ok;
-	snprintf(line, sizeof line, "struct %s {\n\tu32 tiny = 0x7f800000u;\n", name);
+	const int fsqrt = fast ? fast->sqrt_kind : 0;
+	char fs[32] = "";
+	if (fsqrt) snprintf(fs, sizeof fs, "_fast<%d>", fsqrt);
+	snprintf(line, sizeof line, "struct %s {\n\tRange rg;\n", name);
 	s += line;
 	s += "\t__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id) {\n";
 	s += "\t\tbest = __builtin_inff(); best_id = 0u;\n";
@@ -162,15 +167,15 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 		const lol_op& o = P.ops[i];
 		switch (o.op) {
 		case LOL_OP_SPHERE:
-			snprintf(line, sizeof line, "\t\tconst float t%d = sd_sphere%s(p, %s, %s, %s, %s%s);\n", t, fsqrt ? "_fast" : "",
+			snprintf(line, sizeof line, "\t\tconst float t%d = sd_sphere%s(p, %s, %s, %s, %s%s);\n", t, fs,
 			         fbits(o.f[0]).c_str(), fbits(o.f[1]).c_str(), fbits(o.f[2]).c_str(), fbits(o.f[3]).c_str(),
-			         fsqrt ? ", tiny" : "");
+			         fsqrt ? ", rg" : "");
 			s += line; stack.push_back(t++); break;
 		case LOL_OP_RBOX:
 			snprintf(line, sizeof line, "\t\tconst float t%d = sd_round_box%s(p, %s, %s, %s, %s, %s, %s, %s%s);\n", t,
-			         fsqrt ? "_fast" : "",
+			         fs,
 			         fbits(o.f[0]).c_str(), fbits(o.f[1]).c_str(), fbits(o.f[2]).c_str(), fbits(o.f[3]).c_str(),
-			         fbits(o.f[4]).c_str(), fbits(o.f[5]).c_str(), fbits(o.f[6]).c_str(), fsqrt ? ", tiny" : "");
+			         fbits(o.f[4]).c_str(), fbits(o.f[5]).c_str(), fbits(o.f[6]).c_str(), fsqrt ? ", rg" : "");
 			s += line; stack.push_back(t++); break;
 		case LOL_OP_PLANE:
 			snprintf(line, sizeof line, "\t\tconst float t%d = p.y - %s;\n", t, fbits(o.f[0]).c_str());
@@ -197,16 +202,16 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 }
 
 /*
- * The kernel shades every pixel with the fast SDF; a wave in which any squared length fell below
- * SQRT_FAST_MIN (a sample within 2^-48 of a sphere centre) shades its pixels again with the plain
- * SDF, so the shortcut never decides a result.
+ * The kernel shades every pixel with the fast SDF; a wave in which any squared length fell outside
+ * [SQRT_FAST_MIN, inf) (a sample within 2^-48 of a sphere centre, or an overflow) shades its pixels
+ * again with the plain SDF, so the shortcut never decides a result.
  */
 std::string generate_source(const lol_program& P, const FastPaths* fast) {
 	std::string s;
 	s += "#include \"lol_kernel.h\"\n";
 	s += "namespace lol {\n";
 	emit_sdf(s, P, "SpecSdfExact", nullptr);
-	const bool any_fast = fast && (fast->sqrt_ok || !fast->div_ok.empty());
+	const bool any_fast = fast && (fast->sqrt_kind || !fast->div_ok.empty());
 	if (any_fast) emit_sdf(s, P, "SpecSdfFast", fast);
 	s += "}  // namespace lol\n";
 	s += "extern \"C\" __global__ __launch_bounds__(lol::BLOCK) void lol_render_spec(const lol::Launch L) {\n";
@@ -216,7 +221,7 @@ std::string generate_source(const lol_program& P, const FastPaths* fast) {
 	if (any_fast) {
 		s += "\tlol::SpecSdfFast fast;\n";
 		s += "\tlol::Pixel P = lol::shade_pixel(L, fast, lds);\n";
-		s += "\tif (__ballot(fast.tiny < lol::SQRT_FAST_MIN_BITS) != 0) {\n";
+		s += "\tif (__ballot(fast.rg.outside()) != 0) {\n";
 		s += "\t\tlol::SpecSdfExact exact;\n";
 		s += "\t\tP = lol::shade_pixel(L, exact, lds);\n";
 		s += "\t}\n";
@@ -243,8 +248,20 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
 	}
 	std::string arch_opt = "--offload-arch=" + arch;
 	/* -ffp-contract=off: no FMA contraction (the reference has none); the rest are hipcc's defaults made explicit */
-	const char* opts[] = { arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math" };
-	hiprtcResult r = hiprtcCompileProgram(prog, (int)(sizeof opts / sizeof opts[0]), opts);
+	std::vector<std::string> extra;                     /* LOL_GPU_RTC_FLAGS: extra hipRTC options, for tuning experiments */
+	if (const char* e = getenv("LOL_GPU_RTC_FLAGS")) {
+		std::string cur;
+		for (const char* c = e;; c++) {
+			if (*c == ' ' || *c == 0) { if (!cur.empty()) extra.push_back(cur); cur.clear(); if (!*c) break; }
+			else cur += *c;
+		}
+	}
+	/* -fno-slp-vectorize: the SLP pass pairs scalar f32 ops into v_pk_*_f32, which issue at half the
+	 * rate of two scalar ops on gfx950 (tools/valu_rate.hip); measured +10 % Mpixels/s without it. */
+	std::vector<const char*> opts = { arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+	                                  "-fno-slp-vectorize" };
+	for (auto& x : extra) opts.push_back(x.c_str());
+	hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
 	size_t log_size = 0;
 	hiprtcGetProgramLogSize(prog, &log_size);
 	log.clear();
@@ -281,8 +298,11 @@ bool specialise(lol_gpu* ctx) {
 	const char* fenv = getenv("LOL_GPU_FAST");
 	std::string note;
 	if (ctx->want_fast && !(fenv && fenv[0] == '0')) {
-		if (ctx->sqrt_verified < 0) ctx->sqrt_verified = run_verify(ctx, true, 0.f) == 0 ? 1 : 0;
-		fast.sqrt_ok = ctx->sqrt_verified == 1;
+		if (ctx->sqrt_verified < 0) {
+			if (run_verify(ctx, 2, 0.f) == 0) ctx->sqrt_verified = 2;
+			else ctx->sqrt_verified = run_verify(ctx, 1, 0.f) == 0 ? 1 : 0;
+		}
+		fast.sqrt_kind = ctx->sqrt_verified;
 		for (uint32_t i = 0; i < ctx->h_prog.n_ops; i++) {
 			const lol_op& o = ctx->h_prog.ops[i];
 			if (o.op != LOL_OP_SMIN && o.op != LOL_OP_SMIN_R) continue;
@@ -291,13 +311,13 @@ bool specialise(lol_gpu* ctx) {
 			bool known = false, ok = false;
 			for (auto& e : ctx->div_verified) if (e.first == kb) { known = true; ok = e.second; }
 			if (!known) {
-				ok = run_verify(ctx, false, o.f[0]) == 0;
+				ok = run_verify(ctx, 0, o.f[0]) == 0;
 				ctx->div_verified.emplace_back(kb, ok);
 			}
 			if (ok && !fast.has(o.f[0])) fast.div_ok.push_back(o.f[0]);
 		}
 		char b[160];
-		snprintf(b, sizeof b, "fast paths proven on device: sqrt=%d, smin divisors=%zu\n", (int)fast.sqrt_ok, fast.div_ok.size());
+		snprintf(b, sizeof b, "fast paths proven on device: sqrt=%d, smin divisors=%zu\n", fast.sqrt_kind, fast.div_ok.size());
 		note = b;
 	}
 	std::vector<char> code;
@@ -370,12 +390,13 @@ int lol_gpu_set_specialize(lol_gpu* ctx, int enable) {
 }
 
 /* Run the exhaustive (all 2^32 inputs) equivalence checks directly: mismatch counts out. */
-int lol_gpu_verify_fast_paths(lol_gpu* ctx, float k, unsigned long long* sqrt_mismatches,
-                              unsigned long long* div_mismatches) {
+int lol_gpu_verify_fast_paths(lol_gpu* ctx, float k, unsigned long long* sqrt_gs_mismatches,
+                              unsigned long long* sqrt_pm_mismatches, unsigned long long* div_mismatches) {
 	if (!ctx) return LOL_GPU_ERR_ARG;
 	LOL_HIP(ctx, hipSetDevice(ctx->device));
-	if (sqrt_mismatches) *sqrt_mismatches = run_verify(ctx, true, 0.f);
-	if (div_mismatches) *div_mismatches = run_verify(ctx, false, k);
+	if (sqrt_gs_mismatches) *sqrt_gs_mismatches = run_verify(ctx, 2, 0.f);
+	if (sqrt_pm_mismatches) *sqrt_pm_mismatches = run_verify(ctx, 1, 0.f);
+	if (div_mismatches) *div_mismatches = run_verify(ctx, 0, k);
 	return LOL_GPU_OK;
 }
 
@@ -548,7 +569,7 @@ int lol_gpu_compile_offline(const lol_program* prog, const char* arch, const cha
 	std::string lg, src;
 	FastPaths fast;
 	if (assume_fast) {                 /* ISA inspection only: pretend every shortcut was proven */
-		fast.sqrt_ok = true;
+		fast.sqrt_kind = assume_fast == 1 ? 2 : 1;
 		for (uint32_t i = 0; i < prog->n_ops; i++)
 			if ((prog->ops[i].op == LOL_OP_SMIN || prog->ops[i].op == LOL_OP_SMIN_R) && !fast.has(prog->ops[i].f[0]))
 				fast.div_ok.push_back(prog->ops[i].f[0]);

@@ -116,13 +116,33 @@ __device__ __forceinline__ float sd_round_box(V3 p, float cx, float cy, float cz
  * equal to the plain expressions by running every one of the 2^32 float inputs through
  * both on the device (verify_sqrt_kernel / verify_div_kernel): same bits or both NaN.
  *
- * sqrt_fast: v_sqrt_f32 (1 ulp) + the +-1 ulp residual test hipcc's own expansion of a
- * correctly rounded sqrt uses, minus its input scaling and class fix-up.  Exact for
- * x == 0, x >= 2^-96, inf and NaN (v_sqrt_f32 flushes denormal inputs, so smaller positive x
- * are NOT covered); its only argument is a sum of squares, never negative.  Callers flag
- * 0 <= x < SQRT_FAST_MIN and redo the whole pixel through the plain path. */
+ * Measured issue costs on MI355X (tools/valu_rate.hip, 8 waves/SIMD): v_mul/v_add/v_fma ~2.7
+ * cycles per wave-instruction, v_cmp / v_cndmask / v_div_fixup ~4, v_sqrt / v_rsq / v_rcp ~8.5 —
+ * so the compare+select pairs of hipcc's sqrt expansion cost more than its arithmetic.
+ *
+ * sqrt_gs: Goldschmidt iteration from v_rsq_f32 (what hipcc itself emits for a correctly rounded
+ * sqrt when it need not handle denormals): 1 transcendental + 7 plain ops, no compares.  Proven
+ * equal to sqrtf for 2^-96 <= x < inf and NaN.  x == 0 and x == inf give NaN here (0*inf), and
+ * v_rsq_f32 flushes denormal inputs, so callers track the range of its arguments (Range) and a
+ * wave that saw one outside [SQRT_FAST_MIN, inf) shades its pixels again through the plain path.
+ * Its only argument is a sum of squares, never negative. */
 constexpr float SQRT_FAST_MIN = 0x1p-96f;
-__device__ __forceinline__ float sqrt_fast(float x) {
+constexpr u32 SQRT_FAST_MIN_BITS = 0x0f800000u;      /* 2^-96 */
+constexpr u32 F32_INF_BITS = 0x7f800000u;
+__device__ __forceinline__ float sqrt_gs(float x) {
+	float y = __builtin_amdgcn_rsqf(x);
+	float s = x * y;
+	float h = y * 0.5f;
+	float e = __builtin_fmaf(-h, s, 0.5f);
+	h = __builtin_fmaf(h, e, h);
+	s = __builtin_fmaf(s, e, s);
+	float d = __builtin_fmaf(-s, s, x);
+	return __builtin_fmaf(d, h, s);
+}
+/* sqrt_pm: v_sqrt_f32 (1 ulp) + the +-1 ulp residual test of hipcc's denormal-safe expansion, minus
+ * its input scaling and class fix-up.  Proven for x == 0, 2^-96 <= x <= inf and NaN.  Fallback when
+ * sqrt_gs does not verify on a device. */
+__device__ __forceinline__ float sqrt_pm(float x) {
 	float r = __builtin_amdgcn_sqrtf(x);
 	int ri = __builtin_bit_cast(int, r);
 	float rm = __builtin_bit_cast(float, ri - 1), rp = __builtin_bit_cast(float, ri + 1);
@@ -132,6 +152,19 @@ __device__ __forceinline__ float sqrt_fast(float x) {
 	r = ep > 0.f ? rp : r;
 	return r;
 }
+/* Unsigned min / max of the bit patterns of every squared length an evaluation took the root of:
+ * for non-negative floats the bit order is the value order (NaN sorts above inf). */
+struct Range {
+	u32 lo = F32_INF_BITS, hi = 0u;
+	__device__ __forceinline__ void see(float l2) {
+		u32 b = __builtin_bit_cast(u32, l2);
+		lo = b < lo ? b : lo;
+		hi = b > hi ? b : hi;
+	}
+	__device__ __forceinline__ bool outside() const { return lo < SQRT_FAST_MIN_BITS || hi >= F32_INF_BITS; }
+};
+template <int KIND> __device__ __forceinline__ float sqrt_fast(float x) { return KIND == 2 ? sqrt_gs(x) : sqrt_pm(x); }
+
 /* x / k for a scene constant k with rk = 1/k: product, one residual correction, then the
  * hardware's special-case fix-up.  sminf_fastdiv() is what gets verified (over all x). */
 __device__ __forceinline__ float div_const(float x, float k, float rk) {
@@ -147,24 +180,25 @@ __device__ __forceinline__ float sminf_fastdiv(float a, float b, float k, float 
 	float h = smin_h_fast(.5f * (b - a), k, rk);
 	return (b + (a - b) * h) - k * h * (1.f - h);
 }
-/* sd_sphere on the fast sqrt.  `tiny` keeps the unsigned minimum of the squared lengths' bit
- * patterns (for non-negative floats the bit order is the value order; NaN sorts above inf), so
- * one compare against SQRT_FAST_MIN at the end of an evaluation covers every sqrt in it. */
-constexpr u32 SQRT_FAST_MIN_BITS = 0x0f800000u;      /* 2^-96 */
-__device__ __forceinline__ u32 umin_(u32 a, u32 b) { return a < b ? a : b; }
-__device__ __forceinline__ float sd_sphere_fast(V3 p, float cx, float cy, float cz, float r, u32& tiny) {
+/* sd_sphere / sd_round_box on a proven fast sqrt (KIND 1 = sqrt_pm, 2 = sqrt_gs) */
+template <int KIND>
+__device__ __forceinline__ float sd_sphere_fast(V3 p, float cx, float cy, float cz, float r, Range& rg) {
 	V3 q = { p.x - cx, p.y - cy, p.z - cz };
 	float l2 = len2(q);
-	tiny = umin_(tiny, __builtin_bit_cast(u32, l2));
-	return sqrt_fast(l2) - r;
+	rg.see(l2);
+	return sqrt_fast<KIND>(l2) - r;
 }
-__device__ __forceinline__ float sd_round_box_fast(V3 p, float cx, float cy, float cz, float bx, float by, float bz, float r, u32& tiny) {
+template <int KIND>
+__device__ __forceinline__ float sd_round_box_fast(V3 p, float cx, float cy, float cz, float bx, float by, float bz, float r, Range& rg) {
 	V3 q = { __builtin_fabsf(p.x - cx) - bx, __builtin_fabsf(p.y - cy) - by, __builtin_fabsf(p.z - cz) - bz };
 	V3 cq = { maxf_(q.x, 0.f), maxf_(q.y, 0.f), maxf_(q.z, 0.f) };
 	float l2 = len2(cq);
-	/* inside the box l2 is exactly 0, which sqrt_fast handles: only 0 < l2 < 2^-96 needs the plain path */
-	tiny = umin_(tiny, l2 == 0.f ? 0x7f800000u : __builtin_bit_cast(u32, l2));
-	return sqrt_fast(l2) + minf_(maxf_(q.x, maxf_(q.y, q.z)), 0.f) - r;
+	/* inside the box l2 is exactly 0 and the root is 0: do not take it (nor flag it) there */
+	float l2s = l2 == 0.f ? 1.f : l2;
+	rg.see(l2s);
+	float root = sqrt_fast<KIND>(l2s);
+	root = l2 == 0.f ? 0.f : root;
+	return root + minf_(maxf_(q.x, maxf_(q.y, q.z)), 0.f) - r;
 }
 
 /* ------------------------------------------------------------ SDF interpreter
