@@ -71,6 +71,20 @@ def flops_per_sdf(prog: S.Program) -> float:
     return float(sum(cost[prog.ops[i].op] for i in range(prog.n_ops)))
 
 
+def pmc_traffic(kernel: str, workload: str, pixels_per_launch: int):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json:
+    WRITE_SIZE + 2 x FETCH_SIZE, one counter group per pass, the gfx950 FETCH correction applied).  PMC
+    counters cannot be read from inside this process, so the figure comes from the profile of the same
+    command; it is reported only for the kernel / workload / launch size it was measured on."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"].get(kernel)
+    except (OSError, ValueError, KeyError):
+        return None
+    if not rec or rec.get("workload") != workload or rec.get("pixels_per_launch") != pixels_per_launch:
+        return None
+    return rec["traffic_bytes"]
+
+
 def cpu_baseline(sc: S.Scene, cfg: dict, target_s: float = 15.0):
     """Time the CPU oracle on all host cores over a bounded, evenly spread row sample of the frame."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -157,27 +171,31 @@ def main():
         n_local = gpu.part_rows(h, rows)
         cams = [sc.frame_camera(w, h)]
 
-    local = torch.zeros((n_local, w), dtype=torch.int32, device=dev)
-    staging = frame = None
-    if world > 1 and not orbit and rank == 0:
-        staging = torch.empty((world, n_local, w), dtype=torch.int32, device=dev)
-        frame = torch.empty((h, w), dtype=torch.int32, device=dev)
+    # N>1: two frames in flight per rank — frame i's gather overlaps frame i+1's kernel (multi.GatherPipeline).
+    pipe = multi.GatherPipeline(w, h, band if not orbit else h, dev, depth=2) if (world > 1 and not orbit) else None
+    local = torch.zeros((n_local, w), dtype=torch.int32, device=dev) if pipe is None else None
 
     kernel_ms = []
 
-    def step(i, timed):
-        fc = cams[i % len(cams)]
+    def launch(dst_tensor, fc, timed):
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        r.render_into(local.data_ptr(), w, h, max_steps, rows=rows, stream=stream, frame_camera=fc)
+        r.render_into(dst_tensor.data_ptr(), w, h, max_steps, rows=rows, stream=stream, frame_camera=fc)
         if timed:
             e1.record()
             kernel_ms.append((e0, e1))
-        if world > 1 and not orbit:
-            multi.gather_frame(local, h, band, out=frame, staging=staging)
+
+    def step(i, timed):
+        fc = cams[i % len(cams)]
+        if pipe is None:
+            launch(local, fc, timed)
+        else:
+            pipe.submit(lambda part: launch(part, fc, timed))
 
     def fence():
+        if pipe is not None:
+            pipe.drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -224,7 +242,9 @@ def main():
                        "width": w, "height": h, "max_steps": max_steps, "band_rows": band,
                        "kernel": r.kernel_name()},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 6),
+                         "traffic": pmc_traffic(r.kernel_name(), name, px_per_launch),
+                         "algorithmic_bytes": px_per_launch * BYTES_PER_PIXEL,
                          "kernel_ms_avg": round(k_avg, 4), "pixels_per_launch": px_per_launch,
                          "bytes_per_pixel": BYTES_PER_PIXEL,
                          "note": "north_star names the HBM-write roofline; the path is FP32-VALU-bound, see `valu`"},

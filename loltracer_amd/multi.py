@@ -81,6 +81,70 @@ def gather_frame(local: torch.Tensor, h: int, band_rows: int, group=None, dst: i
     return None
 
 
+class GatherPipeline:
+    """Frames in flight: while frame i's parts travel to `dst`, frame i+1 is already rendering.
+
+    Each rank owns `depth` local part buffers.  submit(render) renders the next frame's part into
+    the next buffer (after making sure the gather that last read that buffer has finished) and
+    starts an asynchronous gather of it; on `dst` the gathered parts are un-interleaved into
+    `frame` when their gather is waited for.  drain() completes everything in flight.  A renderer
+    that produces a stream of frames (the reference's frame loop, main.c:163-211) loses nothing by
+    this: every frame still ends up assembled on `dst`, in order.
+    """
+
+    def __init__(self, w: int, h: int, band_rows: int, device, group=None, dst: int = 0, depth: int = 2,
+                 dtype=torch.int32):
+        self.group, self.dst, self.h, self.w, self.band = group, dst, h, w, band_rows
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if self.world > 1 and h % (band_rows * self.world) != 0:
+            raise ValueError(f"h={h} must be a multiple of band_rows*world={band_rows * self.world}")
+        self.rows = part_rows(h, band_rows, self.world, self.rank) if self.world > 1 else h
+        self.depth = depth if self.world > 1 else 1
+        self.local = [torch.zeros((self.rows, w), dtype=dtype, device=device) for _ in range(self.depth)]
+        self.is_dst = self.rank == dst
+        self.staging = ([torch.empty((self.world, self.rows, w), dtype=dtype, device=device) for _ in range(self.depth)]
+                        if self.world > 1 and self.is_dst else None)
+        self.frame = torch.empty((h, w), dtype=dtype, device=device) if self.world > 1 and self.is_dst else None
+        self.work = [None] * self.depth
+        self.n = 0
+        self.frames_done = 0
+
+    def _finish(self, slot: int):
+        w = self.work[slot]
+        if w is None:
+            return
+        w.wait()                                   # orders the current stream after the collective
+        self.work[slot] = None
+        if self.is_dst:
+            self.frame.copy_(assemble(self.staging[slot], self.h, self.band))
+        self.frames_done += 1
+
+    def submit(self, render):
+        """render(local_part_tensor): enqueue the rendering of this rank's part into the tensor."""
+        slot = self.n % self.depth
+        self.n += 1
+        if self.world == 1:
+            render(self.local[0])
+            self.frame = self.local[0]
+            self.frames_done += 1
+            return
+        self._finish(slot)
+        render(self.local[slot])
+        if self.is_dst:
+            self.work[slot] = dist.gather(self.local[slot], [self.staging[slot][i] for i in range(self.world)],
+                                          dst=self.dst, group=self.group, async_op=True)
+        else:
+            self.work[slot] = dist.gather(self.local[slot], None, dst=self.dst, group=self.group, async_op=True)
+
+    def drain(self):
+        """Finish every frame in flight, oldest first; returns the last assembled frame on dst (None elsewhere)."""
+        if self.world > 1:
+            for k in range(self.depth):
+                self._finish((self.n + k) % self.depth)
+        return self.frame if self.is_dst else None
+
+
 def render_frame_distributed(render_part: Callable[[int, int, int], torch.Tensor], w: int, h: int,
                              band_rows: int, group=None, dst: int = 0, out=None, staging=None):
     """render_part(band_rows, world, rank) → this rank's compact [rows, w] int32 tensor; returns the frame on dst."""

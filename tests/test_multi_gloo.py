@@ -68,6 +68,48 @@ def test_band_partition_gather_assembles_the_frame(world, h, band):
     assert q.get(timeout=5) is True
 
 
+def _pipe_worker(rank, world, port, w, h, band, frames, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pipe = multi.GatherPipeline(w, h, band, torch.device("cpu"), depth=2)
+        ys = multi.frame_rows_of_part(h, band, world, rank)
+        ok = True
+        for f in range(frames):
+            def render(part, f=f):
+                # pixel value encodes (frame, row, column) so any mix-up of slots / bands shows
+                part.copy_((f * 1000003 + ys.view(-1, 1) * 4099 + torch.arange(w).view(1, -1)).to(torch.int32))
+            pipe.submit(render)
+            if rank == 0 and f >= 2:
+                # frames complete in order, two in flight: after submitting f, frame f-2 has been assembled
+                want = ((f - 2) * 1000003 + torch.arange(h).view(-1, 1) * 4099 + torch.arange(w).view(1, -1)).to(torch.int32)
+                ok = ok and torch.equal(pipe.frame, want)
+        last = pipe.drain()
+        if rank == 0:
+            want = ((frames - 1) * 1000003 + torch.arange(h).view(-1, 1) * 4099 + torch.arange(w).view(1, -1)).to(torch.int32)
+            q.put(bool(ok and torch.equal(last, want) and pipe.frames_done == frames))
+        else:
+            assert last is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,h,band", [(2, 24, 4), (4, 32, 2)])
+def test_gather_pipeline_keeps_frames_in_order(world, h, band):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipe_worker, args=(r, world, port, 20, h, band, 5, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
 def test_partition_helpers():
     assert multi.choose_band_rows(4320, 8) == 6 and multi.choose_band_rows(4320, 2) == 8
     assert multi.choose_band_rows(2160, 4) == 6 and multi.choose_band_rows(7, 2) == 0
