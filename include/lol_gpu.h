@@ -128,8 +128,9 @@ const char* lol_gpu_specialize_log(const lol_gpu* ctx);
  * inputs through it and through the plain expression and found no difference; this call runs
  * those checks directly and returns the mismatch counts (0 = proven; ~0 = could not run).
  */
-int         lol_gpu_verify_fast_paths(lol_gpu* ctx, float k, unsigned long long* sqrt_gs_mismatches,
-                                      unsigned long long* sqrt_pm_mismatches, unsigned long long* div_mismatches);
+/* sqrt_mismatches[0..2] = sqrt_pm, sqrt_gs, sqrt_r2 (lol_kernel.h); div_mismatches for the divisor k */
+int         lol_gpu_verify_fast_paths(lol_gpu* ctx, float k, unsigned long long sqrt_mismatches[3],
+                                      unsigned long long* div_mismatches);
 /* No device needed: writes <out_base>.hip (generated source) and <out_base>.co (code object for `arch`).
  * assume_fast != 0 generates the shortcuts without proof — for ISA inspection only, never for rendering. */
 int         lol_gpu_compile_offline(const lol_program* prog, const char* arch, const char* out_base,

@@ -53,7 +53,7 @@ struct lol_gpu {
 	hipFunction_t spec_fn = nullptr;
 	std::string  spec_log;
 	int          want_fast = 1;          /* allow the proven-exact shortcuts in the specialised kernel */
-	int          sqrt_verified = -1;     /* -1 not run, 0 none proven, 1 sqrt_pm, 2 sqrt_gs proven on this device */
+	int          sqrt_verified = -1;     /* -1 not run, 0 none proven, else the lol::sqrt_fast KIND proven on this device */
 	std::vector<std::pair<uint32_t, bool>> div_verified;   /* k bits → proven */
 	unsigned long long* d_bad = nullptr; /* mismatch counter of the verification kernels */
 	char         err[512] = { 0 };
@@ -107,12 +107,12 @@ __global__ __launch_bounds__(VERIFY_THREADS) void verify_sqrt_kernel(unsigned lo
 	if (n) atomicAdd(bad, (unsigned long long)n);
 }
 
-__global__ __launch_bounds__(VERIFY_THREADS) void verify_div_kernel(float k, float rk, unsigned long long* bad) {
+__global__ __launch_bounds__(VERIFY_THREADS) void verify_div_kernel(float k, float k2, float hrk, unsigned long long* bad) {
 	uint32_t base = blockIdx.x * VERIFY_THREADS + threadIdx.x;
 	unsigned n = 0;
 	for (uint32_t it = 0; it < VERIFY_ITERS; it++) {
 		float x = __builtin_bit_cast(float, base + it * (VERIFY_BLOCKS * VERIFY_THREADS));
-		if (!same_float(lol::smin_h_fast(x, k, rk), lol::smin_h_exact(x, k))) n++;
+		if (!same_float(lol::smin_h_fast(x, k2, hrk), lol::smin_h_exact(x, k))) n++;
 	}
 	if (n) atomicAdd(bad, (unsigned long long)n);
 }
@@ -123,9 +123,10 @@ unsigned long long run_verify(lol_gpu* ctx, int sqrt_kind, float k) {
 		return ~0ull;
 	unsigned long long bad = 0;
 	if (hipMemcpy(ctx->d_bad, &bad, sizeof bad, hipMemcpyHostToDevice) != hipSuccess) return ~0ull;
-	if (sqrt_kind == 2) hipLaunchKernelGGL(verify_sqrt_kernel<2>, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, ctx->d_bad);
+	if (sqrt_kind == 3) hipLaunchKernelGGL(verify_sqrt_kernel<3>, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, ctx->d_bad);
+	else if (sqrt_kind == 2) hipLaunchKernelGGL(verify_sqrt_kernel<2>, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, ctx->d_bad);
 	else if (sqrt_kind == 1) hipLaunchKernelGGL(verify_sqrt_kernel<1>, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, ctx->d_bad);
-	else hipLaunchKernelGGL(verify_div_kernel, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, k, 1.0f / k, ctx->d_bad);
+	else hipLaunchKernelGGL(verify_div_kernel, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, k, 2.0f * k, 0.5f * (1.0f / k), ctx->d_bad);
 	if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return ~0ull;
 	if (hipMemcpy(&bad, ctx->d_bad, sizeof bad, hipMemcpyDeviceToHost) != hipSuccess) return ~0ull;
 	return bad;
@@ -143,7 +144,7 @@ std::string fbits(float v) {
 
 /* Which proven-exact shortcuts the generated code may use (see lol_kernel.h "fast exact paths"). */
 struct FastPaths {
-	int sqrt_kind = 0;                    /* 0 plain sqrtf; 1 sqrt_pm, 2 sqrt_gs — proven on this device */
+	int sqrt_kind = 0;                    /* 0 plain sqrtf; 1 sqrt_pm, 2 sqrt_gs, 3 sqrt_r2 — proven on this device */
 	std::vector<float> div_ok;            /* smoothness constants k whose smin_h_fast verified */
 	bool has(float k) const {
 		for (float v : div_ok) if (memcmp(&v, &k, 4) == 0) return true;
@@ -185,8 +186,8 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 			int under = stack.back(); stack.pop_back();
 			int a = o.op == LOL_OP_SMIN ? under : top, b = o.op == LOL_OP_SMIN ? top : under;
 			if (fast && fast->has(o.f[0]))
-				snprintf(line, sizeof line, "\t\tconst float t%d = sminf_fastdiv(t%d, t%d, %s, %s);\n", t, a, b,
-				         fbits(o.f[0]).c_str(), fbits(1.0f / o.f[0]).c_str());
+				snprintf(line, sizeof line, "\t\tconst float t%d = sminf_fastdiv(t%d, t%d, %s, %s, %s);\n", t, a, b,
+				         fbits(o.f[0]).c_str(), fbits(2.0f * o.f[0]).c_str(), fbits(0.5f * (1.0f / o.f[0])).c_str());
 			else
 				snprintf(line, sizeof line, "\t\tconst float t%d = sminf_(t%d, t%d, %s);\n", t, a, b, fbits(o.f[0]).c_str());
 			s += line; stack.push_back(t++); break;
@@ -299,8 +300,9 @@ bool specialise(lol_gpu* ctx) {
 	std::string note;
 	if (ctx->want_fast && !(fenv && fenv[0] == '0')) {
 		if (ctx->sqrt_verified < 0) {
-			if (run_verify(ctx, 2, 0.f) == 0) ctx->sqrt_verified = 2;
-			else ctx->sqrt_verified = run_verify(ctx, 1, 0.f) == 0 ? 1 : 0;
+			ctx->sqrt_verified = 0;                     /* cheapest proven sequence wins */
+			for (int kind = 3; kind >= 1 && !ctx->sqrt_verified; kind--)
+				if (run_verify(ctx, kind, 0.f) == 0) ctx->sqrt_verified = kind;
 		}
 		fast.sqrt_kind = ctx->sqrt_verified;
 		for (uint32_t i = 0; i < ctx->h_prog.n_ops; i++) {
@@ -390,12 +392,12 @@ int lol_gpu_set_specialize(lol_gpu* ctx, int enable) {
 }
 
 /* Run the exhaustive (all 2^32 inputs) equivalence checks directly: mismatch counts out. */
-int lol_gpu_verify_fast_paths(lol_gpu* ctx, float k, unsigned long long* sqrt_gs_mismatches,
-                              unsigned long long* sqrt_pm_mismatches, unsigned long long* div_mismatches) {
+int lol_gpu_verify_fast_paths(lol_gpu* ctx, float k, unsigned long long sqrt_mismatches[3],
+                              unsigned long long* div_mismatches) {
 	if (!ctx) return LOL_GPU_ERR_ARG;
 	LOL_HIP(ctx, hipSetDevice(ctx->device));
-	if (sqrt_gs_mismatches) *sqrt_gs_mismatches = run_verify(ctx, 2, 0.f);
-	if (sqrt_pm_mismatches) *sqrt_pm_mismatches = run_verify(ctx, 1, 0.f);
+	if (sqrt_mismatches)
+		for (int kind = 1; kind <= 3; kind++) sqrt_mismatches[kind - 1] = run_verify(ctx, kind, 0.f);
 	if (div_mismatches) *div_mismatches = run_verify(ctx, 0, k);
 	return LOL_GPU_OK;
 }
@@ -569,7 +571,7 @@ int lol_gpu_compile_offline(const lol_program* prog, const char* arch, const cha
 	std::string lg, src;
 	FastPaths fast;
 	if (assume_fast) {                 /* ISA inspection only: pretend every shortcut was proven */
-		fast.sqrt_kind = assume_fast == 1 ? 2 : 1;
+		fast.sqrt_kind = assume_fast >= 1 && assume_fast <= 3 ? 4 - assume_fast : 3;   /* 1 → sqrt_r2, 2 → sqrt_gs, 3 → sqrt_pm */
 		for (uint32_t i = 0; i < prog->n_ops; i++)
 			if ((prog->ops[i].op == LOL_OP_SMIN || prog->ops[i].op == LOL_OP_SMIN_R) && !fast.has(prog->ops[i].f[0]))
 				fast.div_ok.push_back(prog->ops[i].f[0]);

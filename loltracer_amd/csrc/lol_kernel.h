@@ -139,6 +139,15 @@ __device__ __forceinline__ float sqrt_gs(float x) {
 	float d = __builtin_fmaf(-s, s, x);
 	return __builtin_fmaf(d, h, s);
 }
+/* sqrt_r2: the same without the first refinement of (s, h) — v_rsq_f32, 2 mul, 2 fma.  An exhaustive run
+ * (tools/sqrt_search.hip) found it correctly rounded on the whole domain as well; preferred when it verifies. */
+__device__ __forceinline__ float sqrt_r2(float x) {
+	float y = __builtin_amdgcn_rsqf(x);
+	float s = x * y;
+	float h = y * 0.5f;
+	float d = __builtin_fmaf(-s, s, x);
+	return __builtin_fmaf(d, h, s);
+}
 /* sqrt_pm: v_sqrt_f32 (1 ulp) + the +-1 ulp residual test of hipcc's denormal-safe expansion, minus
  * its input scaling and class fix-up.  Proven for x == 0, 2^-96 <= x <= inf and NaN.  Fallback when
  * sqrt_gs does not verify on a device. */
@@ -163,24 +172,31 @@ struct Range {
 	}
 	__device__ __forceinline__ bool outside() const { return lo < SQRT_FAST_MIN_BITS || hi >= F32_INF_BITS; }
 };
-template <int KIND> __device__ __forceinline__ float sqrt_fast(float x) { return KIND == 2 ? sqrt_gs(x) : sqrt_pm(x); }
-
-/* x / k for a scene constant k with rk = 1/k: product, one residual correction, then the
- * hardware's special-case fix-up.  sminf_fastdiv() is what gets verified (over all x). */
-__device__ __forceinline__ float div_const(float x, float k, float rk) {
-	float q = x * rk;
-	float r = __builtin_fmaf(-q, k, x);
-	q = __builtin_fmaf(r, rk, q);
-	return __builtin_amdgcn_div_fixupf(q, k, x);
+template <int KIND> __device__ __forceinline__ float sqrt_fast(float x) {
+	return KIND == 3 ? sqrt_r2(x) : KIND == 2 ? sqrt_gs(x) : sqrt_pm(x);
 }
-__device__ __forceinline__ float smin_h_exact(float x, float k) { return clampf_(.5f + x / k, 0.f, 1.f); }
-__device__ __forceinline__ float smin_h_fast(float x, float k, float rk) { return clampf_(.5f + div_const(x, k, rk), 0.f, 1.f); }
-/* sminf with the division replaced; x = .5f*(b-a) exactly as in sminf_ */
-__device__ __forceinline__ float sminf_fastdiv(float a, float b, float k, float rk) {
-	float h = smin_h_fast(.5f * (b - a), k, rk);
+
+/* The smooth-min blend factor h = clamp(.5f + (.5f*(b-a))/k, 0, 1) (float.h:30) as a function of
+ * dlt = b - a, for a scene constant k.  .5f*dlt is an exact scaling, so with k2 = 2k and hrk = .5f*(1/k):
+ *   q = dlt*hrk;  r = fma(-q, k2, dlt);  q = fma(r, hrk, q);  q = div_fixup(q, k2, dlt)
+ * is the product / one-residual-correction / hardware special-case fix-up form of (.5f*dlt)/k: 4
+ * instructions instead of the 11 of a correctly rounded division (the .5f multiply folds away too).
+ * smin_h_fast is what gets proven equal to smin_h_exact over all 2^32 values of dlt, per k. */
+__device__ __forceinline__ float smin_h_exact(float dlt, float k) { return clampf_(.5f + .5f * dlt / k, 0.f, 1.f); }
+__device__ __forceinline__ float smin_h_fast(float dlt, float k2, float hrk) {
+	float q = dlt * hrk;
+	float r = __builtin_fmaf(-q, k2, dlt);
+	q = __builtin_fmaf(r, hrk, q);
+	q = __builtin_amdgcn_div_fixupf(q, k2, dlt);
+	return clampf_(.5f + q, 0.f, 1.f);
+}
+/* sminf (float.h:29-33) with the proven blend factor */
+__device__ __forceinline__ float sminf_fastdiv(float a, float b, float k, float k2, float hrk) {
+	float h = smin_h_fast(b - a, k2, hrk);
 	return (b + (a - b) * h) - k * h * (1.f - h);
 }
-/* sd_sphere / sd_round_box on a proven fast sqrt (KIND 1 = sqrt_pm, 2 = sqrt_gs) */
+
+/* sd_sphere / sd_round_box on a proven fast sqrt (KIND 1 = sqrt_pm, 2 = sqrt_gs, 3 = sqrt_r2) */
 template <int KIND>
 __device__ __forceinline__ float sd_sphere_fast(V3 p, float cx, float cy, float cz, float r, Range& rg) {
 	V3 q = { p.x - cx, p.y - cy, p.z - cz };

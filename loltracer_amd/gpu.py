@@ -81,7 +81,7 @@ def gpu_lib() -> C.CDLL:
         lib.lol_gpu_specialize_log.restype = C.c_char_p
         lib.lol_gpu_compile_offline.argtypes = [P(S.Program), C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]
         lib.lol_gpu_compile_offline.restype = C.c_int
-        lib.lol_gpu_verify_fast_paths.argtypes = [vp, C.c_float, P(C.c_ulonglong), P(C.c_ulonglong), P(C.c_ulonglong)]
+        lib.lol_gpu_verify_fast_paths.argtypes = [vp, C.c_float, P(C.c_ulonglong), P(C.c_ulonglong)]
         lib.lol_gpu_verify_fast_paths.restype = C.c_int
         _lib = lib
     return _lib
@@ -161,10 +161,10 @@ class Renderer:
         return self._lib.lol_gpu_kernel_name(self._ctx).decode()
 
     def verify_fast_paths(self, k: float = 3.0):
-        """(sqrt_gs, sqrt_pm, x/k) mismatch counts over all 2^32 float inputs; 0 means proven exact."""
-        a, b, c = C.c_ulonglong(), C.c_ulonglong(), C.c_ulonglong()
-        self._check(self._lib.lol_gpu_verify_fast_paths(self._ctx, k, C.byref(a), C.byref(b), C.byref(c)))
-        return a.value, b.value, c.value
+        """([sqrt_pm, sqrt_gs, sqrt_r2], x/k) mismatch counts over all 2^32 float inputs; 0 means proven exact."""
+        sq, dv = (C.c_ulonglong * 3)(), C.c_ulonglong()
+        self._check(self._lib.lol_gpu_verify_fast_paths(self._ctx, k, sq, C.byref(dv)))
+        return list(sq), dv.value
 
     def specialize_log(self) -> str:
         return self._lib.lol_gpu_specialize_log(self._ctx).decode(errors="replace")

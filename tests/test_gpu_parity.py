@@ -176,12 +176,11 @@ def test_fast_paths_are_proven_exhaustively(torch_cuda, scenes):
     """All 2^32 float inputs: sqrt_fast == sqrtf (outside (0, 2^-96)) and clamp(.5 + x/k) via div_const == exact."""
     r = gpu.Renderer(0)
     for k in (3.0, 1.0, 0.1, 7.5, 1e-3, 1e20):
-        gs, pm, dv = r.verify_fast_paths(k)
-        assert gs == 0, f"sqrt_gs differs from sqrtf on {gs} inputs"
-        assert pm == 0, f"sqrt_pm differs from sqrtf on {pm} inputs"
+        sq, dv = r.verify_fast_paths(k)
+        assert sq == [0, 0, 0], f"sqrt_pm / sqrt_gs / sqrt_r2 differ from sqrtf on {sq} inputs"
         assert dv == 0, f"smooth-min division by {k} differs on {dv} inputs"
     r.prepare(scenes["scene4"])
-    assert "sqrt=2, smin divisors=1" in r.specialize_log()
+    assert "sqrt=3, smin divisors=1" in r.specialize_log()
     r.close()
 
 
