@@ -1,0 +1,104 @@
+"""Randomised scenes: every node kind, nested smooth unions, several lights — GPU (all kernels) vs oracle.
+
+The example scenes exercise one rounded box and one tree shape; this generates `.lol` text with random trees
+(spheres, rounded boxes, planes, smooth unions nested up to 4 deep, both left- and right-leaning so that
+SMIN and SMIN_R both occur), 0-3 lights, random materials and cameras (sometimes inside an object), renders
+small frames and requires the same bit-level agreement as tests/test_gpu_parity.py.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from loltracer_amd import gpu, scene as S
+from test_gpu_parity import check_against_oracle, gpu_render
+
+pytestmark = pytest.mark.gpu
+
+
+def fmt(v):
+    return "(%s)" % ", ".join("%.4g" % x for x in v)
+
+
+def rand_leaf(rng):
+    kind = rng.integers(3)
+    if kind == 0:
+        return "sphere { point = %s, radius = %.4g }" % (fmt(rng.normal(size=3) * [4, 2, 4] + [0, 1, -7]), rng.uniform(0.3, 3))
+    if kind == 1:
+        return "box { point = %s, point2 = %s, radius = %.4g }" % (
+            fmt(rng.normal(size=3) * [4, 2, 4] + [0, 1, -7]), fmt(rng.uniform(0.2, 2.5, size=3)), rng.uniform(0, 0.8))
+    return "plane { y = %.4g }" % rng.uniform(-3, 0)
+
+
+def rand_tree(rng, depth):
+    if depth == 0 or rng.random() < 0.3:
+        return rand_leaf(rng)
+    a, b = rand_tree(rng, depth - 1), rand_tree(rng, int(rng.integers(0, depth)))
+    if rng.random() < 0.5:
+        a, b = b, a
+    return "smooth_union { smoothness = %.4g, a = %s, b = %s }" % (rng.choice([0.5, 1, 2, 3, 0.25, 7.5]), a, b)
+
+
+def rand_scene(rng):
+    n_mat = int(rng.integers(1, 5))
+    mats = []
+    for i in range(n_mat):
+        z = i == 0 and rng.random() < 0.5
+        mats.append("{ shininess = %.4g, diffuse = %s, specular = %s, ambient = %s }" % (
+            rng.choice([0, 1, 2, 8, 30.5]), fmt(rng.uniform(0, 0 if z else 0.6, 3)), fmt(rng.uniform(0, 0 if z else 0.4, 3)),
+            fmt(rng.uniform(0, 0.5, 3))))
+    comps = ["ambient { color = %s }" % fmt(rng.uniform(0, 0.2, 3)),
+             "camera { point = %s, direction = %s, fov = %.4g }" % (
+                 fmt(rng.normal(size=3) * [2, 1, 2] + [0, 2, 2]), fmt(rng.normal(size=3) * 0.4 + [0, -0.3, -1]),
+                 rng.uniform(40, 160))]
+    for _ in range(int(rng.integers(0, 4))):
+        comps.append("point_light { point = %s, diffuse_intensity = %s, specular_intensity = %s }" % (
+            fmt(rng.normal(size=3) * 5 + [0, 8, -3]), fmt(rng.uniform(0.5, 4, 3)), fmt(rng.uniform(0, 4, 3))))
+    for _ in range(int(rng.integers(1, 5))):
+        obj = rand_tree(rng, int(rng.integers(0, 5)))
+        head, rest = obj.split("{", 1)
+        comps.append("%s{ material = #%d,%s" % (head, rng.integers(n_mat), rest))
+    return "materials { %s }\nscene { %s }\n" % (",\n".join(mats), ",\n".join(comps))
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+@pytest.mark.parametrize("mode", [1, 3, 0], ids=["spec", "spec-plain", "interp"])
+def test_random_scenes(torch_cuda, mode):
+    rng = np.random.default_rng(20261004)
+    r = gpu.Renderer(0, specialize=mode)
+    ops_seen = set()
+    for i in range(24):
+        text = rand_scene(rng)
+        sc = S.Scene.parse_string(text)
+        prog = sc.flatten()
+        ops_seen |= {prog.ops[k].op for k in range(prog.n_ops)}
+        w, h = int(rng.integers(17, 70)), int(rng.integers(9, 40))
+        g = gpu_render(torch_cuda, r, sc, w, h)
+        try:
+            check_against_oracle(g, sc, w, h)
+        except AssertionError as e:
+            raise AssertionError(f"scene {i} ({w}x{h}) failed: {e}\n{text}") from e
+    assert ops_seen == {S.OP_SPHERE, S.OP_RBOX, S.OP_PLANE, S.OP_SMIN, S.OP_SMIN_R, S.OP_TOP}
+    r.close()
+
+
+def test_degenerate_inputs(torch_cuda):
+    """No lights, no objects, camera inside a sphere / on a plane, negative shininess (powf → inf → NaN → 1.0)."""
+    cases = [
+        "materials { { shininess = 2, diffuse = (1,1,1), specular = (1,1,1), ambient = (.5,.25,.125) } } scene { ambient { color = (1,1,1) } }",
+        "materials { { shininess = 2, diffuse = (1,1,1), specular = (1,1,1), ambient = (.5,.5,.5) } } scene { ambient { color = (.3,.3,.3) }, sphere { radius = 5 }, point_light { point = (0,9,0), diffuse_intensity = (1,1,1), specular_intensity = (1,1,1) } }",
+        "materials { { shininess = -1.5, diffuse = (.2,.2,.2), specular = (.3,.3,.3), ambient = (0,0,0) } } scene { camera { point = (0,1,0), direction = (0,-.2,-1), fov = 90 }, plane { y = 0 }, point_light { point = (2,5,-3), diffuse_intensity = (2,2,2), specular_intensity = (2,2,2) } }",
+        "materials { { shininess = 4, diffuse = (.2,.2,.2), specular = (.3,.3,.3), ambient = (.1,.1,.1) } } scene { camera { point = (0,0,0), direction = (0,0,-1), fov = 120 }, plane { y = 0 }, box { point = (0,0,-4), point2 = (1,1,1), radius = 0 }, point_light { point = (0,0,0), diffuse_intensity = (2,2,2), specular_intensity = (2,2,2) } }",
+    ]
+    for mode in (1, 0):
+        r = gpu.Renderer(0, specialize=mode)
+        for text in cases:
+            sc = S.Scene.parse_string(text)
+            g = gpu_render(torch_cuda, r, sc, 40, 24)
+            check_against_oracle(g, sc, 40, 24)
+        r.close()
