@@ -138,11 +138,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: there is no CPU rendering path")
+    # Rehearsal switch for a 1-GPU box: LOL_BENCH_REHEARSE=1 puts every rank on device 0 and uses gloo, so
+    # the N>1 code path (partition, pipelined gather, assembly, timing) can be exercised without N GPUs.
+    rehearse = os.environ.get("LOL_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     name = args.workload or ("c3" if world == 1 else "c4")
     cfg = WORKLOADS[name]
@@ -216,6 +224,16 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if os.environ.get("LOL_BENCH_CHECK") == "1" and pipe is not None:
+        # correctness rehearsal: the assembled frame on rank 0 must equal a single-launch render of the frame
+        final = pipe.drain()
+        if rank == 0:
+            ref = torch.zeros((h, w), dtype=torch.int32, device=dev)
+            r.render_into(ref.data_ptr(), w, h, max_steps, stream=stream, frame_camera=cams[0])
+            torch.cuda.synchronize()
+            same = bool(torch.equal(final, ref))
+            print(f"[check] assembled {world}-rank frame == single-launch frame: {same}", file=sys.stderr, flush=True)
+            assert same
 
     k_ms = [a.elapsed_time(b) for a, b in kernel_ms]
     k_avg = sum(k_ms) / max(len(k_ms), 1)
