@@ -131,6 +131,16 @@ const char* lol_gpu_specialize_log(const lol_gpu* ctx);
 /* sqrt_mismatches[0..2] = sqrt_pm, sqrt_gs, sqrt_r2 (lol_kernel.h); div_mismatches for the divisor k */
 int         lol_gpu_verify_fast_paths(lol_gpu* ctx, float k, unsigned long long sqrt_mismatches[3],
                                       unsigned long long* div_mismatches);
+/*
+ * Escaped rays are shaded with material #0 (naive_renderer.c:103-112).  When that material has
+ * diffuse == specular == 0, shininess >= 0 and all light intensities are finite, their colour is exactly
+ * clamp(ambient_color * material.ambient) whatever the normal and shadow factors are, so a wavefront whose
+ * rays ALL escaped skips the normal taps and shadow marches.  On by default when the uploaded program
+ * qualifies (checked on the host); set_miss_skip(ctx, 0) or LOL_GPU_MISS_SKIP=0 turn it off.  With it on,
+ * lol_gpu_debug.steps reports 0 shadow steps for the skipped pixels.
+ */
+int         lol_gpu_set_miss_skip(lol_gpu* ctx, int enable);
+int         lol_gpu_miss_skip_active(const lol_gpu* ctx);
 /* No device needed: writes <out_base>.hip (generated source) and <out_base>.co (code object for `arch`).
  * assume_fast != 0 generates the shortcuts without proof — for ISA inspection only, never for rendering. */
 int         lol_gpu_compile_offline(const lol_program* prog, const char* arch, const char* out_base,

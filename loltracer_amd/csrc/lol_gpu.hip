@@ -53,6 +53,8 @@ struct lol_gpu {
 	hipFunction_t spec_fn = nullptr;
 	std::string  spec_log;
 	int          want_fast = 1;          /* allow the proven-exact shortcuts in the specialised kernel */
+	int          want_miss_skip = 1;     /* allow FLAG_MISS_SKIP when the program qualifies */
+	bool         miss_skip = false;      /* the uploaded program qualifies (miss_skip_ok) */
 	int          sqrt_verified = -1;     /* -1 not run, 0 none proven, else the lol::sqrt_fast KIND proven on this device */
 	std::vector<std::pair<uint32_t, bool>> div_verified;   /* k bits → proven */
 	unsigned long long* d_bad = nullptr; /* mismatch counter of the verification kernels */
@@ -80,6 +82,25 @@ template <int STACK>
 hipError_t launch_interp(const lol::Launch& L, dim3 grid, size_t lds, hipStream_t s) {
 	hipLaunchKernelGGL(lol::render_interp<STACK>, grid, dim3(lol::BLOCK), lds, s, L);
 	return hipGetLastError();
+}
+
+/* Conditions under which an escaped ray's colour is exactly clamp(ambient * materials[0].ambient), so
+ * that waves of escaped rays may skip normal + lights (lol_kernel.h, FLAG_MISS_SKIP): material #0 has
+ * diffuse == specular == 0 (either sign), shininess >= 0 and not NaN (powf(c in [0,1], s >= 0) is finite),
+ * and every light intensity is finite (finite * 0 = 0, never NaN). */
+bool miss_skip_ok(const lol_program& P) {
+	if (P.n_materials == 0) return false;
+	const lol_material& m = P.materials[0];
+	const float z[6] = { m.diffuse.x, m.diffuse.y, m.diffuse.z, m.specular.x, m.specular.y, m.specular.z };
+	for (float v : z) if (!(v == 0.0f)) return false;
+	if (!(m.shininess >= 0.0f)) return false;
+	for (uint32_t i = 0; i < P.n_lights; i++) {
+		const lol_light& l = P.lights[i];
+		const float f[6] = { l.diffuse_intensity.x, l.diffuse_intensity.y, l.diffuse_intensity.z,
+		                     l.specular_intensity.x, l.specular_intensity.y, l.specular_intensity.z };
+		for (float v : f) if (!(v - v == 0.0f)) return false;      /* inf or NaN */
+	}
+	return true;
 }
 
 /* --------------------------------------------- exhaustive proofs of the fast paths
@@ -391,6 +412,15 @@ int lol_gpu_set_specialize(lol_gpu* ctx, int enable) {
 	return LOL_GPU_OK;
 }
 
+int lol_gpu_set_miss_skip(lol_gpu* ctx, int enable) {
+	if (!ctx) return LOL_GPU_ERR_ARG;
+	ctx->want_miss_skip = enable ? 1 : 0;
+	if (ctx->have_prog) ctx->miss_skip = ctx->want_miss_skip && miss_skip_ok(ctx->h_prog);
+	return LOL_GPU_OK;
+}
+
+int lol_gpu_miss_skip_active(const lol_gpu* ctx) { return ctx && ctx->miss_skip ? 1 : 0; }
+
 /* Run the exhaustive (all 2^32 inputs) equivalence checks directly: mismatch counts out. */
 int lol_gpu_verify_fast_paths(lol_gpu* ctx, float k, unsigned long long sqrt_mismatches[3],
                               unsigned long long* div_mismatches) {
@@ -436,6 +466,8 @@ int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog) {
 	LOL_HIP(ctx, hipMemcpy(ctx->d_prog, prog, sizeof *prog, hipMemcpyHostToDevice));
 	ctx->h_prog = *prog;
 	ctx->have_prog = true;
+	const char* ms = getenv("LOL_GPU_MISS_SKIP");
+	ctx->miss_skip = ctx->want_miss_skip && !(ms && ms[0] == '0') && miss_skip_ok(*prog);
 	specialise(ctx);
 	return LOL_GPU_OK;
 }
@@ -485,6 +517,7 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	L.materials     = reinterpret_cast<const uint32_t*>(base + offsetof(lol_program, materials));
 	L.root_material = reinterpret_cast<const uint32_t*>(base + offsetof(lol_program, root_material));
 	L.ambient[0] = P.ambient_color.x; L.ambient[1] = P.ambient_color.y; L.ambient[2] = P.ambient_color.z;
+	L.flags = ctx->miss_skip ? lol::FLAG_MISS_SKIP : 0u;
 	L.dst = static_cast<uint32_t*>(dst);
 	L.pitch_px = (uint32_t)(pitch_bytes / 4);
 	if (dbg) {

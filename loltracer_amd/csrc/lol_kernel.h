@@ -47,6 +47,9 @@ constexpr int BLOCK  = TILE_W * TILE_H;   /* 256 threads = 4 waves; wave k owns 
 constexpr int OP_DWORDS = 10, LIGHT_DWORDS = 9, MATERIAL_DWORDS = 10;
 enum { OP_SPHERE = 0, OP_RBOX = 1, OP_PLANE = 2, OP_SMIN = 3, OP_SMIN_R = 4, OP_TOP = 5 };
 
+/* Launch.flags */
+constexpr u32 FLAG_MISS_SKIP = 1u;   /* a wave whose rays all escaped may skip normal + lights (see shade_pixel) */
+
 /* = lol_frame_camera */
 struct Cam { float origin[3], dir[3], right[3], up[3]; float width, height; };
 
@@ -64,6 +67,7 @@ struct Launch {
 	const u32* materials;
 	const u32* root_material;
 	float  ambient[3];
+	u32    flags;                /* FLAG_* */
 	u32*   dst;                  /* XRGB8888, pitch_px dwords per local row */
 	u32    pitch_px;
 	float* dbg_rgb;
@@ -368,8 +372,6 @@ __device__ __forceinline__ Pixel shade_pixel(const Launch& L, Sdf& sdf, const u3
 	rd = normalize(add(rd, cdir));
 
 	Hit hit = march(sdf, ro, rd, L.max_steps);
-	V3 p = add(ro, scale(rd, hit.dist));
-	V3 n = normal_at(sdf, p, hit.dist);
 
 	/* get_material, naive_renderer.c:103-112 (per-lane table lookups) */
 	u32 mid = hit.id ? l_rootm[hit.id - 1] : 0u;
@@ -377,24 +379,39 @@ __device__ __forceinline__ Pixel shade_pixel(const Launch& L, Sdf& sdf, const u3
 	const float shininess = m[0];
 	const V3 m_diff = { m[1], m[2], m[3] }, m_spec = { m[4], m[5], m[6] }, m_amb = { m[7], m[8], m[9] };
 
+	/*
+	 * A ray that escaped is shaded with material #0 (naive_renderer.c:103-112).  When the host has checked
+	 * that material #0 has diffuse == specular == 0, shininess >= 0 and every light intensity is finite
+	 * (lol_gpu.hip: miss_skip_ok), each light's two terms are (finite) * (+-0) = +-0 whatever the normal and
+	 * the shadow factor turn out to be, the running sum stays +0, and get_light() returns exactly
+	 * clamp(ambient_color * material.ambient).  So a wave in which EVERY lane escaped skips the 4 normal taps
+	 * and the shadow marches (about 13 % of all SDF evaluations on scene4) and falls through to the same
+	 * `0 + ambient*mat.ambient` expression; a wave with at least one hit runs everything for all its lanes.
+	 */
+	const bool lit = !((L.flags & FLAG_MISS_SKIP) && __ballot(hit.id != 0u) == 0);
+
 	/* get_light, naive_renderer.c:129-175 */
 	V3 total = { 0.f, 0.f, 0.f };
 	u32 shadow_steps = 0;
-	const V3 camera_dir = normalize(sub(ro, p));
-	for (u32 li = 0; li < L.n_lights; li++) {
-		const u32* lp = l_light + li * LIGHT_DWORDS;
-		V3 to_light = sub(lds_v3(lp), p);
-		float light_dist = len(to_light);
-		V3 light_dir = scale(to_light, 1.0f / light_dist);      /* == v3normalize(light - p) */
-		float shadow = soft_shadow(sdf, p, light_dir, light_dist, shadow_steps);
+	if (lit) {
+		V3 p = add(ro, scale(rd, hit.dist));
+		V3 n = normal_at(sdf, p, hit.dist);
+		const V3 camera_dir = normalize(sub(ro, p));
+		for (u32 li = 0; li < L.n_lights; li++) {
+			const u32* lp = l_light + li * LIGHT_DWORDS;
+			V3 to_light = sub(lds_v3(lp), p);
+			float light_dist = len(to_light);
+			V3 light_dir = scale(to_light, 1.0f / light_dist);      /* == v3normalize(light - p) */
+			float shadow = soft_shadow(sdf, p, light_dir, light_dist, shadow_steps);
 
-		V3 refl = sub(scale(n, 2.f * dot(light_dir, n)), light_dir);
-		float di = clampf_(dot(n, light_dir), 0.f, 1.f);
-		V3 Id = mul(scale(lds_v3(lp + 3), shadow * di), m_diff);
-		total = add(total, Id);
-		float si = di * powf(clampf_(dot(refl, camera_dir), 0.f, 1.f), shininess);
-		V3 Is = mul(scale(lds_v3(lp + 6), shadow * si), m_spec);
-		total = add(total, Is);
+			V3 refl = sub(scale(n, 2.f * dot(light_dir, n)), light_dir);
+			float di = clampf_(dot(n, light_dir), 0.f, 1.f);
+			V3 Id = mul(scale(lds_v3(lp + 3), shadow * di), m_diff);
+			total = add(total, Id);
+			float si = di * powf(clampf_(dot(refl, camera_dir), 0.f, 1.f), shininess);
+			V3 Is = mul(scale(lds_v3(lp + 6), shadow * si), m_spec);
+			total = add(total, Is);
+		}
 	}
 	total = add(total, mul(v3(L.ambient), m_amb));
 	/* v3clamp: max(min(v, 1), 0) — NaN → 1 (vec.h:63-65) */

@@ -83,6 +83,10 @@ def gpu_lib() -> C.CDLL:
         lib.lol_gpu_compile_offline.restype = C.c_int
         lib.lol_gpu_verify_fast_paths.argtypes = [vp, C.c_float, P(C.c_ulonglong), P(C.c_ulonglong)]
         lib.lol_gpu_verify_fast_paths.restype = C.c_int
+        lib.lol_gpu_set_miss_skip.argtypes = [vp, C.c_int]
+        lib.lol_gpu_set_miss_skip.restype = C.c_int
+        lib.lol_gpu_miss_skip_active.argtypes = [vp]
+        lib.lol_gpu_miss_skip_active.restype = C.c_int
         _lib = lib
     return _lib
 
@@ -91,7 +95,8 @@ EXPORTED_SYMBOLS = [
     "lol_gpu_device_count", "lol_gpu_create", "lol_gpu_destroy", "lol_gpu_error", "lol_gpu_upload_program",
     "lol_gpu_part_rows", "lol_gpu_render_device", "lol_gpu_render_host", "lol_gpu_sync", "lol_gpu_malloc",
     "lol_gpu_free", "lol_gpu_memcpy_d2h", "lol_gpu_kernel_name", "lol_gpu_set_specialize",
-    "lol_gpu_specialize_log", "lol_gpu_compile_offline", "lol_gpu_verify_fast_paths",
+    "lol_gpu_specialize_log", "lol_gpu_compile_offline", "lol_gpu_verify_fast_paths", "lol_gpu_set_miss_skip",
+    "lol_gpu_miss_skip_active",
 ]
 
 
@@ -165,6 +170,12 @@ class Renderer:
         sq, dv = (C.c_ulonglong * 3)(), C.c_ulonglong()
         self._check(self._lib.lol_gpu_verify_fast_paths(self._ctx, k, sq, C.byref(dv)))
         return list(sq), dv.value
+
+    def set_miss_skip(self, enable: bool):
+        self._check(self._lib.lol_gpu_set_miss_skip(self._ctx, 1 if enable else 0))
+
+    def miss_skip_active(self) -> bool:
+        return bool(self._lib.lol_gpu_miss_skip_active(self._ctx))
 
     def specialize_log(self) -> str:
         return self._lib.lol_gpu_specialize_log(self._ctx).decode(errors="replace")

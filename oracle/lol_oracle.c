@@ -234,7 +234,7 @@ static uint32_t pack_xrgb(v3 c) {
 /* the pixel body of render_thread, naive_renderer.c:217-235 */
 static uint32_t shade_pixel(const lol_scene* sc, const lol_camera* cam, int x, int y,
                             float fwidth, float fheight, int max_steps, struct tally* t,
-                            float* rgb_out, lol_oracle_probe* probe, int* missed) {
+                            float* rgb_out, lol_oracle_probe* probe, int* missed, uint32_t* hit_id) {
 	v3 ro = from_lol(cam->point);
 	float aspect = fwidth / fheight;
 	float vx = (x + .5f) / fwidth * 2.f - 1.f;
@@ -250,6 +250,7 @@ static uint32_t shade_pixel(const lol_scene* sc, const lol_camera* cam, int x, i
 	uint32_t px = pack_xrgb(c);
 
 	if (missed) *missed = hit.id == 0;
+	if (hit_id) *hit_id = hit.id;
 	if (rgb_out) { rgb_out[0] = c.x; rgb_out[1] = c.y; rgb_out[2] = c.z; }
 	if (probe) {
 		probe->rd[0] = rd.x; probe->rd[1] = rd.y; probe->rd[2] = rd.z;
@@ -271,12 +272,16 @@ static void render_row(const lol_scene* sc, const lol_camera* cam, int w, int h,
 	for (int x = 0; x < w; x++) {
 		struct tally t = { 0, 0, 0, 0 };
 		int missed = 0;
+		uint32_t hit_id = 0;
 		uint32_t px = shade_pixel(sc, cam, x, y, fw, fh, max_steps, &t,
-		                          rgb ? rgb + ((size_t)y * w + x) * 3 : NULL, NULL, &missed);
+		                          rgb ? rgb + ((size_t)y * w + x) * 3 : NULL, NULL, &missed, &hit_id);
 		if (xrgb) memcpy((char*)xrgb + (size_t)y * pitch + (size_t)x * 4, &px, 4);
 		if (steps) {
-			steps[((size_t)y * w + x) * 2 + 0] = (uint16_t)t.march_steps;
-			steps[((size_t)y * w + x) * 2 + 1] = (uint16_t)(t.shadow_steps > 65535 ? 65535 : t.shadow_steps);
+			uint16_t* o = steps + ((size_t)y * w + x) * 4;
+			o[0] = (uint16_t)t.march_steps;
+			o[1] = (uint16_t)(t.shadow_steps > 65535 ? 65535 : t.shadow_steps);
+			o[2] = (uint16_t)(hit_id > 65535 ? 65535 : hit_id);
+			o[3] = 0;
 		}
 		if (ctr) {
 			ctr->pixels++;
@@ -371,7 +376,7 @@ void lol_oracle_probe_pixel(const lol_scene* sc, const lol_camera* cam, int w, i
                             int x, int y, lol_oracle_probe* out) {
 	struct tally t = { 0, 0, 0, 0 };
 	memset(out, 0, sizeof *out);
-	shade_pixel(sc, cam, x, y, (float)w, (float)h, max_steps, &t, NULL, out, NULL);
+	shade_pixel(sc, cam, x, y, (float)w, (float)h, max_steps, &t, NULL, out, NULL, NULL);
 }
 
 float lol_oracle_sdf(const lol_scene* sc, float px, float py, float pz, uint32_t* id) {

@@ -7,14 +7,15 @@
  * bench.py's `cpu_baseline` leg may load it; the product (loltracer_amd/,
  * include/lol_gpu.h) never links or calls anything in oracle/.
  *
- * Pinning: the reference ships no tests or golden images.  The
- * restatement is pinned by (1) the five whole-frame XRGB8888 hashes the survey
- * recorded from the unmodified naive_renderer.c, checked in
- * tests/test_oracle.py, and (2) oracle/_ref — the reference's own SDL-free
- * headers (float.h, vec.h, sdf.h) and scene.c compiled where they lie and
- * compared bit-for-bit with the primitives here (oracle/ref_harness.c).
- * naive_renderer.c itself cannot be compiled in this image (it includes
- * <SDL.h> through renderer.h and SDL2 is absent), see DESIGN.md.
+ * Pinning (details and honest limits in DESIGN.md §5): the reference ships no tests or golden
+ * images, and naive_renderer.c itself cannot be compiled in this image (it
+ * includes <SDL.h> through renderer.h; SDL2 is absent).  The restatement is pinned by
+ *  (1) oracle/_ref — the reference's own SDL-free headers (float.h, vec.h, sdf.h) and scene.c
+ *      compiled where they lie; their outputs on committed input vectors
+ *      (tests/golden/ref_primitives.json, ref_scenes.json) must match bit for bit;
+ *  (2) the known pixels and per-pixel work counters the survey recorded from the unmodified
+ *      naive_renderer.c — reproduced; its whole-frame hashes are NOT reproduced,
+ *      so the pipeline level is only partially pinned.
  */
 #ifndef LOL_ORACLE_H
 #define LOL_ORACLE_H
@@ -58,7 +59,7 @@ typedef struct lol_oracle_probe {
  *   xrgb   : h rows of `pitch_bytes`; pixel (x,y) at xrgb + y*pitch + 4*x,
  *            value r<<16|g<<8|b (renderer.h:17-22 with an XRGB8888 surface)
  *   rgb    : optional w*h*3 floats, post-gamma pre-quantisation, row-major
- *   steps  : optional w*h uint16 pairs {march, shadow-total} per pixel
+ *   steps  : optional w*h x 4 uint16 {march steps, shadow steps (all lights), hit id, 0} per pixel
  *   ctr    : optional counters, accumulated (caller zeroes)
  */
 void lol_oracle_render_rows(const lol_scene* scene, const lol_camera* cam,

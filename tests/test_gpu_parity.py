@@ -50,7 +50,8 @@ def gpu_render(torch, r, sc, w, h, max_steps=256, rows=None, camera=None, pitch_
                   debug=dbg, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     return dict(xrgb=frame.cpu().numpy().view(np.uint32), rgb=rgb.cpu().numpy(), dist=dist.cpu().numpy(),
-                id=hid.cpu().numpy().view(np.uint32), steps=steps.cpu().numpy().view(np.uint32))
+                id=hid.cpu().numpy().view(np.uint32), steps=steps.cpu().numpy().view(np.uint32),
+                miss_skip=r.miss_skip_active())
 
 
 def channels(x):
@@ -63,7 +64,15 @@ def check_against_oracle(g, sc, w, h, max_steps=256, y0=0, y1=None, camera=None)
     ox, orgb, osteps = ox[y0:y1], orgb[y0:y1], osteps[y0:y1]
     gx = g["xrgb"][:, :w]
     assert np.array_equal(g["steps"] & 0xFFFF, osteps[..., 0]), "march step counts differ"
-    assert np.array_equal(g["steps"] >> 16, osteps[..., 1]), "shadow step counts differ"
+    gsh, osh = g["steps"] >> 16, osteps[..., 1]
+    if g.get("miss_skip"):
+        # waves of escaped rays skip their shadow marches (lol_gpu.h, lol_gpu_set_miss_skip): 0 steps there
+        skipped = (osteps[..., 2] == 0) & (gsh == 0)
+        assert np.array_equal(np.where(skipped, osh, gsh), osh), "shadow step counts differ"
+    else:
+        assert np.array_equal(gsh, osh), "shadow step counts differ"
+    if "id" in g:
+        assert np.array_equal(g["id"], osteps[..., 2]), "hit ids differ"
     d = np.abs(g["rgb"] - orgb)
     assert np.nanmax(d) <= RGB_TOL, f"max |rgb delta| = {np.nanmax(d)}"
     assert not np.isnan(g["rgb"]).any()
@@ -159,7 +168,7 @@ def test_full_size_sampled_rows_and_partition(torch_cuda, renderer, scenes):
     w, h = 3840, 2160
     g = gpu_render(torch_cuda, renderer, sc, w, h)
     for y in (0, 777, 1080, 1500, 2159):
-        sub = {k: v[y:y + 1] for k, v in g.items()}
+        sub = {k: (v[y:y + 1] if isinstance(v, np.ndarray) else v) for k, v in g.items()}
         check_against_oracle(sub, sc, w, h, y0=y, y1=y + 1)
     # size-independent property: 8-way band partition reassembles bit-identically
     band, n_parts = 6, 8
@@ -196,6 +205,30 @@ def test_tiny_squared_length_takes_the_plain_path(torch_cuda, scenes):
     w, h = 64, 32
     g = gpu_render(torch_cuda, r, sc, w, h, camera=cam)
     check_against_oracle(g, sc, w, h, camera=cam)
+    r.close()
+
+
+def test_miss_skip_is_exact_and_conditional(torch_cuda, scenes):
+    """Escaped-ray waves skip normal + shadows only when material #0 makes that exact; pixels are identical
+    with the skip on and off, and with it off every shadow step count equals the oracle's."""
+    sc = scenes["scene4"]
+    w, h = 200, 120
+    r = gpu.Renderer(0)
+    on = gpu_render(torch_cuda, r, sc, w, h)
+    assert on["miss_skip"] and (on["steps"][on["id"] == 0] >> 16).min() == 0
+    r.set_miss_skip(False)
+    off = gpu_render(torch_cuda, r, sc, w, h)
+    assert not off["miss_skip"]
+    check_against_oracle(off, sc, w, h)
+    assert np.array_equal(on["xrgb"], off["xrgb"]) and np.array_equal(on["rgb"].view(np.uint32), off["rgb"].view(np.uint32))
+    # a miss material with a non-zero diffuse term (or a negative shininess) does not qualify
+    text = open(__import__("os").path.join(__import__("conftest").SCENES, "scene4.lol")).read()
+    for old, new in (("diffuse\t\t= (0, 0, 0)", "diffuse = (0, 0.5, 0)"), ("shininess\t= 0,", "shininess = -1,")):
+        assert old in text
+        sc2 = S.Scene.parse_string(text.replace(old, new, 1))
+        g = gpu_render(torch_cuda, r if False else gpu.Renderer(0), sc2, 64, 40)
+        assert not g["miss_skip"]
+        check_against_oracle(g, sc2, 64, 40)
     r.close()
 
 
