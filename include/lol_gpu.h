@@ -138,6 +138,11 @@ int         lol_gpu_verify_fast_paths(lol_gpu* ctx, float k, unsigned long long 
  * rays ALL escaped skips the normal taps and shadow marches.  On by default when the uploaded program
  * qualifies (checked on the host); set_miss_skip(ctx, 0) or LOL_GPU_MISS_SKIP=0 turn it off.  With it on,
  * lol_gpu_debug.steps reports 0 shadow steps for the skipped pixels.
+ *
+ * The same switch governs the per-light form: where a surface faces away from a light (diffuse incidence
+ * clamps to exactly 0) both Phong terms of that light are +-0 for any shadow factor, so that lane does not
+ * march the shadow ray (needs all light intensities and material colours finite and every shininess >= 0).
+ * lol_gpu_miss_skip_active(): bit 0 = escaped-wave skip, bit 1 = zero-incidence skip.
  */
 int         lol_gpu_set_miss_skip(lol_gpu* ctx, int enable);
 int         lol_gpu_miss_skip_active(const lol_gpu* ctx);

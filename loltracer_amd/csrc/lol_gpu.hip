@@ -55,6 +55,7 @@ struct lol_gpu {
 	int          want_fast = 1;          /* allow the proven-exact shortcuts in the specialised kernel */
 	int          want_miss_skip = 1;     /* allow FLAG_MISS_SKIP when the program qualifies */
 	bool         miss_skip = false;      /* the uploaded program qualifies (miss_skip_ok) */
+	bool         dark_skip = false;      /* the uploaded program qualifies (dark_skip_ok) */
 	int          sqrt_verified = -1;     /* -1 not run, 0 none proven, else the lol::sqrt_fast KIND proven on this device */
 	std::vector<std::pair<uint32_t, bool>> div_verified;   /* k bits → proven */
 	unsigned long long* d_bad = nullptr; /* mismatch counter of the verification kernels */
@@ -99,6 +100,26 @@ bool miss_skip_ok(const lol_program& P) {
 		const float f[6] = { l.diffuse_intensity.x, l.diffuse_intensity.y, l.diffuse_intensity.z,
 		                     l.specular_intensity.x, l.specular_intensity.y, l.specular_intensity.z };
 		for (float v : f) if (!(v - v == 0.0f)) return false;      /* inf or NaN */
+	}
+	return true;
+}
+
+/* Conditions for FLAG_DARK_SKIP (lol_kernel.h): with diffuse incidence exactly 0 a light contributes
+ * I * (shadow * 0) * colour and I * (shadow * (0 * powf(c, shininess))) * colour, which is +-0 for any shadow in
+ * [0, 1] provided I and the colours are finite and powf is finite (c in [0, 1], shininess >= 0). */
+bool dark_skip_ok(const lol_program& P) {
+	auto finite = [](float v) { return v - v == 0.0f; };
+	for (uint32_t i = 0; i < P.n_lights; i++) {
+		const lol_light& l = P.lights[i];
+		const float f[6] = { l.diffuse_intensity.x, l.diffuse_intensity.y, l.diffuse_intensity.z,
+		                     l.specular_intensity.x, l.specular_intensity.y, l.specular_intensity.z };
+		for (float v : f) if (!finite(v)) return false;
+	}
+	for (uint32_t i = 0; i < P.n_materials; i++) {
+		const lol_material& m = P.materials[i];
+		const float f[6] = { m.diffuse.x, m.diffuse.y, m.diffuse.z, m.specular.x, m.specular.y, m.specular.z };
+		for (float v : f) if (!finite(v)) return false;
+		if (!(m.shininess >= 0.0f)) return false;
 	}
 	return true;
 }
@@ -415,11 +436,17 @@ int lol_gpu_set_specialize(lol_gpu* ctx, int enable) {
 int lol_gpu_set_miss_skip(lol_gpu* ctx, int enable) {
 	if (!ctx) return LOL_GPU_ERR_ARG;
 	ctx->want_miss_skip = enable ? 1 : 0;
-	if (ctx->have_prog) ctx->miss_skip = ctx->want_miss_skip && miss_skip_ok(ctx->h_prog);
+	if (ctx->have_prog) {
+		ctx->miss_skip = ctx->want_miss_skip && miss_skip_ok(ctx->h_prog);
+		ctx->dark_skip = ctx->want_miss_skip && dark_skip_ok(ctx->h_prog);
+	}
 	return LOL_GPU_OK;
 }
 
-int lol_gpu_miss_skip_active(const lol_gpu* ctx) { return ctx && ctx->miss_skip ? 1 : 0; }
+/* bit 0: escaped-wave skip active; bit 1: zero-incidence shadow skip active */
+int lol_gpu_miss_skip_active(const lol_gpu* ctx) {
+	return ctx ? (ctx->miss_skip ? 1 : 0) | (ctx->dark_skip ? 2 : 0) : 0;
+}
 
 /* Run the exhaustive (all 2^32 inputs) equivalence checks directly: mismatch counts out. */
 int lol_gpu_verify_fast_paths(lol_gpu* ctx, float k, unsigned long long sqrt_mismatches[3],
@@ -468,6 +495,7 @@ int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog) {
 	ctx->have_prog = true;
 	const char* ms = getenv("LOL_GPU_MISS_SKIP");
 	ctx->miss_skip = ctx->want_miss_skip && !(ms && ms[0] == '0') && miss_skip_ok(*prog);
+	ctx->dark_skip = ctx->want_miss_skip && !(ms && ms[0] == '0') && dark_skip_ok(*prog);
 	specialise(ctx);
 	return LOL_GPU_OK;
 }
@@ -517,7 +545,7 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	L.materials     = reinterpret_cast<const uint32_t*>(base + offsetof(lol_program, materials));
 	L.root_material = reinterpret_cast<const uint32_t*>(base + offsetof(lol_program, root_material));
 	L.ambient[0] = P.ambient_color.x; L.ambient[1] = P.ambient_color.y; L.ambient[2] = P.ambient_color.z;
-	L.flags = ctx->miss_skip ? lol::FLAG_MISS_SKIP : 0u;
+	L.flags = (ctx->miss_skip ? lol::FLAG_MISS_SKIP : 0u) | (ctx->dark_skip ? lol::FLAG_DARK_SKIP : 0u);
 	L.dst = static_cast<uint32_t*>(dst);
 	L.pitch_px = (uint32_t)(pitch_bytes / 4);
 	if (dbg) {

@@ -49,6 +49,7 @@ enum { OP_SPHERE = 0, OP_RBOX = 1, OP_PLANE = 2, OP_SMIN = 3, OP_SMIN_R = 4, OP_
 
 /* Launch.flags */
 constexpr u32 FLAG_MISS_SKIP = 1u;   /* a wave whose rays all escaped may skip normal + lights (see shade_pixel) */
+constexpr u32 FLAG_DARK_SKIP = 2u;   /* lanes whose diffuse incidence for a light is exactly 0 need no shadow march for it */
 
 /* = lol_frame_camera */
 struct Cam { float origin[3], dir[3], right[3], up[3]; float width, height; };
@@ -296,10 +297,10 @@ __device__ __forceinline__ Hit march(Sdf& sdf, V3 ro, V3 rd, int max_steps) {
 /* in_shadow + softshadow, naive_renderer.c:73-100.  dir/light_dist come from the caller,
  * which needs the same normalize(light - p) for the Phong term. */
 template <class Sdf>
-__device__ __forceinline__ float soft_shadow(Sdf& sdf, V3 p, V3 dir, float max_dist, u32& steps) {
+__device__ __forceinline__ float soft_shadow(Sdf& sdf, V3 p, V3 dir, float max_dist, u32& steps, bool needed) {
 	V3 ro = add(p, dir);
 	float res = 1.f, t = 0.f;
-	bool alive = true;
+	bool alive = needed;          /* a lane that does not need the factor never marches (returns 1) */
 	for (int i = 0; i < 128; i++) {
 		if (__ballot(alive) == 0) break;
 		V3 q = add(ro, scale(dir, t));
@@ -402,10 +403,21 @@ __device__ __forceinline__ Pixel shade_pixel(const Launch& L, Sdf& sdf, const u3
 			V3 to_light = sub(lds_v3(lp), p);
 			float light_dist = len(to_light);
 			V3 light_dir = scale(to_light, 1.0f / light_dist);      /* == v3normalize(light - p) */
-			float shadow = soft_shadow(sdf, p, light_dir, light_dist, shadow_steps);
+			float di = clampf_(dot(n, light_dir), 0.f, 1.f);
+			/*
+			 * With di == 0 (surface faces away from the light; clamp also maps NaN to 0) both terms of this
+			 * light are I * (shadow * 0) * colour = +-0 for ANY shadow factor in [0, 1], and adding +-0 never
+			 * changes the running sum (it starts at +0).  The host sets FLAG_DARK_SKIP only when every light
+			 * intensity and material colour is finite and every shininess >= 0 (so powf stays finite and
+			 * 0 * powf is 0).  Such lanes — and escaped lanes under FLAG_MISS_SKIP — then sit the shadow march
+			 * out; a wave with no lane left skips it.
+			 */
+			bool needed = true;
+			if (L.flags & FLAG_DARK_SKIP) needed = di > 0.f;
+			if ((L.flags & FLAG_MISS_SKIP) && hit.id == 0u) needed = false;
+			float shadow = soft_shadow(sdf, p, light_dir, light_dist, shadow_steps, needed);
 
 			V3 refl = sub(scale(n, 2.f * dot(light_dir, n)), light_dir);
-			float di = clampf_(dot(n, light_dir), 0.f, 1.f);
 			V3 Id = mul(scale(lds_v3(lp + 3), shadow * di), m_diff);
 			total = add(total, Id);
 			float si = di * powf(clampf_(dot(refl, camera_dir), 0.f, 1.f), shininess);

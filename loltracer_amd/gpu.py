@@ -174,8 +174,9 @@ class Renderer:
     def set_miss_skip(self, enable: bool):
         self._check(self._lib.lol_gpu_set_miss_skip(self._ctx, 1 if enable else 0))
 
-    def miss_skip_active(self) -> bool:
-        return bool(self._lib.lol_gpu_miss_skip_active(self._ctx))
+    def miss_skip_active(self) -> int:
+        """bit 0: escaped-wave skip active; bit 1: zero-incidence shadow skip active."""
+        return int(self._lib.lol_gpu_miss_skip_active(self._ctx))
 
     def specialize_log(self) -> str:
         return self._lib.lol_gpu_specialize_log(self._ctx).decode(errors="replace")

@@ -178,7 +178,7 @@ static v3 get_normal(const lol_scene* sc, v3 p, float dist, struct tally* t) {
 
 /* get_light, naive_renderer.c:129-175 */
 static v3 get_light(const lol_scene* sc, v3 cam_pos, v3 p, v3 n, uint32_t obj_id, struct tally* t,
-                    lol_oracle_probe* probe) {
+                    lol_oracle_probe* probe, uint32_t* dark_mask, uint16_t* per_light) {
 	lol_material mat = get_material(sc, obj_id);
 	v3 total = { 0.f, 0.f, 0.f };
 	for (size_t li = 0; li < sc->n_lights; li++) {
@@ -189,6 +189,7 @@ static v3 get_light(const lol_scene* sc, v3 cam_pos, v3 p, v3 n, uint32_t obj_id
 			probe->shadow[li] = shadow;
 			probe->shadow_steps[li] = (uint32_t)(t->shadow_steps - before);
 		}
+		if (per_light && li < 4) per_light[li] = (uint16_t)(t->shadow_steps - before);
 		v3 Id = from_lol(light->diffuse_intensity);
 		v3 Is = from_lol(light->specular_intensity);
 		v3 light_dir = v3normalize(v3sub(from_lol(light->point), p));
@@ -196,6 +197,7 @@ static v3 get_light(const lol_scene* sc, v3 cam_pos, v3 p, v3 n, uint32_t obj_id
 		v3 camera_dir = v3normalize(v3sub(cam_pos, p));
 
 		float diffuse_incidence = clampf(v3dot(n, light_dir), 0.f, 1.f);
+		if (dark_mask && li < 16 && diffuse_incidence == 0.f) *dark_mask |= 1u << li;
 		Id = v3scale(Id, shadow * diffuse_incidence);
 		Id = v3mul(Id, from_lol(mat.diffuse));
 		total = v3add(total, Id);
@@ -234,7 +236,8 @@ static uint32_t pack_xrgb(v3 c) {
 /* the pixel body of render_thread, naive_renderer.c:217-235 */
 static uint32_t shade_pixel(const lol_scene* sc, const lol_camera* cam, int x, int y,
                             float fwidth, float fheight, int max_steps, struct tally* t,
-                            float* rgb_out, lol_oracle_probe* probe, int* missed, uint32_t* hit_id) {
+                            float* rgb_out, lol_oracle_probe* probe, int* missed, uint32_t* hit_id,
+                            uint32_t* dark_out, uint16_t* per_light) {
 	v3 ro = from_lol(cam->point);
 	float aspect = fwidth / fheight;
 	float vx = (x + .5f) / fwidth * 2.f - 1.f;
@@ -245,7 +248,9 @@ static uint32_t shade_pixel(const lol_scene* sc, const lol_camera* cam, int x, i
 	uint64_t march = t->march_steps;
 	v3 p = v3add(ro, v3scale(rd, hit.dist));
 	v3 n = get_normal(sc, p, hit.dist, t);
-	v3 lin = get_light(sc, ro, p, n, hit.id, t, probe);
+	uint32_t dark = 0;
+	v3 lin = get_light(sc, ro, p, n, hit.id, t, probe, &dark, per_light);
+	if (dark_out) *dark_out = dark;
 	v3 c = v3pow(lin, 1.f / 2.2f);
 	uint32_t px = pack_xrgb(c);
 
@@ -272,16 +277,19 @@ static void render_row(const lol_scene* sc, const lol_camera* cam, int w, int h,
 	for (int x = 0; x < w; x++) {
 		struct tally t = { 0, 0, 0, 0 };
 		int missed = 0;
-		uint32_t hit_id = 0;
+		uint32_t hit_id = 0, dark = 0;
+		uint16_t per_light[4] = { 0, 0, 0, 0 };
 		uint32_t px = shade_pixel(sc, cam, x, y, fw, fh, max_steps, &t,
-		                          rgb ? rgb + ((size_t)y * w + x) * 3 : NULL, NULL, &missed, &hit_id);
+		                          rgb ? rgb + ((size_t)y * w + x) * 3 : NULL, NULL, &missed, &hit_id, &dark,
+		                          per_light);
 		if (xrgb) memcpy((char*)xrgb + (size_t)y * pitch + (size_t)x * 4, &px, 4);
 		if (steps) {
-			uint16_t* o = steps + ((size_t)y * w + x) * 4;
+			uint16_t* o = steps + ((size_t)y * w + x) * 8;
 			o[0] = (uint16_t)t.march_steps;
 			o[1] = (uint16_t)(t.shadow_steps > 65535 ? 65535 : t.shadow_steps);
 			o[2] = (uint16_t)(hit_id > 65535 ? 65535 : hit_id);
-			o[3] = 0;
+			o[3] = (uint16_t)dark;             /* bit i: light i has diffuse incidence exactly 0 here */
+			for (int k = 0; k < 4; k++) o[4 + k] = per_light[k];
 		}
 		if (ctr) {
 			ctr->pixels++;
@@ -376,7 +384,7 @@ void lol_oracle_probe_pixel(const lol_scene* sc, const lol_camera* cam, int w, i
                             int x, int y, lol_oracle_probe* out) {
 	struct tally t = { 0, 0, 0, 0 };
 	memset(out, 0, sizeof *out);
-	shade_pixel(sc, cam, x, y, (float)w, (float)h, max_steps, &t, NULL, out, NULL, NULL);
+	shade_pixel(sc, cam, x, y, (float)w, (float)h, max_steps, &t, NULL, out, NULL, NULL, NULL, NULL);
 }
 
 float lol_oracle_sdf(const lol_scene* sc, float px, float py, float pz, uint32_t* id) {

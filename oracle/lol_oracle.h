@@ -59,7 +59,8 @@ typedef struct lol_oracle_probe {
  *   xrgb   : h rows of `pitch_bytes`; pixel (x,y) at xrgb + y*pitch + 4*x,
  *            value r<<16|g<<8|b (renderer.h:17-22 with an XRGB8888 surface)
  *   rgb    : optional w*h*3 floats, post-gamma pre-quantisation, row-major
- *   steps  : optional w*h x 4 uint16 {march steps, shadow steps (all lights), hit id, 0} per pixel
+ *   steps  : optional w*h x 8 uint16 per pixel: {march steps, shadow steps (all lights), hit id,
+ *            bit mask of lights whose diffuse incidence is exactly 0, shadow steps of lights 0..3}
  *   ctr    : optional counters, accumulated (caller zeroes)
  */
 void lol_oracle_render_rows(const lol_scene* scene, const lol_camera* cam,

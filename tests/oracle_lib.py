@@ -83,12 +83,13 @@ def render(scene: S.Scene, w: int, h: int, max_steps: int = 256, threads: int = 
 
 def render_rows(scene: S.Scene, w: int, h: int, y0: int, y1: int, max_steps: int = 256, camera=None,
                 want_steps: bool = False):
-    """Rows [y0,y1) → (xrgb [h,w] with only those rows filled, rgb [h,w,3], steps [h,w,4] | None);
-    steps[..., 0] march steps, [..., 1] shadow steps summed over lights, [..., 2] hit id."""
+    """Rows [y0,y1) → (xrgb [h,w] with only those rows filled, rgb [h,w,3], steps [h,w,8] | None);
+    steps[..., 0] march steps, [..., 1] shadow steps summed over lights, [..., 2] hit id, [..., 3] bit mask of
+    lights with diffuse incidence exactly 0, [..., 4:8] shadow steps of lights 0..3."""
     cam = camera if camera is not None else scene.c.camera
     xrgb = np.zeros((h, w), dtype=np.uint32)
     rgb = np.zeros((h, w, 3), dtype=np.float32)
-    steps = np.zeros((h, w, 4), dtype=np.uint16) if want_steps else None
+    steps = np.zeros((h, w, 8), dtype=np.uint16) if want_steps else None
     lib().lol_oracle_render_rows(scene.ptr, C.byref(cam), w, h, max_steps, y0, y1,
                                  xrgb.ctypes.data, w * 4, rgb.ctypes.data,
                                  steps.ctypes.data if steps is not None else None, None)
