@@ -59,6 +59,7 @@ struct lol_gpu {
 	int          sqrt_verified = -1;     /* -1 not run, 0 none proven, else the lol::sqrt_fast KIND proven on this device */
 	std::vector<std::pair<uint32_t, bool>> div_verified;   /* k bits → proven */
 	unsigned long long* d_bad = nullptr; /* mismatch counter of the verification kernels */
+	int          wave_w = LOL_WAVE_W, wave_h = LOL_WAVE_H, waves_x = LOL_WAVES_X;   /* footprint of the spec kernel */
 	char         err[512] = { 0 };
 	char         kernel_name[64] = "render_interp";
 };
@@ -279,7 +280,7 @@ std::string generate_source(const lol_program& P, const FastPaths* fast) {
 
 /* hipRTC: generated source + lol_kernel.h → code object for `arch`.  Needs no device. */
 bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string& arch, std::vector<char>& code,
-                  std::string& log, std::string* src_out = nullptr) {
+                  std::string& log, std::string* src_out = nullptr, const int* shape = nullptr) {
 	std::string src = generate_source(P, fast);
 	if (src_out) *src_out = src;
 	const char* hdr_src[] = { LOL_KERNEL_H_TEXT };
@@ -303,6 +304,13 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
 	 * rate of two scalar ops on gfx950 (tools/valu_rate.hip); measured +10 % Mpixels/s without it. */
 	std::vector<const char*> opts = { arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
 	                                  "-fno-slp-vectorize" };
+	char d0[32], d1[32], d2[32];
+	if (shape) {
+		snprintf(d0, sizeof d0, "-DLOL_WAVE_W=%d", shape[0]);
+		snprintf(d1, sizeof d1, "-DLOL_WAVE_H=%d", shape[1]);
+		snprintf(d2, sizeof d2, "-DLOL_WAVES_X=%d", shape[2]);
+		opts.push_back(d0); opts.push_back(d1); opts.push_back(d2);
+	}
 	for (auto& x : extra) opts.push_back(x.c_str());
 	hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
 	size_t log_size = 0;
@@ -365,7 +373,16 @@ bool specialise(lol_gpu* ctx) {
 		note = b;
 	}
 	std::vector<char> code;
-	if (!compile_spec(ctx->h_prog, &fast, arch, code, ctx->spec_log)) return false;
+	/* tuning knobs for the pixel footprint of the specialised kernel (defaults: 8x8 per wave, 4 waves per block) */
+	ctx->wave_w = LOL_WAVE_W; ctx->wave_h = LOL_WAVE_H; ctx->waves_x = LOL_WAVES_X;
+	if (const char* e = getenv("LOL_GPU_WAVE_SHAPE")) {
+		int a = 0, b = 0, c = 0;
+		if (sscanf(e, "%dx%dx%d", &a, &b, &c) == 3 && a > 0 && b > 0 && a * b == 64 && c >= 1 && c <= 16) {
+			ctx->wave_w = a; ctx->wave_h = b; ctx->waves_x = c;
+		}
+	}
+	const int shape[3] = { ctx->wave_w, ctx->wave_h, ctx->waves_x };
+	if (!compile_spec(ctx->h_prog, &fast, arch, code, ctx->spec_log, nullptr, shape)) return false;
 	ctx->spec_log = note + ctx->spec_log;
 	if (hipModuleLoadData(&ctx->spec_module, code.data()) != hipSuccess) {
 		ctx->spec_log = "hipModuleLoadData failed";
@@ -553,14 +570,17 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 		L.dbg_hit_id = dbg->hit_id; L.dbg_steps = dbg->steps;
 	}
 
-	dim3 grid((w + lol::TILE_W - 1) / lol::TILE_W, (n_rows + lol::TILE_H - 1) / lol::TILE_H);
-	size_t common = (size_t)lol::common_lds_dwords(P.n_lights, P.n_materials, P.n_roots) * 4;
+	const bool spec = ctx->spec_fn != nullptr;
+	const int tile_w = spec ? ctx->wave_w * ctx->waves_x : lol::TILE_W, tile_h = spec ? ctx->wave_h : lol::TILE_H;
+	const int block = tile_w * tile_h;
+	dim3 grid((w + tile_w - 1) / tile_w, (n_rows + tile_h - 1) / tile_h);
+	size_t common = (size_t)(lol::common_lds_dwords(P.n_lights, P.n_materials, P.n_roots) - lol::TILE_W * lol::TILE_H + block) * 4;
 	hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
 	LOL_HIP(ctx, hipSetDevice(ctx->device));
 	hipError_t e;
 	if (ctx->spec_fn) {
 		void* args[] = { &L };
-		e = hipModuleLaunchKernel(ctx->spec_fn, grid.x, grid.y, 1, lol::BLOCK, 1, 1, (unsigned)common, s, args, nullptr);
+		e = hipModuleLaunchKernel(ctx->spec_fn, grid.x, grid.y, 1, block, 1, 1, (unsigned)common, s, args, nullptr);
 	} else {
 		size_t lds = common + (size_t)P.n_ops * lol::OP_DWORDS * 4;
 		uint32_t need = P.max_stack;

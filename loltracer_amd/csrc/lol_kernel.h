@@ -25,8 +25,8 @@
  *    by predication;
  *  - lights and materials are staged once per block into LDS and read back
  *    with wave-uniform (lights) or per-lane (material of the hit) addresses;
- *  - pixels are written through an LDS tile so each wave stores whole 128-byte
- *    row segments.
+ *  - pixels are written through an LDS tile so each wave stores whole row
+ *    segments (4 rows x 64 bytes with the default 16x4 patch).
  */
 #pragma once
 
@@ -39,9 +39,25 @@ namespace lol {
 typedef unsigned int u32;
 typedef int i32;
 
-constexpr int TILE_W = 32;            /* pixels per block row  */
-constexpr int TILE_H = 8;             /* pixel rows per block  */
-constexpr int BLOCK  = TILE_W * TILE_H;   /* 256 threads = 4 waves; wave k owns columns [8k, 8k+8) */
+/* Pixel footprint: each wave owns a WAVE_W x WAVE_H patch (64 pixels); a block is WAVES_X patches side by side.
+ * Default 16x4 per wave, one wave per block: single-wave blocks free their slot as soon as their own rays are
+ * done (pixels differ 100x in cost, so a 4-wave block often waits for one straggler) — measured +4 % over
+ * 8x8 patches in 4-wave blocks; 16x4 keeps 64-byte row segments for the framebuffer stores.  The specialised
+ * kernel can be compiled with other shapes for experiments (LOL_GPU_WAVE_SHAPE=WxHxN, lol_gpu.hip). */
+#ifndef LOL_WAVE_W
+#define LOL_WAVE_W 16
+#endif
+#ifndef LOL_WAVE_H
+#define LOL_WAVE_H 4
+#endif
+#ifndef LOL_WAVES_X
+#define LOL_WAVES_X 1
+#endif
+static_assert(LOL_WAVE_W * LOL_WAVE_H == 64, "a wave shades 64 pixels");
+constexpr int WAVE_W = LOL_WAVE_W, WAVE_H = LOL_WAVE_H;
+constexpr int TILE_W = WAVE_W * LOL_WAVES_X;   /* pixels per block row  */
+constexpr int TILE_H = WAVE_H;                 /* pixel rows per block  */
+constexpr int BLOCK  = TILE_W * TILE_H;        /* 64 * WAVES_X threads; wave k owns columns [WAVE_W*k, WAVE_W*(k+1)) */
 
 /* dword layouts of lol_op / lol_light / lol_material (lol_scene.h); checked by static_asserts in lol_gpu.hip */
 constexpr int OP_DWORDS = 10, LIGHT_DWORDS = 9, MATERIAL_DWORDS = 10;
@@ -352,9 +368,9 @@ __device__ __forceinline__ Pixel shade_pixel(const Launch& L, Sdf& sdf, const u3
 	const u32* l_mat   = l_light + L.n_lights * LIGHT_DWORDS;
 	const u32* l_rootm = l_mat + L.n_materials * MATERIAL_DWORDS;
 
-	/* lane → pixel: wave k covers an 8x8 patch at columns 8k.. of the 32x8 tile */
+	/* lane → pixel: wave k covers a WAVE_W x WAVE_H patch of the block's tile */
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int tx = wave * 8 + (lane & 7), ty = lane >> 3;
+	const int tx = wave * WAVE_W + (lane % WAVE_W), ty = lane / WAVE_W;
 	int x = blockIdx.x * TILE_W + tx;
 	int r = blockIdx.y * TILE_H + ty;                     /* local row */
 	/* out-of-frame lanes shade a clamped pixel and skip the store: keeps the wave uniform */
@@ -440,7 +456,7 @@ __device__ __forceinline__ Pixel shade_pixel(const Launch& L, Sdf& sdf, const u3
 __device__ __forceinline__ void store_pixel(const Launch& L, const Pixel& P, u32* lds) {
 	u32* l_tile = lds + L.n_lights * LIGHT_DWORDS + L.n_materials * MATERIAL_DWORDS + L.n_roots;
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int tx = wave * 8 + (lane & 7), ty = lane >> 3;
+	const int tx = wave * WAVE_W + (lane % WAVE_W), ty = lane / WAVE_W;
 	const int gx = blockIdx.x * TILE_W + tx, gr = blockIdx.y * TILE_H + ty;
 	if (gx < L.w && gr < L.n_rows) {
 		unsigned long long o = (unsigned long long)gr * L.w + gx;
@@ -449,10 +465,10 @@ __device__ __forceinline__ void store_pixel(const Launch& L, const Pixel& P, u32
 		if (L.dbg_hit_id) L.dbg_hit_id[o] = P.hit.id;
 		if (L.dbg_steps) L.dbg_steps[o] = (P.hit.steps & 0xFFFFu) | (P.shadow_steps << 16);
 	}
-	/* through LDS so a wave stores two full 128-byte row segments */
+	/* through LDS so the block stores whole row segments (64 bytes each with the default 16x4 patch) */
 	l_tile[ty * TILE_W + tx] = P.px;
 	__syncthreads();
-	const int sx = threadIdx.x & (TILE_W - 1), sy = threadIdx.x >> 5;
+	const int sx = threadIdx.x % TILE_W, sy = threadIdx.x / TILE_W;
 	const int ox = blockIdx.x * TILE_W + sx, orow = blockIdx.y * TILE_H + sy;
 	if (ox < L.w && orow < L.n_rows)
 		L.dst[(unsigned long long)orow * L.pitch_px + ox] = l_tile[sy * TILE_W + sx];
