@@ -85,7 +85,7 @@ def pmc_traffic(kernel: str, workload: str, pixels_per_launch: int):
     return rec["traffic_bytes"]
 
 
-def cpu_baseline(sc: S.Scene, cfg: dict, target_s: float = 15.0):
+def cpu_baseline(sc: S.Scene, cfg: dict, target_s: float = 15.0, gpu_frame=None):
     """Time the CPU oracle on all host cores over a bounded, evenly spread row sample of the frame."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
@@ -113,9 +113,20 @@ def cpu_baseline(sc: S.Scene, cfg: dict, target_s: float = 15.0):
     want_px = rate * target_s
     stride = max(1, int(math.ceil(w * h / max(want_px, 1.0))))
     t, ctr = run(stride)
-    return dict(value=ctr.pixels / t / 1e6, unit="Mpixels/s", cores=cores, kind="port",
+    base = dict(value=ctr.pixels / t / 1e6, unit="Mpixels/s", cores=cores, kind="port",
                 sample=f"every {stride}th row of the {w}x{h} frame ({ctr.pixels} px, {t:.1f} s, "
-                       f"{cores} threads claiming rows from an atomic counter)"), ctr
+                       f"{cores} threads claiming rows from an atomic counter)")
+    if gpu_frame is not None:
+        # the oracle just rendered these rows of the same frame: use them as the checker for the GPU frame
+        rows = np.arange(0, h, stride)
+        g, o = gpu_frame[rows], buf[rows]
+        sh = np.array([16, 8, 0], dtype=np.uint32)
+        d = np.abs(((g[..., None] >> sh) & 0xFF).astype(np.int32) - ((o[..., None] >> sh) & 0xFF).astype(np.int32))
+        base["parity_vs_gpu"] = {"pixels_compared": int(g.size), "pixels_differing": int((g != o).sum()),
+                                 "max_channel_delta_lsb": int(d.max()),
+                                 "note": "XRGB8888 of the timed GPU frame vs the oracle on the sampled rows; float colour "
+                                         "parity (<=1e-4) and step-count equality are asserted by tests/test_gpu_parity.py"}
+    return base, ctr
 
 
 def main():
@@ -268,7 +279,7 @@ def main():
                          "note": "north_star names the HBM-write roofline; the path is FP32-VALU-bound, see `valu`"},
         }
         if world == 1 and not args.no_cpu_baseline and not orbit:
-            base, ctr = cpu_baseline(sc, cfg)
+            base, ctr = cpu_baseline(sc, cfg, gpu_frame=local.cpu().numpy().view(np.uint32))
             out["cpu_baseline"] = base
             fpp = (ctr.sdf_evals * flops_per_sdf(r.program) + ctr.march_steps * 9 + ctr.shadow_steps * 12) / ctr.pixels
             kernel_mpix = px_per_launch / (k_avg * 1e-3) / 1e6
