@@ -8,7 +8,11 @@
  *   render_prepare  once, main thread, workers already parked on the entry
  *                   semaphore (main.c:147-161): create the GPU context,
  *                   flatten the scene, upload it.  Renderer flags start at
- *                   argv[3] (main.c:223-242): --device N, --max-steps N.
+ *                   argv[3] (main.c:223-242): --device N, --max-steps N, and
+ *                   --dump-kernel BASE, the counterpart of the JIT renderer's
+ *                   -j/--jitdump (tracing_jit_renderer.dasc:424-433): writes the
+ *                   scene-specialised kernel as BASE.hip (generated source) and
+ *                   BASE.co (gfx950 code object, for llvm-objdump / rocprofv3).
  *   render_thread   every worker: wait entry → return 0 if exiting → work →
  *                   post exit exactly once (naive_renderer.c:203-205,238).
  *                   The reference's workers claim one row at a time with
@@ -41,12 +45,14 @@ struct hip_renderer {
 void render_prepare(struct render_data* data, int argc, const char* argv[]) {
 	struct hip_renderer* r = calloc(1, sizeof *r);
 	int device = 0;
+	const char* dump = NULL;
 	HOST_PRIVATE(data) = r;
 	if (!r) { fprintf(stderr, "hip_renderer: out of memory\n"); return; }
 	r->max_steps = 256;
 	for (int i = 3; i + 1 < argc; i++) {
 		if (!strcmp(argv[i], "--device")) device = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "--max-steps")) r->max_steps = atoi(argv[++i]);
+		else if (!strcmp(argv[i], "--dump-kernel")) dump = argv[++i];
 	}
 
 	const lol_scene* scene = HOST_SCENE_TO_LOL(data->scene);
@@ -55,6 +61,12 @@ void render_prepare(struct render_data* data, int argc, const char* argv[]) {
 	lol_scene_free((lol_scene*)scene);      /* the converted copy; the program holds everything */
 #endif
 	if (st != LOL_OK) { fprintf(stderr, "hip_renderer: cannot flatten scene: %s\n", lol_status_str(st)); return; }
+
+	if (dump) {
+		char log[1024];
+		if (lol_gpu_compile_offline(&r->program, "gfx950", dump, 0, log, sizeof log) != LOL_GPU_OK)
+			fprintf(stderr, "hip_renderer: --dump-kernel failed: %s\n", log);
+	}
 
 	st = lol_gpu_create(device, &r->gpu);
 	if (st != LOL_GPU_OK) { fprintf(stderr, "hip_renderer: no usable HIP device %d (status %d)\n", device, st); return; }

@@ -64,3 +64,14 @@ def test_c_host_max_steps_flag(tmp_path, scenes):
     ox, _, _ = O.render(scenes["scene4"], w, h, max_steps=9, threads=4)
     want = np.stack([(ox >> 16) & 0xFF, (ox >> 8) & 0xFF, ox & 0xFF], axis=-1).astype(np.int32)
     assert np.abs(img - want).max() <= 1
+
+
+def test_dump_kernel_flag_is_the_jitdump_counterpart(tmp_path):
+    """--dump-kernel BASE (cf. the JIT renderer's --jitdump): generated HIP source + gfx950 code object, no GPU needed."""
+    base = tmp_path / "k"
+    p = subprocess.run([HOST, "1", SCENE4, "--size", "8x8", "--dump-kernel", str(base)],
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0
+    src = open(str(base) + ".hip").read()
+    assert "lol_render_spec" in src and src.count("sd_sphere(") == 5
+    assert os.path.getsize(str(base) + ".co") > 1000
