@@ -373,7 +373,7 @@ bool specialise(lol_gpu* ctx) {
 		note = b;
 	}
 	std::vector<char> code;
-	/* tuning knobs for the pixel footprint of the specialised kernel (defaults: 8x8 per wave, 4 waves per block) */
+	/* tuning knobs for the pixel footprint of the specialised kernel (defaults: lol_kernel.h LOL_WAVE_W/H, LOL_WAVES_X) */
 	ctx->wave_w = LOL_WAVE_W; ctx->wave_h = LOL_WAVE_H; ctx->waves_x = LOL_WAVES_X;
 	if (const char* e = getenv("LOL_GPU_WAVE_SHAPE")) {
 		int a = 0, b = 0, c = 0;

@@ -137,9 +137,10 @@ __device__ __forceinline__ float sd_round_box(V3 p, float cx, float cy, float cz
  * equal to the plain expressions by running every one of the 2^32 float inputs through
  * both on the device (verify_sqrt_kernel / verify_div_kernel): same bits or both NaN.
  *
- * Measured issue costs on MI355X (tools/valu_rate.hip, 8 waves/SIMD): v_mul/v_add/v_fma ~2.7
- * cycles per wave-instruction, v_cmp / v_cndmask / v_div_fixup ~4, v_sqrt / v_rsq / v_rcp ~8.5 —
- * so the compare+select pairs of hipcc's sqrt expansion cost more than its arithmetic.
+ * Measured issue costs on MI355X (tools/valu_rate.hip, 8 waves/SIMD): v_mul/v_add/v_fma ~2.3
+ * cycles per wave-instruction, v_sqrt / v_rsq / v_rcp ~8.2 and not overlapped with anything —
+ * so time ~ 2 x instructions + 6 x transcendentals, and hipcc's 16-instruction sqrt and
+ * 11-instruction division are the first things to shrink.
  *
  * sqrt_gs: Goldschmidt iteration from v_rsq_f32 (what hipcc itself emits for a correctly rounded
  * sqrt when it need not handle denormals): 1 transcendental + 7 plain ops, no compares.  Proven

@@ -164,6 +164,18 @@ __global__ __launch_bounds__(256) void k(float* out, float a, float b, float c) 
 			asm volatile("v_mul_f32 %0, %0, %8\n v_add_f32 %0, %0, %9\n v_mul_f32 %0, %0, %8\n v_add_f32 %0, %0, %9\n"
 			             "v_mul_f32 %0, %0, %8\n v_add_f32 %0, %0, %9\n v_mul_f32 %0, %0, %8\n v_add_f32 %0, %0, %9\n"
 			             : REGS : "v"(a), "v"(b));
+		} else if (MODE == 40) {  // mix: 2 rsq + 6 fma, independent
+			asm volatile("v_rsq_f32 %0, %0\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+			             "v_rsq_f32 %4, %4\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+			             : REGS : "v"(a), "v"(b));
+		} else if (MODE == 41) {  // mix: 4 v_min (half rate) + 4 fma
+			asm volatile("v_min_f32 %0, %0, %8\n v_fma_f32 %1, %1, %8, %9\n v_min_f32 %2, %2, %8\n v_fma_f32 %3, %3, %8, %9\n"
+			             "v_min_f32 %4, %4, %8\n v_fma_f32 %5, %5, %8, %9\n v_min_f32 %6, %6, %8\n v_fma_f32 %7, %7, %8, %9\n"
+			             : REGS : "v"(a), "v"(b));
+		} else if (MODE == 42) {  // mix: 1 rsq + 7 fma
+			asm volatile("v_rsq_f32 %0, %0\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+			             "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+			             : REGS : "v"(a), "v"(b));
 		} else if (MODE == 20) {  // s_nop 0 x8
 			asm volatile("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n" : REGS);
 		} else if (MODE == 21) {  // 4 fma + 4 s_nop 1 interleaved
@@ -233,6 +245,9 @@ int main() {
 	run<5>("v_rsq_f32", d, p.clockRate);
 	run<19>("v_rcp_f32", d, p.clockRate);
 	run<14>("v_rsq + 7 dependent fma", d, p.clockRate);
+	run<40>("MIX 2 rsq + 6 fma (serial = 3.5)", d, p.clockRate);
+	run<42>("MIX 1 rsq + 7 fma (serial = 2.75)", d, p.clockRate);
+	run<41>("MIX 4 v_min + 4 fma (serial = 3.0)", d, p.clockRate);
 	run<9>("v_cmp_lt_f32 vcc", d, p.clockRate);
 	run<8>("v_cndmask_b32 vcc", d, p.clockRate);
 	run<6>("v_cmp vcc + v_cndmask pairs", d, p.clockRate);
