@@ -363,7 +363,8 @@ bool specialise(lol_gpu* ctx) {
 			bool known = false, ok = false;
 			for (auto& e : ctx->div_verified) if (e.first == kb) { known = true; ok = e.second; }
 			if (!known) {
-				ok = run_verify(ctx, 0, o.f[0]) == 0;
+				/* |k| >= 2^-100: see sminf_fastdiv (lol_kernel.h); then the exhaustive proof of the blend factor */
+				ok = (o.f[0] >= 0x1p-100f || o.f[0] <= -0x1p-100f) && run_verify(ctx, 0, o.f[0]) == 0;
 				ctx->div_verified.emplace_back(kb, ok);
 			}
 			if (ok && !fast.has(o.f[0])) fast.div_ok.push_back(o.f[0]);

@@ -212,10 +212,14 @@ __device__ __forceinline__ float smin_h_fast(float dlt, float k2, float hrk) {
 	q = __builtin_amdgcn_div_fixupf(q, k2, dlt);
 	return clampf_(.5f + q, 0.f, 1.f);
 }
-/* sminf (float.h:29-33) with the proven blend factor */
+/* sminf (float.h:29-33) with the proven blend factor.  lerp(b, a, h) = b + (a - b)*h is written b - (b - a)*h:
+ * a - b and b - a are exact negatives of each other unless a == b with equal signs, where h = .5 and the two
+ * forms can only differ in the sign of a zero sum (a == b == -0) that the subtraction of k*h*(1-h) = k/4 != 0
+ * then erases — lol_gpu.hip uses this form only for |k| >= 2^-100 so that k/4 is a non-zero normal number. */
 __device__ __forceinline__ float sminf_fastdiv(float a, float b, float k, float k2, float hrk) {
-	float h = smin_h_fast(b - a, k2, hrk);
-	return (b + (a - b) * h) - k * h * (1.f - h);
+	float dlt = b - a;
+	float h = smin_h_fast(dlt, k2, hrk);
+	return (b - dlt * h) - k * h * (1.f - h);
 }
 
 /* sd_sphere / sd_round_box on a proven fast sqrt (KIND 1 = sqrt_pm, 2 = sqrt_gs, 3 = sqrt_r2) */
