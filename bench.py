@@ -113,7 +113,12 @@ def cpu_baseline(sc: S.Scene, cfg: dict, target_s: float = 15.0, gpu_frame=None)
     want_px = rate * target_s
     stride = max(1, int(math.ceil(w * h / max(want_px, 1.0))))
     t, ctr = run(stride)
+    # one thread too, on a thinner sample of the same frame
+    cores_all, cores = cores, 1
+    t1, c1 = run(max(stride, h // 24))
+    cores = cores_all
     base = dict(value=ctr.pixels / t / 1e6, unit="Mpixels/s", cores=cores, kind="port",
+                value_1_thread=round(c1.pixels / t1 / 1e6, 4),
                 sample=f"every {stride}th row of the {w}x{h} frame ({ctr.pixels} px, {t:.1f} s, "
                        f"{cores} threads claiming rows from an atomic counter)")
     if gpu_frame is not None:
@@ -175,6 +180,13 @@ def main():
     torch.cuda.set_stream(side)
     stream = side.cuda_stream
     assert stream, "expected a non-NULL HIP stream handle"
+
+    if world > 1:
+        # set-up, like render_prepare: bring the communicator up before any timed or warm-up step
+        warm = torch.zeros(1, device=dev)
+        dist.all_reduce(warm)
+        dist.barrier()
+        torch.cuda.synchronize()
 
     orbit = name == "orbit"
     if orbit:
