@@ -102,3 +102,16 @@ def test_degenerate_inputs(torch_cuda):
             g = gpu_render(torch_cuda, r, sc, 40, 24)
             check_against_oracle(g, sc, 40, 24)
         r.close()
+
+
+def test_orbit_frames_match_the_oracle(torch_cuda, scenes):
+    """BASELINE config 5's camera path (bench.orbit_camera): 12 of the 256 orbit frames, every pixel checked."""
+    import bench
+    sc = scenes["scene4"]
+    r = gpu.Renderer(0)
+    w, h = 256, 144
+    for i in range(0, 256, 22):
+        cam = bench.orbit_camera(i, 256)
+        g = gpu_render(torch_cuda, r, sc, w, h, camera=cam)
+        check_against_oracle(g, sc, w, h, camera=cam)
+    r.close()
