@@ -25,7 +25,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -279,10 +281,22 @@ std::string generate_source(const lol_program& P, const FastPaths* fast) {
 }
 
 /* hipRTC: generated source + lol_kernel.h → code object for `arch`.  Needs no device. */
+/* Process-wide cache of compiled kernels: hosts (and the tests) upload the same scene many times. */
+std::mutex g_cache_mutex;
+std::unordered_map<std::string, std::vector<char>> g_code_cache;
+
 bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string& arch, std::vector<char>& code,
                   std::string& log, std::string* src_out = nullptr, const int* shape = nullptr) {
 	std::string src = generate_source(P, fast);
 	if (src_out) *src_out = src;
+	std::string key = arch + "|" + (getenv("LOL_GPU_RTC_FLAGS") ? getenv("LOL_GPU_RTC_FLAGS") : "") + "|";
+	if (shape) key += std::to_string(shape[0]) + "x" + std::to_string(shape[1]) + "x" + std::to_string(shape[2]);
+	key += "|" + src;
+	{
+		std::lock_guard<std::mutex> lock(g_cache_mutex);
+		auto it = g_code_cache.find(key);
+		if (it != g_code_cache.end()) { code = it->second; log.clear(); return true; }
+	}
 	const char* hdr_src[] = { LOL_KERNEL_H_TEXT };
 	const char* hdr_name[] = { "lol_kernel.h" };
 	hiprtcProgram prog = nullptr;
@@ -327,6 +341,10 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
 	code.resize(code_size);
 	hiprtcGetCode(prog, code.data());
 	hiprtcDestroyProgram(&prog);
+	{
+		std::lock_guard<std::mutex> lock(g_cache_mutex);
+		g_code_cache[key] = code;
+	}
 	return true;
 }
 
