@@ -236,6 +236,31 @@ def test_miss_skip_is_exact_and_conditional(torch_cuda, scenes):
     r.close()
 
 
+def test_baseline_configs_2_and_4_at_full_size(torch_cuda, scenes):
+    """C2: scene.lol 1920x1080 at 128 march steps; C4: scene4.lol 7680x4320 — oracle on sampled rows, and for C4
+    the 8-way band partition the multi-GPU bench uses (band 6) against the single-launch frame."""
+    r = gpu.Renderer(0)
+    sc, w, h = scenes["scene"], 1920, 1080
+    g = gpu_render(torch_cuda, r, sc, w, h, max_steps=128)
+    for y in (0, 300, 540, 800, 1079):
+        sub = {k: (v[y:y + 1] if isinstance(v, np.ndarray) else v) for k, v in g.items()}
+        check_against_oracle(sub, sc, w, h, max_steps=128, y0=y, y1=y + 1)
+    del g
+    sc, w, h = scenes["scene4"], 7680, 4320
+    g = gpu_render(torch_cuda, r, sc, w, h)
+    for y in (1, 2160, 3000, 4319):
+        sub = {k: (v[y:y + 1] if isinstance(v, np.ndarray) else v) for k, v in g.items()}
+        check_against_oracle(sub, sc, w, h, y0=y, y1=y + 1)
+    full = g["xrgb"]
+    del g
+    from loltracer_amd import multi
+    band, n_parts = multi.choose_band_rows(h, 8), 8
+    for part in (0, 5):
+        pg = gpu_render(torch_cuda, r, sc, w, h, rows=gpu.Rows(band, n_parts, part))["xrgb"]
+        assert np.array_equal(pg.reshape(-1, band, w), full.reshape(-1, n_parts, band, w)[:, part])
+    r.close()
+
+
 def test_errors_are_loud(torch_cuda, scenes):
     r = gpu.Renderer(0)
     import torch
