@@ -42,6 +42,8 @@ static_assert(offsetof(lol_op, f) == 8 && offsetof(lol_op, id) == 4, "lol_op fie
 static_assert(LOL_OP_SPHERE == lol::OP_SPHERE && LOL_OP_RBOX == lol::OP_RBOX && LOL_OP_PLANE == lol::OP_PLANE &&
               LOL_OP_SMIN == lol::OP_SMIN && LOL_OP_SMIN_R == lol::OP_SMIN_R && LOL_OP_TOP == lol::OP_TOP, "opcodes");
 
+constexpr uint32_t LOL_SPEC_MAX_OPS = 128;
+
 struct lol_gpu {
 	int          device = -1;
 	hipStream_t  stream = nullptr;
@@ -355,6 +357,13 @@ bool specialise(lol_gpu* ctx) {
 	ctx->spec_log.clear();
 	const char* env = getenv("LOL_GPU_SPECIALIZE");
 	if (!ctx->want_spec || (env && env[0] == '0')) return false;
+	/* straight-line code grows with the scene (the SDF is inlined in the march, normal and shadow loops, twice):
+	 * past LOL_SPEC_MAX_OPS it would outgrow the instruction cache and take tens of seconds to compile, so
+	 * large scenes stay on the interpreter. */
+	if (ctx->h_prog.n_ops > LOL_SPEC_MAX_OPS) {
+		ctx->spec_log = "scene too large to specialise; using the interpreter kernel";
+		return false;
+	}
 
 	hipDeviceProp_t prop;
 	std::string arch = "gfx950";

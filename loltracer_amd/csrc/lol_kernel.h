@@ -337,18 +337,26 @@ __device__ __forceinline__ float soft_shadow(Sdf& sdf, V3 p, V3 dir, float max_d
 	return maxf_(res, 0.f);
 }
 
-/* get_normal, naive_renderer.c:114-125: k0=(1,-1,-1) k1=(-1,-1,1) k2=(-1,1,-1) k3=(1,1,1) */
+/* get_normal, naive_renderer.c:114-125: k0=(1,-1,-1) k1=(-1,-1,1) k2=(-1,1,-1) k3=(1,1,1);
+ * n = normalize(k0*s0 + (k1*s1 + (k2*s2 + k3*s3))), s_i = sdf(p + k_i*h).  The taps run as a rolled loop from
+ * k3 down to k0 (one copy of the SDF code instead of four; + is commutative, so adding each new term on the
+ * left of the running sum reproduces the reference's association). */
 template <class Sdf>
 __device__ __forceinline__ V3 normal_at(Sdf& sdf, V3 p, float dist) {
 	const float h = dist / 100.f;
 	const float nh = -1.f * h;       /* v3scale(k, h) multiplies; -1*h == -h bit for bit */
-	float s0, s1, s2, s3; u32 unused;
-	sdf.eval({ p.x + h,  p.y + nh, p.z + nh }, s0, unused);
-	sdf.eval({ p.x + nh, p.y + nh, p.z + h  }, s1, unused);
-	sdf.eval({ p.x + nh, p.y + h,  p.z + nh }, s2, unused);
-	sdf.eval({ p.x + h,  p.y + h,  p.z + h  }, s3, unused);
-	V3 p0 = {  s0, -s0, -s0 }, p1 = { -s1, -s1,  s1 }, p2 = { -s2,  s2, -s2 }, p3 = { s3, s3, s3 };
-	return normalize(add(p0, add(p1, add(p2, p3))));
+	V3 acc = { 0.f, 0.f, 0.f };
+#pragma unroll 1
+	for (int k = 3; k >= 0; k--) {
+		/* sign pattern of tap k, wave-uniform: x is + for k0,k3; y is + for k2,k3; z is + for k1,k3 */
+		const bool px = k == 0 || k == 3, py = k >= 2, pz = k == 1 || k == 3;
+		float s; u32 unused;
+		sdf.eval({ p.x + (px ? h : nh), p.y + (py ? h : nh), p.z + (pz ? h : nh) }, s, unused);
+		const float ns = -s;          /* -1.f * s */
+		V3 term = { px ? s : ns, py ? s : ns, pz ? s : ns };
+		acc = k == 3 ? term : add(term, acc);
+	}
+	return normalize(acc);
 }
 
 __device__ __forceinline__ V3 lds_v3(const u32* base) {

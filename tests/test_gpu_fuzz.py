@@ -115,3 +115,25 @@ def test_orbit_frames_match_the_oracle(torch_cuda, scenes):
         g = gpu_render(torch_cuda, r, sc, w, h, camera=cam)
         check_against_oracle(g, sc, w, h, camera=cam)
     r.close()
+
+
+def test_large_scene_falls_back_to_the_interpreter(torch_cuda):
+    """More than LOL_SPEC_MAX_OPS (128) ops: no specialisation (code size / compile time), same pixels."""
+    rng = np.random.default_rng(3)
+    body = "sphere { point = (0,0,-5), radius = 1 }"
+    for i in range(69):
+        body = "smooth_union { smoothness = 1, a = sphere { point = %s, radius = %.3g }, b = %s }" % (
+            fmt(rng.normal(size=3) * [3, 2, 3] + [0, 0, -7]), rng.uniform(0.3, 1.2), body)
+    text = ("materials { { shininess = 2, diffuse = (0,0,0), specular = (0,0,0), ambient = (0,0,0) },"
+            " { shininess = 8, diffuse = (.5,.5,.5), specular = (.2,.2,.2), ambient = (.1,.1,.1) } }\n"
+            "scene { point_light { point = (0,9,0), diffuse_intensity = (2,2,2), specular_intensity = (2,2,2) }, "
+            + body.replace("{", "{ material = #1,", 1) + " }")
+    sc = S.Scene.parse_string(text)
+    assert sc.flatten().n_ops == 140
+    r = gpu.Renderer(0)
+    r.prepare(sc)
+    assert r.kernel_name() == "render_interp" and "too large" in r.specialize_log()
+    r.want_kernel = "render_interp"
+    g = gpu_render(torch_cuda, r, sc, 48, 32)
+    check_against_oracle(g, sc, 48, 32)
+    r.close()
