@@ -119,7 +119,8 @@ const char* lol_gpu_kernel_name(const lol_gpu* ctx);
  * disabled (set_specialize(ctx, 0) before the upload, or LOL_GPU_SPECIALIZE=0) or fails, frames
  * are rendered by the ahead-of-time interpreter kernel instead — same bits either way.
  */
-/* enable: 0 = interpreter only; 1 = specialise, with the proven-exact shortcuts; 3 = specialise without them */
+/* enable: 0 = interpreter, plain arithmetic; 1 = specialise, with the proven-exact shortcuts (default);
+ * 3 = specialise without them; 4 = interpreter with them.  Takes effect at the next lol_gpu_upload_program. */
 int         lol_gpu_set_specialize(lol_gpu* ctx, int enable);
 const char* lol_gpu_specialize_log(const lol_gpu* ctx);
 /*

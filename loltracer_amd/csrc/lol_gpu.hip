@@ -60,6 +60,7 @@ struct lol_gpu {
 	int          want_miss_skip = 1;     /* allow FLAG_MISS_SKIP when the program qualifies */
 	bool         miss_skip = false;      /* the uploaded program qualifies (miss_skip_ok) */
 	bool         dark_skip = false;      /* the uploaded program qualifies (dark_skip_ok) */
+	int          interp_sqrt_kind = 0;   /* fast sqrt of the interpreter: 3 (sqrt_r2) when proven and allowed, else 0 */
 	int          sqrt_verified = -1;     /* -1 not run, 0 none proven, else the lol::sqrt_fast KIND proven on this device */
 	std::vector<std::pair<uint32_t, bool>> div_verified;   /* k bits → proven */
 	unsigned long long* d_bad = nullptr; /* mismatch counter of the verification kernels */
@@ -85,8 +86,9 @@ int fail(lol_gpu* ctx, int status, const char* what, hipError_t e = hipSuccess) 
 	} while (0)
 
 template <int STACK>
-hipError_t launch_interp(const lol::Launch& L, dim3 grid, size_t lds, hipStream_t s) {
-	hipLaunchKernelGGL(lol::render_interp<STACK>, grid, dim3(lol::BLOCK), lds, s, L);
+hipError_t launch_interp(const lol::Launch& L, dim3 grid, size_t lds, hipStream_t s, int sqrt_kind) {
+	if (sqrt_kind == 3) hipLaunchKernelGGL((lol::render_interp<STACK, 3>), grid, dim3(lol::BLOCK), lds, s, L);
+	else                hipLaunchKernelGGL((lol::render_interp<STACK, 0>), grid, dim3(lol::BLOCK), lds, s, L);
 	return hipGetLastError();
 }
 
@@ -350,6 +352,34 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
 	return true;
 }
 
+/* Prove, on this device, the shortcuts `prog` could use (results are cached per context). */
+FastPaths prove_fast_paths(lol_gpu* ctx, const lol_program& prog) {
+	FastPaths fast;
+	const char* fenv = getenv("LOL_GPU_FAST");
+	if (!ctx->want_fast || (fenv && fenv[0] == '0')) return fast;
+	if (ctx->sqrt_verified < 0) {
+		ctx->sqrt_verified = 0;                     /* cheapest proven sequence wins */
+		for (int kind = 3; kind >= 1 && !ctx->sqrt_verified; kind--)
+			if (run_verify(ctx, kind, 0.f) == 0) ctx->sqrt_verified = kind;
+	}
+	fast.sqrt_kind = ctx->sqrt_verified;
+	for (uint32_t i = 0; i < prog.n_ops; i++) {
+		const lol_op& o = prog.ops[i];
+		if (o.op != LOL_OP_SMIN && o.op != LOL_OP_SMIN_R) continue;
+		uint32_t kb;
+		memcpy(&kb, &o.f[0], 4);
+		bool known = false, ok = false;
+		for (auto& e : ctx->div_verified) if (e.first == kb) { known = true; ok = e.second; }
+		if (!known) {
+			/* |k| >= 2^-100: see sminf_fastdiv (lol_kernel.h); then the exhaustive proof of the blend factor */
+			ok = (o.f[0] >= 0x1p-100f || o.f[0] <= -0x1p-100f) && run_verify(ctx, 0, o.f[0]) == 0;
+			ctx->div_verified.emplace_back(kb, ok);
+		}
+		if (ok && !fast.has(o.f[0])) fast.div_ok.push_back(o.f[0]);
+	}
+	return fast;
+}
+
 /* Compile + load the specialised kernel for ctx's program.  On failure the context keeps the interpreter. */
 bool specialise(lol_gpu* ctx) {
 	if (ctx->spec_module) { (void)hipModuleUnload(ctx->spec_module); ctx->spec_module = nullptr; ctx->spec_fn = nullptr; }
@@ -372,30 +402,9 @@ bool specialise(lol_gpu* ctx) {
 		arch = name.substr(0, name.find(':'));
 	}
 	/* prove the shortcuts on this device before generating them */
-	FastPaths fast;
-	const char* fenv = getenv("LOL_GPU_FAST");
+	FastPaths fast = prove_fast_paths(ctx, ctx->h_prog);
 	std::string note;
-	if (ctx->want_fast && !(fenv && fenv[0] == '0')) {
-		if (ctx->sqrt_verified < 0) {
-			ctx->sqrt_verified = 0;                     /* cheapest proven sequence wins */
-			for (int kind = 3; kind >= 1 && !ctx->sqrt_verified; kind--)
-				if (run_verify(ctx, kind, 0.f) == 0) ctx->sqrt_verified = kind;
-		}
-		fast.sqrt_kind = ctx->sqrt_verified;
-		for (uint32_t i = 0; i < ctx->h_prog.n_ops; i++) {
-			const lol_op& o = ctx->h_prog.ops[i];
-			if (o.op != LOL_OP_SMIN && o.op != LOL_OP_SMIN_R) continue;
-			uint32_t kb;
-			memcpy(&kb, &o.f[0], 4);
-			bool known = false, ok = false;
-			for (auto& e : ctx->div_verified) if (e.first == kb) { known = true; ok = e.second; }
-			if (!known) {
-				/* |k| >= 2^-100: see sminf_fastdiv (lol_kernel.h); then the exhaustive proof of the blend factor */
-				ok = (o.f[0] >= 0x1p-100f || o.f[0] <= -0x1p-100f) && run_verify(ctx, 0, o.f[0]) == 0;
-				ctx->div_verified.emplace_back(kb, ok);
-			}
-			if (ok && !fast.has(o.f[0])) fast.div_ok.push_back(o.f[0]);
-		}
+	{
 		char b[160];
 		snprintf(b, sizeof b, "fast paths proven on device: sqrt=%d, smin divisors=%zu\n", fast.sqrt_kind, fast.div_ok.size());
 		note = b;
@@ -472,9 +481,9 @@ const char* lol_gpu_error(const lol_gpu* ctx) { return ctx ? ctx->err : "null co
 
 int lol_gpu_set_specialize(lol_gpu* ctx, int enable) {
 	if (!ctx) return LOL_GPU_ERR_ARG;
-	ctx->want_spec = enable ? 1 : 0;
-	ctx->want_fast = enable >= 2 || enable == 1 ? 1 : 0;
-	if (enable == 3) ctx->want_fast = 0;          /* 3 = specialise, but without the fast exact paths */
+	/* 0 interpreter, plain | 1 specialised + proven fast paths (default) | 3 specialised, plain | 4 interpreter + fast paths */
+	ctx->want_spec = (enable == 1 || enable == 3) ? 1 : 0;
+	ctx->want_fast = (enable == 1 || enable == 4) ? 1 : 0;
 	return LOL_GPU_OK;
 }
 
@@ -535,9 +544,27 @@ int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog) {
 	LOL_HIP(ctx, hipSetDevice(ctx->device));
 	/* ordered after frames already queued on the context stream */
 	LOL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	LOL_HIP(ctx, hipMemcpy(ctx->d_prog, prog, sizeof *prog, hipMemcpyHostToDevice));
 	ctx->h_prog = *prog;
 	ctx->have_prog = true;
+	/* The interpreter's copy: smooth unions whose blend factor is proven become OP_SMINF* with {k, 2k, .5/k};
+	 * the proven sqrt is selected by instantiation at launch. */
+	{
+		FastPaths fast = prove_fast_paths(ctx, *prog);
+		ctx->interp_sqrt_kind = fast.sqrt_kind == 3 ? 3 : 0;
+		lol_program* patched = new (std::nothrow) lol_program(*prog);
+		if (!patched) return fail(ctx, LOL_GPU_ERR_HIP, "out of memory");
+		for (uint32_t i = 0; i < patched->n_ops; i++) {
+			lol_op& o = patched->ops[i];
+			if ((o.op == LOL_OP_SMIN || o.op == LOL_OP_SMIN_R) && fast.has(o.f[0])) {
+				o.op = o.op == LOL_OP_SMIN ? lol::OP_SMINF : lol::OP_SMINF_R;
+				o.f[1] = 2.0f * o.f[0];
+				o.f[2] = 0.5f * (1.0f / o.f[0]);
+			}
+		}
+		hipError_t e = hipMemcpy(ctx->d_prog, patched, sizeof *patched, hipMemcpyHostToDevice);
+		delete patched;
+		if (e != hipSuccess) return fail(ctx, LOL_GPU_ERR_HIP, "hipMemcpy(program)", e);
+	}
 	const char* ms = getenv("LOL_GPU_MISS_SKIP");
 	ctx->miss_skip = ctx->want_miss_skip && !(ms && ms[0] == '0') && miss_skip_ok(*prog);
 	ctx->dark_skip = ctx->want_miss_skip && !(ms && ms[0] == '0') && dark_skip_ok(*prog);
@@ -612,9 +639,10 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	} else {
 		size_t lds = common + (size_t)P.n_ops * lol::OP_DWORDS * 4;
 		uint32_t need = P.max_stack;
-		if (need <= 2)      e = launch_interp<2>(L, grid, lds, s);
-		else if (need <= 4) e = launch_interp<4>(L, grid, lds, s);
-		else                e = launch_interp<LOL_MAX_STACK>(L, grid, lds, s);
+		const int kind = ctx->interp_sqrt_kind;
+		if (need <= 2)      e = launch_interp<2>(L, grid, lds, s, kind);
+		else if (need <= 4) e = launch_interp<4>(L, grid, lds, s, kind);
+		else                e = launch_interp<LOL_MAX_STACK>(L, grid, lds, s, kind);
 	}
 	if (e != hipSuccess) return fail(ctx, LOL_GPU_ERR_HIP, "kernel launch", e);
 	return LOL_GPU_OK;

@@ -10,7 +10,7 @@
  * powf (colour, never control flow) may differ from glibc by an ulp.
  *
  * The file is compiled twice:
- *  - ahead of time by hipcc (lol_gpu.hip) with Interp<STACK>: the flattened SDF
+ *  - ahead of time by hipcc (lol_gpu.hip) with Interp<STACK, KIND>: the flattened SDF
  *    program is staged once per block into LDS and interpreted with
  *    wave-uniform scalar branches and a register operand stack;
  *  - at render_prepare time by hipRTC (lol_gpu.hip: specialise()) together with
@@ -61,7 +61,8 @@ constexpr int BLOCK  = TILE_W * TILE_H;        /* 64 * WAVES_X threads; wave k o
 
 /* dword layouts of lol_op / lol_light / lol_material (lol_scene.h); checked by static_asserts in lol_gpu.hip */
 constexpr int OP_DWORDS = 10, LIGHT_DWORDS = 9, MATERIAL_DWORDS = 10;
-enum { OP_SPHERE = 0, OP_RBOX = 1, OP_PLANE = 2, OP_SMIN = 3, OP_SMIN_R = 4, OP_TOP = 5 };
+enum { OP_SPHERE = 0, OP_RBOX = 1, OP_PLANE = 2, OP_SMIN = 3, OP_SMIN_R = 4, OP_TOP = 5,
+       OP_SMINF = 6, OP_SMINF_R = 7 };   /* device-only: smooth min with a proven fast blend factor */
 
 /* Launch.flags */
 constexpr u32 FLAG_MISS_SKIP = 1u;   /* a wave whose rays all escaped may skip normal + lights (see shade_pixel) */
@@ -248,10 +249,11 @@ __device__ __forceinline__ float sd_round_box_fast(V3 p, float cx, float cy, flo
  * points into LDS; every lane reads the same address, and the opcode is moved
  * to an SGPR so the switch is a scalar branch.  STACK is the register stack
  * depth (>= program max_stack); push = shift, so nothing goes to scratch. */
-template <int STACK>
+template <int STACK, int KIND = 0>
 struct Interp {
 	const u32* ops;      /* LDS */
 	u32        n_ops;
+	Range      rg;       /* KIND != 0: range of the squared lengths given to the proven fast sqrt (see above) */
 
 	__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id) {
 		float s[STACK];
@@ -262,25 +264,34 @@ struct Interp {
 		for (u32 i = 0; i < n_ops; i++) {
 			const u32* o = ops + i * OP_DWORDS;
 			const float* f = reinterpret_cast<const float*>(o + 2);
-			u32 op = __builtin_amdgcn_readfirstlane(o[0]);
+			/* (prefetching op i+1 while op i executes was tried: more VGPRs, lower occupancy, 20 % slower) */
+			const u32 w0 = o[0], w1 = o[1];
+			u32 op = __builtin_amdgcn_readfirstlane(w0);
 			if (op <= OP_PLANE) {
 				float d;
-				if (op == OP_SPHERE)    d = sd_sphere(p, f[0], f[1], f[2], f[3]);
-				else if (op == OP_RBOX) d = sd_round_box(p, f[0], f[1], f[2], f[3], f[4], f[5], f[6]);
-				else                    d = p.y - f[0];          /* plane: (p - (0,y,0)).y */
+				if (op == OP_SPHERE)
+					d = KIND ? sd_sphere_fast<KIND ? KIND : 1>(p, f[0], f[1], f[2], f[3], rg)
+					         : sd_sphere(p, f[0], f[1], f[2], f[3]);
+				else if (op == OP_RBOX)
+					d = KIND ? sd_round_box_fast<KIND ? KIND : 1>(p, f[0], f[1], f[2], f[3], f[4], f[5], f[6], rg)
+					         : sd_round_box(p, f[0], f[1], f[2], f[3], f[4], f[5], f[6]);
+				else
+					d = p.y - f[0];                              /* plane: (p - (0,y,0)).y */
 #pragma unroll
 				for (int j = STACK - 1; j > 0; j--) s[j] = s[j - 1];
 				s[0] = d;
 			} else if (op == OP_TOP) {                           /* sdf(): strict '<', naive_renderer.c:39 */
-				u32 id = __builtin_amdgcn_readfirstlane(o[1]);
+				u32 id = __builtin_amdgcn_readfirstlane(w1);
 				if (s[0] < best) { best = s[0]; best_id = id; }
 #pragma unroll
 				for (int j = 0; j < STACK - 1; j++) s[j] = s[j + 1];
-			} else {                                             /* SMIN: top is b; SMIN_R: top is a */
+			} else {                                             /* SMIN*: top is b; SMIN*_R: top is a */
 				float top = s[0], under = s[1];
-				float a = op == OP_SMIN ? under : top;
-				float b = op == OP_SMIN ? top : under;
-				s[0] = sminf_(a, b, f[0]);
+				const bool swapped = op == OP_SMIN_R || op == OP_SMINF_R;
+				float a = swapped ? top : under;
+				float b = swapped ? under : top;
+				/* OP_SMINF*: lol_gpu.hip rewrote the op after proving the fast blend factor for this k: f = {k, 2k, .5/k} */
+				s[0] = op >= OP_SMINF ? sminf_fastdiv(a, b, f[0], f[1], f[2]) : sminf_(a, b, f[0]);
 #pragma unroll
 				for (int j = 1; j < STACK - 1; j++) s[j] = s[j + 1];
 			}
@@ -497,8 +508,10 @@ __device__ __forceinline__ void stage_common(const Launch& L, u32* lds) {
 	for (u32 i = threadIdx.x; i < L.n_roots; i += BLOCK) l_rootm[i] = L.root_material[i];
 }
 
-/* Generic kernel: LDS = ops | common */
-template <int STACK>
+/* Generic kernel: LDS = ops | common.  KIND != 0 selects the proven fast sqrt (the host launches that
+ * instantiation only after the exhaustive check passed on the device); a wave that fed it a squared length
+ * outside its proven domain shades its pixels again with the plain interpreter, as in the specialised kernel. */
+template <int STACK, int KIND>
 __global__ __launch_bounds__(BLOCK)
 void render_interp(const Launch L) {
 	extern __shared__ u32 lds[];
@@ -507,8 +520,12 @@ void render_interp(const Launch L) {
 	for (u32 i = threadIdx.x; i < L.n_ops * OP_DWORDS; i += BLOCK) l_ops[i] = L.ops[i];
 	stage_common(L, l_common);
 	__syncthreads();
-	Interp<STACK> sdf{ l_ops, L.n_ops };
+	Interp<STACK, KIND> sdf{ l_ops, L.n_ops, {} };
 	Pixel P = shade_pixel(L, sdf, l_common);
+	if (KIND != 0 && __ballot(sdf.rg.outside()) != 0) {
+		Interp<STACK, 0> exact{ l_ops, L.n_ops, {} };
+		P = shade_pixel(L, exact, l_common);
+	}
 	store_pixel(L, P, l_common);
 }
 

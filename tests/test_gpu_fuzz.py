@@ -67,7 +67,7 @@ def torch_cuda():
     return torch
 
 
-@pytest.mark.parametrize("mode", [1, 3, 0], ids=["spec", "spec-plain", "interp"])
+@pytest.mark.parametrize("mode", [1, 3, 0, 4], ids=["spec", "spec-plain", "interp-plain", "interp"])
 def test_random_scenes(torch_cuda, mode):
     rng = np.random.default_rng(20261004)
     r = gpu.Renderer(0, specialize=mode)
@@ -95,7 +95,7 @@ def test_degenerate_inputs(torch_cuda):
         "materials { { shininess = -1.5, diffuse = (.2,.2,.2), specular = (.3,.3,.3), ambient = (0,0,0) } } scene { camera { point = (0,1,0), direction = (0,-.2,-1), fov = 90 }, plane { y = 0 }, point_light { point = (2,5,-3), diffuse_intensity = (2,2,2), specular_intensity = (2,2,2) } }",
         "materials { { shininess = 4, diffuse = (.2,.2,.2), specular = (.3,.3,.3), ambient = (.1,.1,.1) } } scene { camera { point = (0,0,0), direction = (0,0,-1), fov = 120 }, plane { y = 0 }, box { point = (0,0,-4), point2 = (1,1,1), radius = 0 }, point_light { point = (0,0,0), diffuse_intensity = (2,2,2), specular_intensity = (2,2,2) } }",
     ]
-    for mode in (1, 0):
+    for mode in (1, 4):
         r = gpu.Renderer(0, specialize=mode)
         for text in cases:
             sc = S.Scene.parse_string(text)

@@ -25,11 +25,11 @@ def torch_cuda():
     return torch
 
 
-@pytest.fixture(scope="module", params=[1, 3, 0], ids=["spec", "spec-plain", "interp"])
+@pytest.fixture(scope="module", params=[1, 3, 0, 4], ids=["spec", "spec-plain", "interp-plain", "interp"])
 def renderer(torch_cuda, request):
-    """All kernels: hipRTC scene-specialised (with and without the proven fast paths) and the AOT LDS interpreter."""
+    """All kernels: hipRTC scene-specialised and the AOT LDS interpreter, each with and without the proven fast paths."""
     r = gpu.Renderer(0, specialize=request.param)
-    r.want_kernel = "lol_render_spec" if request.param else "render_interp"
+    r.want_kernel = "lol_render_spec" if request.param in (1, 3) else "render_interp"
     yield r
     r.close()
 
