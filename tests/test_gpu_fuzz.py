@@ -15,18 +15,23 @@ from test_gpu_parity import check_against_oracle, gpu_render
 pytestmark = pytest.mark.gpu
 
 
+def num(x):
+    """`.lol` numbers are [-.0-9]+ (scene-lexer.l:12): no exponent syntax, so never print one."""
+    return ("%.5f" % x).rstrip("0").rstrip(".") if "." in "%.5f" % x else "%.5f" % x
+
+
 def fmt(v):
-    return "(%s)" % ", ".join("%.4g" % x for x in v)
+    return "(%s)" % ", ".join(num(x) for x in v)
 
 
 def rand_leaf(rng):
     kind = rng.integers(3)
     if kind == 0:
-        return "sphere { point = %s, radius = %.4g }" % (fmt(rng.normal(size=3) * [4, 2, 4] + [0, 1, -7]), rng.uniform(0.3, 3))
+        return "sphere { point = %s, radius = %s }" % (fmt(rng.normal(size=3) * [4, 2, 4] + [0, 1, -7]), num(rng.uniform(0.3, 3)))
     if kind == 1:
-        return "box { point = %s, point2 = %s, radius = %.4g }" % (
-            fmt(rng.normal(size=3) * [4, 2, 4] + [0, 1, -7]), fmt(rng.uniform(0.2, 2.5, size=3)), rng.uniform(0, 0.8))
-    return "plane { y = %.4g }" % rng.uniform(-3, 0)
+        return "box { point = %s, point2 = %s, radius = %s }" % (
+            fmt(rng.normal(size=3) * [4, 2, 4] + [0, 1, -7]), fmt(rng.uniform(0.2, 2.5, size=3)), num(rng.uniform(0, 0.8)))
+    return "plane { y = %s }" % num(rng.uniform(-3, 0))
 
 
 def rand_tree(rng, depth):
@@ -35,7 +40,7 @@ def rand_tree(rng, depth):
     a, b = rand_tree(rng, depth - 1), rand_tree(rng, int(rng.integers(0, depth)))
     if rng.random() < 0.5:
         a, b = b, a
-    return "smooth_union { smoothness = %.4g, a = %s, b = %s }" % (rng.choice([0.5, 1, 2, 3, 0.25, 7.5]), a, b)
+    return "smooth_union { smoothness = %s, a = %s, b = %s }" % (num(rng.choice([0.5, 1, 2, 3, 0.25, 7.5])), a, b)
 
 
 def rand_scene(rng):
@@ -43,13 +48,13 @@ def rand_scene(rng):
     mats = []
     for i in range(n_mat):
         z = i == 0 and rng.random() < 0.5
-        mats.append("{ shininess = %.4g, diffuse = %s, specular = %s, ambient = %s }" % (
-            rng.choice([0, 1, 2, 8, 30.5]), fmt(rng.uniform(0, 0 if z else 0.6, 3)), fmt(rng.uniform(0, 0 if z else 0.4, 3)),
+        mats.append("{ shininess = %s, diffuse = %s, specular = %s, ambient = %s }" % (
+            num(rng.choice([0, 1, 2, 8, 30.5])), fmt(rng.uniform(0, 0 if z else 0.6, 3)), fmt(rng.uniform(0, 0 if z else 0.4, 3)),
             fmt(rng.uniform(0, 0.5, 3))))
     comps = ["ambient { color = %s }" % fmt(rng.uniform(0, 0.2, 3)),
-             "camera { point = %s, direction = %s, fov = %.4g }" % (
+             "camera { point = %s, direction = %s, fov = %s }" % (
                  fmt(rng.normal(size=3) * [2, 1, 2] + [0, 2, 2]), fmt(rng.normal(size=3) * 0.4 + [0, -0.3, -1]),
-                 rng.uniform(40, 160))]
+                 num(rng.uniform(40, 160)))]
     for _ in range(int(rng.integers(0, 4))):
         comps.append("point_light { point = %s, diffuse_intensity = %s, specular_intensity = %s }" % (
             fmt(rng.normal(size=3) * 5 + [0, 8, -3]), fmt(rng.uniform(0.5, 4, 3)), fmt(rng.uniform(0, 4, 3))))
@@ -122,8 +127,8 @@ def test_large_scene_falls_back_to_the_interpreter(torch_cuda):
     rng = np.random.default_rng(3)
     body = "sphere { point = (0,0,-5), radius = 1 }"
     for i in range(69):
-        body = "smooth_union { smoothness = 1, a = sphere { point = %s, radius = %.3g }, b = %s }" % (
-            fmt(rng.normal(size=3) * [3, 2, 3] + [0, 0, -7]), rng.uniform(0.3, 1.2), body)
+        body = "smooth_union { smoothness = 1, a = sphere { point = %s, radius = %s }, b = %s }" % (
+            fmt(rng.normal(size=3) * [3, 2, 3] + [0, 0, -7]), num(rng.uniform(0.3, 1.2)), body)
     text = ("materials { { shininess = 2, diffuse = (0,0,0), specular = (0,0,0), ambient = (0,0,0) },"
             " { shininess = 8, diffuse = (.5,.5,.5), specular = (.2,.2,.2), ambient = (.1,.1,.1) } }\n"
             "scene { point_light { point = (0,9,0), diffuse_intensity = (2,2,2), specular_intensity = (2,2,2) }, "
