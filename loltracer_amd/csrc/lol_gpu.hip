@@ -20,6 +20,7 @@
 
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
+#include <dlfcn.h>
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
@@ -285,6 +286,29 @@ std::string generate_source(const lol_program& P, const FastPaths* fast) {
 }
 
 /* hipRTC: generated source + lol_kernel.h → code object for `arch`.  Needs no device. */
+/* ---- optional roctx ranges (LOL_GPU_ROCTX=1): one range per frame launch, visible to `rocprofv3 --marker-trace`.
+ * The counterpart of the reference's perf/jitdump aid (jitdump.c) on this side; resolved with dlopen so the library
+ * is only needed when asked for. */
+struct Roctx {
+	int  (*push)(const char*) = nullptr;
+	int  (*pop)() = nullptr;
+	bool tried = false;
+	void init() {
+		if (tried) return;
+		tried = true;
+		const char* e = getenv("LOL_GPU_ROCTX");
+		if (!e || e[0] != '1') return;
+		for (const char* name : { "librocprofiler-sdk-roctx.so", "libroctx64.so" }) {
+			if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+				push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+				pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+				if (push && pop) return;
+				push = nullptr; pop = nullptr;
+			}
+		}
+	}
+} g_roctx;
+
 /* Process-wide cache of compiled kernels: hosts (and the tests) upload the same scene many times. */
 std::mutex g_cache_mutex;
 std::unordered_map<std::string, std::vector<char>> g_code_cache;
@@ -633,6 +657,12 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
 	LOL_HIP(ctx, hipSetDevice(ctx->device));
 	hipError_t e;
+	g_roctx.init();
+	if (g_roctx.push) {
+		char label[96];
+		snprintf(label, sizeof label, "lol frame %dx%d rows=%d part=%d/%d %s", w, h, n_rows, R->part, R->n_parts, ctx->kernel_name);
+		g_roctx.push(label);
+	}
 	if (ctx->spec_fn) {
 		void* args[] = { &L };
 		e = hipModuleLaunchKernel(ctx->spec_fn, grid.x, grid.y, 1, block, 1, 1, (unsigned)common, s, args, nullptr);
@@ -644,6 +674,7 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 		else if (need <= 4) e = launch_interp<4>(L, grid, lds, s, kind);
 		else                e = launch_interp<LOL_MAX_STACK>(L, grid, lds, s, kind);
 	}
+	if (g_roctx.pop) g_roctx.pop();
 	if (e != hipSuccess) return fail(ctx, LOL_GPU_ERR_HIP, "kernel launch", e);
 	return LOL_GPU_OK;
 }
