@@ -203,7 +203,8 @@ def main():
         cams = [sc.frame_camera(w, h)]
 
     # N>1: two frames in flight per rank — frame i's gather overlaps frame i+1's kernel (multi.GatherPipeline).
-    pipe = multi.GatherPipeline(w, h, band if not orbit else h, dev, depth=2) if (world > 1 and not orbit) else None
+    depth = max(1, int(os.environ.get("LOL_BENCH_PIPELINE_DEPTH", "2")))     # 1 = gather each frame before the next renders
+    pipe = multi.GatherPipeline(w, h, band if not orbit else h, dev, depth=depth) if (world > 1 and not orbit) else None
     local = torch.zeros((n_local, w), dtype=torch.int32, device=dev) if pipe is None else None
 
     kernel_ms = []
