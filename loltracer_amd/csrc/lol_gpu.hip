@@ -443,18 +443,23 @@ bool specialise(lol_gpu* ctx) {
 		}
 	}
 	const int shape[3] = { ctx->wave_w, ctx->wave_h, ctx->waves_x };
-	if (!compile_spec(ctx->h_prog, &fast, arch, code, ctx->spec_log, nullptr, shape)) return false;
+	/* an unexpected failure is reported once on stderr: frames still render, through the (slower) interpreter */
+	auto complain = [&]() {
+		fprintf(stderr, "lol_gpu: scene specialisation failed, using the interpreter kernel: %s\n", ctx->spec_log.c_str());
+		return false;
+	};
+	if (!compile_spec(ctx->h_prog, &fast, arch, code, ctx->spec_log, nullptr, shape)) return complain();
 	ctx->spec_log = note + ctx->spec_log;
 	if (hipModuleLoadData(&ctx->spec_module, code.data()) != hipSuccess) {
 		ctx->spec_log = "hipModuleLoadData failed";
 		ctx->spec_module = nullptr;
-		return false;
+		return complain();
 	}
 	if (hipModuleGetFunction(&ctx->spec_fn, ctx->spec_module, "lol_render_spec") != hipSuccess) {
 		ctx->spec_log = "lol_render_spec not found in the compiled module";
 		(void)hipModuleUnload(ctx->spec_module);
 		ctx->spec_module = nullptr; ctx->spec_fn = nullptr;
-		return false;
+		return complain();
 	}
 	snprintf(ctx->kernel_name, sizeof ctx->kernel_name, "lol_render_spec");
 	return true;
