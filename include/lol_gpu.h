@@ -147,6 +147,13 @@ int         lol_gpu_verify_fast_paths(lol_gpu* ctx, float k, unsigned long long 
  */
 int         lol_gpu_set_miss_skip(lol_gpu* ctx, int enable);
 int         lol_gpu_miss_skip_active(const lol_gpu* ctx);
+/*
+ * Diagnostic: out[i] = the renderer's powf(x[i], y[i]) (device pointers, asynchronous on `stream`, NULL = the
+ * context's stream).  The kernel's powf restates the algorithm of the CPU libm's powf so that colours round
+ * identically on both sides (lol_kernel.h, powf_glibc); this entry point lets a test compare the two bit for bit.
+ */
+int         lol_gpu_powf_batch(lol_gpu* ctx, const float* x_dev, const float* y_dev, float* out_dev, size_t n,
+                               void* stream);
 /* No device needed: writes <out_base>.hip (generated source) and <out_base>.co (code object for `arch`).
  * assume_fast != 0 generates the shortcuts without proof — for ISA inspection only, never for rendering. */
 int         lol_gpu_compile_offline(const lol_program* prog, const char* arch, const char* out_base,

@@ -167,6 +167,12 @@ __global__ __launch_bounds__(VERIFY_THREADS) void verify_div_kernel(float k, flo
 	if (n) atomicAdd(bad, (unsigned long long)n);
 }
 
+/* diagnostic: out[i] = powf_glibc(x[i], y[i]) — lets the tests compare the device's powf with the CPU's */
+__global__ __launch_bounds__(256) void powf_batch_kernel(const float* x, const float* y, float* out, size_t n) {
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) out[i] = lol::powf_glibc(x[i], y[i]);
+}
+
 /* returns mismatch count, or ~0ull when the check itself could not run */
 unsigned long long run_verify(lol_gpu* ctx, int sqrt_kind, float k) {
 	if (!ctx->d_bad && hipMalloc(reinterpret_cast<void**>(&ctx->d_bad), sizeof(unsigned long long)) != hipSuccess)
@@ -734,6 +740,16 @@ int lol_gpu_memcpy_d2h(lol_gpu* ctx, void* host, const void* dev, size_t bytes) 
 }
 
 const char* lol_gpu_kernel_name(const lol_gpu* ctx) { return ctx ? ctx->kernel_name : ""; }
+
+int lol_gpu_powf_batch(lol_gpu* ctx, const float* x_dev, const float* y_dev, float* out_dev, size_t n, void* stream) {
+	if (!ctx || !x_dev || !y_dev || !out_dev) return LOL_GPU_ERR_ARG;
+	if (n == 0) return LOL_GPU_OK;
+	LOL_HIP(ctx, hipSetDevice(ctx->device));
+	hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+	hipLaunchKernelGGL(powf_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x_dev, y_dev, out_dev, n);
+	LOL_HIP(ctx, hipGetLastError());
+	return LOL_GPU_OK;
+}
 
 /* Offline use (tests, ISA inspection; needs no device): compile the scene-specialised kernel for
  * `arch` and write `<out_base>.hip` (generated source) and `<out_base>.co` (code object). */

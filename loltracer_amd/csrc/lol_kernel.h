@@ -6,8 +6,9 @@
  * gamma → XRGB8888.  Arithmetic is IEEE binary32 in the reference's operation
  * order (compile with -ffp-contract=off: the reference has no FMA), with
  * correctly rounded '/' and sqrt (hipcc's default), so every loop exit
- * (naive_renderer.c:61,85) is taken on the same iteration as on the CPU; only
- * powf (colour, never control flow) may differ from glibc by an ulp.
+ * (naive_renderer.c:61,85) is taken on the same iteration as on the CPU, and
+ * powf (colour only) restates the CPU libm's algorithm (powf_glibc below), so the
+ * frames come out bit-identical to the CPU oracle's, packed pixels included.
  *
  * The file is compiled twice:
  *  - ahead of time by hipcc (lol_gpu.hip) with Interp<STACK, KIND>: the flattened SDF
@@ -131,6 +132,122 @@ __device__ __forceinline__ float sd_round_box(V3 p, float cx, float cy, float cz
 	V3 q = { __builtin_fabsf(p.x - cx) - bx, __builtin_fabsf(p.y - cy) - by, __builtin_fabsf(p.z - cz) - bz };
 	V3 cq = { maxf_(q.x, 0.f), maxf_(q.y, 0.f), maxf_(q.z, 0.f) };
 	return len(cq) + minf_(maxf_(q.x, maxf_(q.y, q.z)), 0.f) - r;
+}
+
+/* ------------------------------------------------------------------------ powf
+ * The colour path calls powf 3 + n_lights times per pixel (naive_renderer.c:158,231).  The device
+ * library's powf and the CPU's (glibc) each err by < 1 ulp but not identically, which moves a few dozen
+ * 8-bit channels per 4K frame by one step.  To round colours exactly like the reference does on the CPU,
+ * this restates the algorithm of the powf the CPU oracle runs — glibc 2.35 sysdeps/ieee754/flt-32/e_powf.c
+ * (Szabolcs Nagy's design from ARM optimized-routines): log2(x) from a 16-entry table + degree-5 polynomial,
+ * y*log2(x) in binary64, 2^z from a 32-entry table + cubic, every a*b+c fused as in glibc's FMA build
+ * (the variant x86-64 glibc selects on any CPU with FMA/AVX2).  Table values are the published ones.
+ * tests/test_gpu_powf.py compares it with the CPU's powf bit for bit over every float in [0, 1] for the
+ * exponents in use and over millions of random (x, y) pairs including NaN / inf / negative / subnormal. */
+__device__ const double POWF_LOG2_TAB[16][2] = {
+	{ 0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2 }, { 0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2 },
+	{ 0x1.49539f0f010b0p+0, -0x1.7418b0a1fb77bp-2 }, { 0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2 },
+	{ 0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2 }, { 0x1.25e227b0b8ea0p+0, -0x1.97c1d1b3b7af0p-3 },
+	{ 0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3 }, { 0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4 },
+	{ 0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5 }, { 0x1.0000000000000p+0, 0x0.0p+0 },
+	{ 0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4 }, { 0x1.ca4b31f026aa0p-1, 0x1.476a9543891bap-3 },
+	{ 0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3 }, { 0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2 },
+	{ 0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2 }, { 0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2 },
+};
+__device__ const unsigned long long POWF_EXP2_TAB[32] = {
+	0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+	0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+	0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+	0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+	0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+	0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+	0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+	0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull,
+};
+__device__ __forceinline__ bool powf_zeroinfnan(u32 i) { return 2u * i - 1u >= 2u * 0x7f800000u - 1u; }
+/* 0: y is not an integer, 1: odd integer, 2: even integer */
+__device__ __forceinline__ int powf_checkint(u32 iy) {
+	int e = (int)(iy >> 23 & 0xffu);
+	if (e < 0x7f) return 0;
+	if (e > 0x7f + 23) return 2;
+	if (iy & ((1u << (0x7f + 23 - e)) - 1u)) return 0;
+	if (iy & (1u << (0x7f + 23 - e))) return 1;
+	return 2;
+}
+__device__ __noinline__ float powf_glibc(float x, float y) {
+	const double A0 = 0x1.27616c9496e0bp-2, A1 = -0x1.71969a075c67ap-2, A2 = 0x1.ec70a6ca7baddp-2,
+	             A3 = -0x1.7154748bef6c8p-1, A4 = 0x1.71547652ab82bp+0;
+	const double C0 = 0x1.c6af84b912394p-5, C1 = 0x1.ebfce50fac4f3p-3, C2 = 0x1.62e42ff0c52d6p-1;
+	const double SHIFT = 0x1.8p+47;                     /* 0x1.8p52 / 32 */
+	u32 sign_bias = 0;
+	u32 ix = __builtin_bit_cast(u32, x), iy = __builtin_bit_cast(u32, y);
+	if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u || powf_zeroinfnan(iy)) {
+		/* either (x < 0x1p-126 or inf or nan) or (y is 0 or inf or nan) */
+		if (powf_zeroinfnan(iy)) {
+			if (2u * iy == 0u) return 1.0f;
+			if (ix == 0x3f800000u) return 1.0f;
+			if (2u * ix > 2u * 0x7f800000u || 2u * iy > 2u * 0x7f800000u) return x + y;
+			if (2u * ix == 2u * 0x3f800000u) return 1.0f;
+			if ((2u * ix < 2u * 0x3f800000u) == !(iy & 0x80000000u)) return 0.0f;   /* |x|<1 && y==inf or |x|>1 && y==-inf */
+			return y * y;
+		}
+		if (powf_zeroinfnan(ix)) {
+			float x2 = x * x;
+			if ((ix & 0x80000000u) && powf_checkint(iy) == 1) x2 = -x2;
+			return (iy & 0x80000000u) ? 1 / x2 : x2;
+		}
+		/* x and y are non-zero finite */
+		if (ix & 0x80000000u) {
+			int yint = powf_checkint(iy);
+			if (yint == 0) return (x - x) / (x - x);
+			if (yint == 1) sign_bias = 1u << (5 + 11);
+			ix &= 0x7fffffffu;
+		}
+		if (ix < 0x00800000u) {                          /* normalise subnormal x */
+			ix = __builtin_bit_cast(u32, x * 0x1p23f);
+			ix &= 0x7fffffffu;
+			ix -= 23u << 23;
+		}
+	}
+	/* log2_inline */
+	u32 tmp = ix - 0x3f330000u;
+	int i = (int)((tmp >> (23 - 4)) % 16u);
+	u32 top = tmp & 0xff800000u;
+	u32 iz = ix - top;
+	int k = (int)top >> 23;
+	double invc = POWF_LOG2_TAB[i][0], logc = POWF_LOG2_TAB[i][1];
+	double z = (double)__builtin_bit_cast(float, iz);
+	double r = __builtin_fma(z, invc, -1.0);
+	double y0 = logc + (double)k;
+	double r2 = r * r;
+	double yy = __builtin_fma(A0, r, A1);
+	double pp = __builtin_fma(A2, r, A3);
+	double r4 = r2 * r2;
+	double q = __builtin_fma(A4, r, y0);
+	q = __builtin_fma(pp, r2, q);
+	double logx = __builtin_fma(yy, r4, q);
+	double ylogx = (double)y * logx;                      /* cannot overflow, y is single precision */
+	if ((__builtin_bit_cast(unsigned long long, ylogx) >> 47 & 0xffffu) >=
+	    (__builtin_bit_cast(unsigned long long, 126.0) >> 47)) {
+		/* |y*log(x)| >= 126 */
+		if (ylogx > 0x1.fffffffd1d571p+6) return sign_bias ? -__builtin_inff() : __builtin_inff();
+		if (ylogx <= -150.0) return sign_bias ? -0.0f : 0.0f;
+	}
+	/* exp2_inline */
+	double kd = ylogx + SHIFT;
+	unsigned long long ki = __builtin_bit_cast(unsigned long long, kd);
+	kd -= SHIFT;
+	double rr = ylogx - kd;
+	unsigned long long t = POWF_EXP2_TAB[ki % 32u];
+	unsigned long long ski = ki + sign_bias;
+	t += ski << (52 - 5);
+	double sc = __builtin_bit_cast(double, t);
+	double zz = __builtin_fma(C0, rr, C1);
+	double rr2 = rr * rr;
+	double res = __builtin_fma(C2, rr, 1.0);
+	res = __builtin_fma(zz, rr2, res);
+	res = res * sc;
+	return (float)res;
 }
 
 /* ---------------------------------------------------------------- fast exact paths
@@ -460,7 +577,7 @@ __device__ __forceinline__ Pixel shade_pixel(const Launch& L, Sdf& sdf, const u3
 			V3 refl = sub(scale(n, 2.f * dot(light_dir, n)), light_dir);
 			V3 Id = mul(scale(lds_v3(lp + 3), shadow * di), m_diff);
 			total = add(total, Id);
-			float si = di * powf(clampf_(dot(refl, camera_dir), 0.f, 1.f), shininess);
+			float si = di * powf_glibc(clampf_(dot(refl, camera_dir), 0.f, 1.f), shininess);
 			V3 Is = mul(scale(lds_v3(lp + 6), shadow * si), m_spec);
 			total = add(total, Is);
 		}
@@ -471,7 +588,7 @@ __device__ __forceinline__ Pixel shade_pixel(const Launch& L, Sdf& sdf, const u3
 
 	/* gamma + colorf_to_pixfmt, naive_renderer.c:231-232, renderer.h:17-22 */
 	const float g = 1.f / 2.2f;
-	c = { powf(c.x, g), powf(c.y, g), powf(c.z, g) };
+	c = { powf_glibc(c.x, g), powf_glibc(c.y, g), powf_glibc(c.z, g) };
 	u32 px = ((u32)(c.x * 255.f) & 0xFFu) << 16 | ((u32)(c.y * 255.f) & 0xFFu) << 8 | ((u32)(c.z * 255.f) & 0xFFu);
 	return { px, c, hit, shadow_steps };
 }

@@ -83,6 +83,8 @@ def gpu_lib() -> C.CDLL:
         lib.lol_gpu_compile_offline.restype = C.c_int
         lib.lol_gpu_verify_fast_paths.argtypes = [vp, C.c_float, P(C.c_ulonglong), P(C.c_ulonglong)]
         lib.lol_gpu_verify_fast_paths.restype = C.c_int
+        lib.lol_gpu_powf_batch.argtypes = [vp, vp, vp, vp, C.c_size_t, vp]
+        lib.lol_gpu_powf_batch.restype = C.c_int
         lib.lol_gpu_set_miss_skip.argtypes = [vp, C.c_int]
         lib.lol_gpu_set_miss_skip.restype = C.c_int
         lib.lol_gpu_miss_skip_active.argtypes = [vp]
@@ -96,7 +98,7 @@ EXPORTED_SYMBOLS = [
     "lol_gpu_part_rows", "lol_gpu_render_device", "lol_gpu_render_host", "lol_gpu_sync", "lol_gpu_malloc",
     "lol_gpu_free", "lol_gpu_memcpy_d2h", "lol_gpu_kernel_name", "lol_gpu_set_specialize",
     "lol_gpu_specialize_log", "lol_gpu_compile_offline", "lol_gpu_verify_fast_paths", "lol_gpu_set_miss_skip",
-    "lol_gpu_miss_skip_active",
+    "lol_gpu_miss_skip_active", "lol_gpu_powf_batch",
 ]
 
 
@@ -170,6 +172,11 @@ class Renderer:
         sq, dv = (C.c_ulonglong * 3)(), C.c_ulonglong()
         self._check(self._lib.lol_gpu_verify_fast_paths(self._ctx, k, sq, C.byref(dv)))
         return list(sq), dv.value
+
+    def powf_batch(self, x_ptr: int, y_ptr: int, out_ptr: int, n: int, stream: int | None = None):
+        """out[i] = the kernel's powf(x[i], y[i]) on device arrays (diagnostic for tests)."""
+        self._check(self._lib.lol_gpu_powf_batch(self._ctx, C.c_void_p(x_ptr), C.c_void_p(y_ptr), C.c_void_p(out_ptr), n,
+                                                 C.c_void_p(stream) if stream else None))
 
     def set_miss_skip(self, enable: bool):
         self._check(self._lib.lol_gpu_set_miss_skip(self._ctx, 1 if enable else 0))

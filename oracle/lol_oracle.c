@@ -421,6 +421,11 @@ float lol_oracle_sd_round_box(const float p[3], const float b[3], float r) {
 	return sdRoundBox((v3){ p[0], p[1], p[2] }, (v3){ b[0], b[1], b[2] }, r);
 }
 
+/* libm's powf on arrays: the reference for the device's powf restatement (tests/test_gpu_powf.py) */
+void lol_oracle_powf_batch(const float* x, const float* y, float* out, size_t n) {
+	for (size_t i = 0; i < n; i++) out[i] = powf(x[i], y[i]);
+}
+
 uint64_t lol_oracle_hash_xrgb(const void* xrgb, int w, int h, size_t pitch) {
 	uint64_t hsh = 0xcbf29ce484222325ull;
 	for (int y = 0; y < h; y++) {

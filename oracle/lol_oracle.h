@@ -104,6 +104,9 @@ void  lol_oracle_v3clamp(const float a[3], float lo, float hi, float out[3]);
 float lol_oracle_sd_sphere(const float p[3], float r);
 float lol_oracle_sd_round_box(const float p[3], const float b[3], float r);
 
+/* out[i] = powf(x[i], y[i]) with the host libm (what naive_renderer.c calls at :158 and :231 via vec.h:66-67) */
+void lol_oracle_powf_batch(const float* x, const float* y, float* out, size_t n);
+
 /* FNV-1a-style hash over 32-bit pixels, row-major, skipping row padding
  * (the survey's known-answer hash). */
 uint64_t lol_oracle_hash_xrgb(const void* xrgb, int w, int h, size_t pitch_bytes);

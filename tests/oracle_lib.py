@@ -48,6 +48,8 @@ def lib() -> C.CDLL:
         l.lol_oracle_probe_pixel.restype = None
         l.lol_oracle_sdf.argtypes = [sp, C.c_float, C.c_float, C.c_float, P(C.c_uint32)]
         l.lol_oracle_sdf.restype = C.c_float
+        l.lol_oracle_powf_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        l.lol_oracle_powf_batch.restype = None
         l.lol_oracle_hash_xrgb.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t]
         l.lol_oracle_hash_xrgb.restype = C.c_uint64
         f3 = P(C.c_float)
@@ -101,6 +103,15 @@ def probe(scene: S.Scene, w: int, h: int, x: int, y: int, max_steps: int = 256, 
     p = Probe()
     lib().lol_oracle_probe_pixel(scene.ptr, C.byref(cam), w, h, max_steps, x, y, C.byref(p))
     return p
+
+
+def powf(x: np.ndarray, y: np.ndarray) -> np.ndarray:
+    """Host libm powf, elementwise on float32 arrays."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    out = np.empty_like(x)
+    lib().lol_oracle_powf_batch(x.ctypes.data, y.ctypes.data, out.ctypes.data, x.size)
+    return out
 
 
 def hash_xrgb(xrgb: np.ndarray) -> int:

@@ -18,6 +18,17 @@ pytestmark = pytest.mark.gpu
 RGB_TOL = 1e-4      # north_star tolerance on post-gamma float colour
 
 
+def _host_has_fma():
+    try:
+        return " fma " in open("/proc/cpuinfo").read()
+    except OSError:
+        return False
+
+
+# glibc picks its FMA build of powf on x86-64 CPUs with FMA; that is the variant the device code restates
+HOST_LIBM_IS_FMA_VARIANT = _host_has_fma()
+
+
 @pytest.fixture(scope="module")
 def torch_cuda():
     import torch
@@ -82,6 +93,10 @@ def check_against_oracle(g, sc, w, h, max_steps=256, y0=0, y1=None, camera=None)
     assert not np.isnan(g["rgb"]).any()
     cd = np.abs(channels(gx) - channels(ox))
     assert cd.max() <= 1, f"XRGB channel delta {cd.max()}"
+    if HOST_LIBM_IS_FMA_VARIANT:
+        # the kernel's powf restates the libm algorithm this host runs (tests/test_gpu_powf.py): colours are bit-identical
+        assert np.array_equal(g["rgb"].view(np.uint32), orgb.view(np.uint32)), "float colours are not bit-identical"
+        assert np.array_equal(gx, ox), "packed pixels are not identical"
     return int((gx != ox).sum())
 
 
@@ -163,6 +178,8 @@ def test_render_host_surface(torch_cuda, renderer, scenes):
     renderer.render_host(surf.ctypes.data, w, h, 256, pitch_bytes=pitch)
     ox, _, _ = O.render_rows(sc, w, h, 0, h)
     assert np.abs(channels(surf[:, :w]) - channels(ox)).max() <= 1
+    if HOST_LIBM_IS_FMA_VARIANT:
+        assert np.array_equal(surf[:, :w], ox[:h])
     assert (surf[:, w:] == 0xDEADBEEF).all()
 
 
