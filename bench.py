@@ -204,7 +204,14 @@ def main():
 
     # N>1: two frames in flight per rank — frame i's gather overlaps frame i+1's kernel (multi.GatherPipeline).
     depth = max(1, int(os.environ.get("LOL_BENCH_PIPELINE_DEPTH", "2")))     # 1 = gather each frame before the next renders
-    pipe = multi.GatherPipeline(w, h, band if not orbit else h, dev, depth=depth) if (world > 1 and not orbit) else None
+    # LOL_BENCH_FORCE_PIPE=1 under a 1-rank torchrun: exercise the real backend's gather path on one device
+    force_pipe = os.environ.get("LOL_BENCH_FORCE_PIPE") == "1" and not orbit
+    if force_pipe and world == 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    pipe = (multi.GatherPipeline(w, h, band if not orbit else h, dev, depth=depth, force_collective=force_pipe)
+            if ((world > 1 or force_pipe) and not orbit) else None)
     local = torch.zeros((n_local, w), dtype=torch.int32, device=dev) if pipe is None else None
 
     kernel_ms = []
@@ -248,6 +255,8 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if force_pipe and world == 1 and rank == 0:
+        print("[force-pipe] 1-rank nccl gather path completed", file=sys.stderr, flush=True)
     if os.environ.get("LOL_BENCH_CHECK") == "1" and pipe is not None:
         # correctness rehearsal: the assembled frame on rank 0 must equal a single-launch render of the frame
         final = pipe.drain()
@@ -303,7 +312,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     r.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

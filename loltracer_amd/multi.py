@@ -93,19 +93,21 @@ class GatherPipeline:
     """
 
     def __init__(self, w: int, h: int, band_rows: int, device, group=None, dst: int = 0, depth: int = 2,
-                 dtype=torch.int32):
+                 dtype=torch.int32, force_collective: bool = False):
         self.group, self.dst, self.h, self.w, self.band = group, dst, h, w, band_rows
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # force_collective: run the gather even in a 1-rank group (exercises the backend's gather on one device)
+        self.single = self.world == 1 and not (force_collective and dist.is_initialized())
         if self.world > 1 and h % (band_rows * self.world) != 0:
             raise ValueError(f"h={h} must be a multiple of band_rows*world={band_rows * self.world}")
         self.rows = part_rows(h, band_rows, self.world, self.rank) if self.world > 1 else h
-        self.depth = depth if self.world > 1 else 1
+        self.depth = depth if not self.single else 1
         self.local = [torch.zeros((self.rows, w), dtype=dtype, device=device) for _ in range(self.depth)]
         self.is_dst = self.rank == dst
         self.staging = ([torch.empty((self.world, self.rows, w), dtype=dtype, device=device) for _ in range(self.depth)]
-                        if self.world > 1 and self.is_dst else None)
-        self.frame = torch.empty((h, w), dtype=dtype, device=device) if self.world > 1 and self.is_dst else None
+                        if not self.single and self.is_dst else None)
+        self.frame = torch.empty((h, w), dtype=dtype, device=device) if not self.single and self.is_dst else None
         self.work = [None] * self.depth
         self.n = 0
         self.frames_done = 0
@@ -124,7 +126,7 @@ class GatherPipeline:
         """render(local_part_tensor): enqueue the rendering of this rank's part into the tensor."""
         slot = self.n % self.depth
         self.n += 1
-        if self.world == 1:
+        if self.single:
             render(self.local[0])
             self.frame = self.local[0]
             self.frames_done += 1
@@ -139,7 +141,7 @@ class GatherPipeline:
 
     def drain(self):
         """Finish every frame in flight, oldest first; returns the last assembled frame on dst (None elsewhere)."""
-        if self.world > 1:
+        if not self.single:
             for k in range(self.depth):
                 self._finish((self.n + k) % self.depth)
         return self.frame if self.is_dst else None
