@@ -20,9 +20,15 @@ import torch
 import torch.distributed as dist
 
 
-def choose_band_rows(h: int, world: int, preferred: int = 8) -> int:
-    """Largest band <= preferred with h % (band * world) == 0, so all parts are equal; 0 if none."""
-    for band in range(min(preferred, max(h // world, 1)), 0, -1):
+def choose_band_rows(h: int, world: int, preferred: int = 16, patch_rows: int = 4) -> int:
+    """Band height with h % (band * world) == 0 (equal parts): the largest multiple of the kernel's patch
+    height (16x4 pixels per wave) up to `preferred`, so that no wave straddles two bands — frame rows that are
+    `world` bands apart; failing that the largest divisor <= 8; 0 if none."""
+    limit = max(h // world, 1)
+    for band in range(min(preferred, limit) // patch_rows * patch_rows, 0, -patch_rows):
+        if h % (band * world) == 0:
+            return band
+    for band in range(min(8, limit), 0, -1):
         if h % (band * world) == 0:
             return band
     return 0

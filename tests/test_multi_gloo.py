@@ -111,8 +111,10 @@ def test_gather_pipeline_keeps_frames_in_order(world, h, band):
 
 
 def test_partition_helpers():
-    assert multi.choose_band_rows(4320, 8) == 6 and multi.choose_band_rows(4320, 2) == 8
-    assert multi.choose_band_rows(2160, 4) == 6 and multi.choose_band_rows(7, 2) == 0
+    # multiples of the 4-row wave patch are preferred, so no wave straddles two bands
+    assert multi.choose_band_rows(4320, 8) == 12 and multi.choose_band_rows(4320, 2) == 16
+    assert multi.choose_band_rows(4320, 4) == 12 and multi.choose_band_rows(2160, 4) == 12
+    assert multi.choose_band_rows(30, 3) == 5 and multi.choose_band_rows(7, 2) == 0
     h, band, world = 48, 4, 3
     seen = torch.cat([multi.frame_rows_of_part(h, band, world, r) for r in range(world)])
     assert sorted(seen.tolist()) == list(range(h))
