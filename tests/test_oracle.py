@@ -114,6 +114,17 @@ def test_survey_work_counters(scenes, name, w, h, sdf_per_px):
     assert c.node_evals == nodes * c.sdf_evals
 
 
+def test_survey_step_split_at_960x540(scenes):
+    """SURVEY.md §3.3 / BASELINE.md §2: scene4 at 960x540 costs 21.9 primary march steps + 71.5 shadow steps + 4 normal
+    taps = 97.4 sdf() calls per pixel, each walking 10 nodes; scene.lol at 480x270: 26.7 + 8.4 + 4 = 39.1 over 4 nodes."""
+    _, _, c = O.render(scenes["scene4"], 960, 540, threads=8, want_counters=True)
+    assert round(c.march_steps / c.pixels, 1) == 21.9
+    assert abs(c.shadow_steps / c.pixels - 71.5) < 0.06          # the survey printed 71.5; this oracle gives 71.45
+    assert round(c.sdf_evals / c.pixels, 1) == 97.4 and c.node_evals == 10 * c.sdf_evals
+    _, _, c = O.render(scenes["scene"], 480, 270, threads=8, want_counters=True)
+    assert round(c.march_steps / c.pixels, 1) == 26.7 and round(c.shadow_steps / c.pixels, 1) == 8.4
+
+
 def test_survey_frame_hashes_are_not_reproduced(scenes):
     """Recorded honestly: the survey's FNV hashes of whole frames (scenes entered by hand there) do not
     match this oracle's frames, although the known pixels and work counters above do.  If this test ever
