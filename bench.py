@@ -284,7 +284,7 @@ def main():
         out = {
             "metric": "Mpixels/s at 3840x2160, <=256 march steps; max |pixel delta| vs naive_renderer.c",
             "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": steps_reported,
-            "warmup": args.warmup, "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": round(dt / steps_reported * 1e3, 4), "higher_is_better": True,
             "scaling": "weak" if orbit else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{name}: tests/golden/scenes/{cfg['scene']}.lol {w}x{h}, {max_steps} march steps"
                                    + (f", {cfg['frames']}-frame orbit striped over ranks" if orbit else
