@@ -75,3 +75,16 @@ def test_dump_kernel_flag_is_the_jitdump_counterpart(tmp_path):
     src = open(str(base) + ".hip").read()
     assert "lol_render_spec" in src and src.count("sd_sphere(") == 5
     assert os.path.getsize(str(base) + ".co") > 1000
+
+
+@pytest.mark.gpu
+def test_python_cli_renders_the_same_frame(tmp_path, scenes):
+    import sys
+    out = tmp_path / "p.ppm"
+    p = subprocess.run([sys.executable, "-m", "loltracer_amd", SCENE4, "--size", "120x68", "-o", str(out)],
+                       capture_output=True, text=True, timeout=180, cwd=ROOT)
+    assert p.returncode == 0, p.stderr
+    img = read_ppm(out).astype(np.int32)
+    ox, _, _ = O.render(scenes["scene4"], 120, 68, threads=4)
+    want = np.stack([(ox >> 16) & 0xFF, (ox >> 8) & 0xFF, ox & 0xFF], axis=-1).astype(np.int32)
+    assert np.abs(img - want).max() <= 1
