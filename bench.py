@@ -134,6 +134,58 @@ def cpu_baseline(sc: S.Scene, cfg: dict, target_s: float = 15.0, gpu_frame=None)
     return base, ctr
 
 
+def both_kernels(r, sc, spec_frame, w, h, max_steps, fc, stream, spec_ms, px, frames: int = 5):
+    """After the timed region: the same frame on the OTHER kernel of the library — the ahead-of-time LDS
+    op-list interpreter `render_interp` (the literal north-star kernel; what runs when hipRTC is unavailable) —
+    timed with HIP events, and compared with the frame the default kernel just rendered."""
+    out = {r.kernel_name(): {"mpixels_per_s": round(px / (spec_ms * 1e-3) / 1e6, 1), "kernel_ms_avg": round(spec_ms, 4)}}
+    ri = gpu.Renderer(torch.cuda.current_device(), specialize=4 if r.kernel_name() == "lol_render_spec" else 1)
+    try:
+        ri.prepare(sc)
+        buf = torch.zeros_like(spec_frame)
+        ri.render_into(buf.data_ptr(), w, h, max_steps, stream=stream, frame_camera=fc)      # warm-up
+        ev = []
+        for _ in range(frames):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ri.render_into(buf.data_ptr(), w, h, max_steps, stream=stream, frame_camera=fc)
+            e1.record()
+            ev.append((e0, e1))
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+        out[ri.kernel_name()] = {"mpixels_per_s": round(px / (ms * 1e-3) / 1e6, 1), "kernel_ms_avg": round(ms, 4),
+                                 "frames": frames, "frame_equal_to_spec": bool(torch.equal(buf, spec_frame))}
+    finally:
+        ri.close()
+    return out
+
+
+def launcher_command(n: int, argv: list, port: int) -> list:
+    """The command `python bench.py --gpus N` runs for N > 1: one rank per GPU under torch.distributed.run
+    (the same form the driver uses), rendezvous on 127.0.0.1."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(n: int, argv: list) -> int:
+    """Start the N ranks as a child process group and wait for them; returns their exit status.
+    Called before this process has made any HIP call (importing torch does not initialise the GPU)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL needs it on this pool
+    proc = subprocess.Popen(launcher_command(n, argv, port), env=env)   # stdout / stderr inherited: rank 0's JSON line
+    try:
+        return proc.wait()
+    except KeyboardInterrupt:
+        proc.terminate()
+        return proc.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,16 +196,21 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N`: this process becomes the launcher.  It starts the N ranks as CHILD
+        # processes (never an exec) before anything here has touched the GPU, relays their output and
+        # exits with their status.
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-        args.gpus = world
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start the ranks with "
+                         f"`python bench.py --gpus {args.gpus}` or torch.distributed.run --nproc-per-node {args.gpus}")
 
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device: there is no CPU rendering path")
+        raise SystemExit(f"bench.py needs a HIP device: there is no CPU rendering path (rank {rank} of {world})")
     # Rehearsal switch for a 1-GPU box: LOL_BENCH_REHEARSE=1 puts every rank on device 0 and uses gloo, so
     # the N>1 code path (partition, pipelined gather, assembly, timing) can be exercised without N GPUs.
     rehearse = os.environ.get("LOL_BENCH_REHEARSE") == "1"
@@ -268,6 +325,19 @@ def main():
             print(f"[check] assembled {world}-rank frame == single-launch frame: {same}", file=sys.stderr, flush=True)
             assert same
 
+    # the exchange step on its own (outside the timed region): barrier, gather this rank's last part to rank 0,
+    # un-interleave there, wait — best of 3.  In the timed loop it overlaps the next frame's kernel.
+    gather_ms = None
+    if pipe is not None and not pipe.single:
+        ts = []
+        for _ in range(3):
+            fence()
+            t0 = time.perf_counter()
+            pipe.regather()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        gather_ms = round(min(ts) * 1e3, 4)
+
     k_ms = [a.elapsed_time(b) for a, b in kernel_ms]
     k_avg = sum(k_ms) / max(len(k_ms), 1)
     px_per_launch = n_local * w
@@ -292,14 +362,23 @@ def main():
                                        if world > 1 else ", one kernel launch per frame")),
                        "width": w, "height": h, "max_steps": max_steps, "band_rows": band,
                        "kernel": r.kernel_name()},
+            # what the process group really is: ranks seen by torch.distributed and its backend ("nccl" = RCCL)
+            "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
+            "backend": dist.get_backend() if dist.is_initialized() else None,
+            "gather_ms": gather_ms,
+            "parity_checker": "oracle/lol_oracle.c — the CPU restatement of naive_renderer.c (DESIGN.md §5)",
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 6),
                          "traffic": pmc_traffic(r.kernel_name(), name, px_per_launch),
+                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command, "
+                                           "tools/pmc_summary.py; not re-measured in this run)",
                          "algorithmic_bytes": px_per_launch * BYTES_PER_PIXEL,
                          "kernel_ms_avg": round(k_avg, 4), "pixels_per_launch": px_per_launch,
                          "bytes_per_pixel": BYTES_PER_PIXEL,
                          "note": "north_star names the HBM-write roofline; the path is FP32-VALU-bound, see `valu`"},
         }
+        if world == 1 and not orbit:
+            out["kernels"] = both_kernels(r, sc, local, w, h, max_steps, cams[0], stream, k_avg, px_per_launch)
         if world == 1 and not args.no_cpu_baseline and not orbit:
             base, ctr = cpu_baseline(sc, cfg, gpu_frame=local.cpu().numpy().view(np.uint32))
             out["cpu_baseline"] = base

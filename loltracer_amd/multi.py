@@ -145,6 +145,19 @@ class GatherPipeline:
         else:
             self.work[slot] = dist.gather(self.local[slot], None, dst=self.dst, group=self.group, async_op=True)
 
+    def regather(self, slot: int = 0):
+        """Gather + assemble the part already sitting in local[slot] again, synchronously (for timing the
+        exchange step on its own).  Every rank must call it."""
+        if self.single:
+            return
+        self._finish(slot)
+        if self.is_dst:
+            self.work[slot] = dist.gather(self.local[slot], [self.staging[slot][i] for i in range(self.world)],
+                                          dst=self.dst, group=self.group, async_op=True)
+        else:
+            self.work[slot] = dist.gather(self.local[slot], None, dst=self.dst, group=self.group, async_op=True)
+        self._finish(slot)
+
     def drain(self):
         """Finish every frame in flight, oldest first; returns the last assembled frame on dst (None elsewhere)."""
         if not self.single:

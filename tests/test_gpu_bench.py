@@ -1,0 +1,50 @@
+"""bench.py end to end on the GPU box, in the driver's command form.
+
+`python bench.py --gpus 2` must start two ranks by itself and print ONE JSON line.  A 1-GPU box has one
+device, so the ranks share it and talk gloo (LOL_BENCH_REHEARSE=1) — the partition, the pipelined gather,
+the assembly and the timing protocol are the real ones; only the transport differs from the 8-GPU run.
+LOL_BENCH_CHECK=1 makes rank 0 compare the assembled frame with a single-launch render.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _bench(args, **env):
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    e.update(env)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=420)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0]), p.stderr
+
+
+def test_gpus_2_self_launches_and_assembles_the_frame():
+    out, err = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1"], LOL_BENCH_REHEARSE="1", LOL_BENCH_CHECK="1")
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["backend"] == "gloo"
+    assert out["config"]["width"] == 7680 and out["config"]["height"] == 4320
+    assert "[check] assembled 2-rank frame == single-launch frame: True" in err
+    assert out["gather_ms"] is not None and out["gather_ms"] > 0
+    assert out["value"] > 0 and out["scaling"] == "strong"
+
+
+def test_default_line_carries_roofline_cpu_baseline_and_both_kernels():
+    out, _ = _bench(["--steps", "5", "--warmup", "2"])
+    assert out["n_gpus"] == 1 and out["unit"] == "Mpixels/s" and out["dtype"] == "f32"
+    assert out["config"]["workload"].startswith("c3:")
+    rf = out["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    assert cb["parity_vs_gpu"]["pixels_differing"] == 0
+    ks = out["kernels"]
+    assert ks["lol_render_spec"]["mpixels_per_s"] > 0 and ks["render_interp"]["mpixels_per_s"] > 0
+    assert ks["render_interp"]["frame_equal_to_spec"] is True
