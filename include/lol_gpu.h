@@ -71,9 +71,15 @@ int  lol_gpu_device_count(void);
 int  lol_gpu_create(int device, lol_gpu** out);
 void lol_gpu_destroy(lol_gpu* ctx);
 const char* lol_gpu_error(const lol_gpu* ctx);
+int  lol_gpu_device(const lol_gpu* ctx);          /* the HIP device ordinal of a context */
+
+/* Stream arguments: NULL = the context's own (non-blocking) stream; LOL_GPU_STREAM_DEFAULT = HIP's legacy
+ * default stream (hipStreamLegacy, the stream a handle of 0 means to HIP itself); else a hipStream_t. */
+#define LOL_GPU_STREAM_DEFAULT ((void*)1)
 
 /* Copy the flattened scene (lol_scene_flatten) to the device.  May be called
- * again at any time; frames issued afterwards use the new program. */
+ * again at any time (it first waits for everything queued on the device);
+ * frames issued afterwards use the new program. */
 int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog);
 
 /* Number of local rows a part owns (for sizing destinations). */
@@ -86,7 +92,7 @@ int lol_gpu_part_rows(int h, const lol_gpu_rows* rows);
  *   rows      partition (NULL = whole frame)
  *   dst       DEVICE pointer, XRGB8888 (r<<16|g<<8|b), `pitch_bytes` per local row
  *   dbg       optional diagnostics (NULL in production)
- *   stream    hipStream_t to launch on, as void*; NULL = the context's own stream
+ *   stream    hipStream_t to launch on, as void*; NULL = the context's own stream (see LOL_GPU_STREAM_DEFAULT)
  */
 int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h, int max_steps,
                           const lol_gpu_rows* rows, void* dst, size_t pitch_bytes,
@@ -158,6 +164,63 @@ int         lol_gpu_powf_batch(lol_gpu* ctx, const float* x_dev, const float* y_
  * assume_fast != 0 generates the shortcuts without proof — for ISA inspection only, never for rendering. */
 int         lol_gpu_compile_offline(const lol_program* prog, const char* arch, const char* out_base,
                                     int assume_fast, char* log, size_t logcap);
+
+/* ------------------------------------------------------------------------------------------------
+ * Several devices behind the same boundary (BASELINE.json north_star: "the image is
+ * row-tile-partitioned across the 8 GPUs of one node with an RCCL gather over xGMI").
+ *
+ * One process, one renderer context + two HIP streams per device, one RCCL communicator per device
+ * (ncclCommInitAll).  A frame's rows are cut into bands dealt round-robin over the devices — the static
+ * form of the reference's row self-scheduling (naive_renderer.c:216: workers claim rows from an atomic
+ * counter; every row is independent).  Device r renders part r compactly on its render stream; on its
+ * exchange stream every device ncclSend()s its part to device 0 (devices[0], the root), which
+ * ncclRecv()s them (one grouped call, parts may differ in size) and un-interleaves the bands into the
+ * destination — the frame barrier of main.c:189-194 becomes the completion of that exchange.  Parts are
+ * double-buffered, so frame i's exchange overlaps frame i+1's kernels.  RCCL is loaded (dlopen) by
+ * lol_gpu_multi_create only, single-device users never touch it.  No CPU fallback and no other
+ * transport: without RCCL, or with a device listed twice, creation fails.
+ */
+typedef struct lol_gpu_multi lol_gpu_multi;
+
+#define LOL_GPU_MULTI_MAX_DEVICES 16
+
+int  lol_gpu_multi_create(const int* devices, int n_devices, lol_gpu_multi** out);
+void lol_gpu_multi_destroy(lol_gpu_multi* m);
+const char* lol_gpu_multi_error(const lol_gpu_multi* m);
+int  lol_gpu_multi_device_count(const lol_gpu_multi* m);
+/* the single-device context of device index i (to set its switches before the upload, read its logs) */
+lol_gpu* lol_gpu_multi_context(lol_gpu_multi* m, int i);
+/* render_prepare: the flattened scene goes to every device (14 KB each; the specialised kernel is compiled once) */
+int  lol_gpu_multi_upload_program(lol_gpu_multi* m, const lol_program* prog);
+/* Band height used for frames of height h over n devices: the largest multiple of the 4-row wave patch <= 16
+ * that still gives every device at least four bands, else 4.  lol_gpu_multi_set_band_rows(m, b > 0) overrides. */
+int  lol_gpu_choose_band_rows(int h, int n_devices);
+int  lol_gpu_multi_set_band_rows(lol_gpu_multi* m, int band_rows);
+/* Frame row shown by local row `local_row` of a part (the inverse of the kernel's mapping); -1 if out of range. */
+int  lol_gpu_part_frame_row(int h, const lol_gpu_rows* rows, int local_row);
+/*
+ * One frame over all devices, asynchronously: on return the work is queued; the assembled XRGB8888 frame
+ * is in `dst` (memory of the root device, `pitch_bytes` per row) once lol_gpu_multi_sync() returns.
+ * Up to two frames may be in flight (double-buffered parts); give them different destinations.
+ */
+int  lol_gpu_multi_render_device(lol_gpu_multi* m, const lol_frame_camera* cam, int w, int h, int max_steps,
+                                 void* dst, size_t pitch_bytes);
+/* What render_thread does with surf->pixels: one frame over all devices into a HOST surface; waits. */
+int  lol_gpu_multi_render_host(lol_gpu_multi* m, const lol_frame_camera* cam, int w, int h, int max_steps,
+                               void* host_pixels, size_t pitch_bytes);
+int  lol_gpu_multi_sync(lol_gpu_multi* m);
+/* Memory on the root device (for destinations of lol_gpu_multi_render_device). */
+int  lol_gpu_multi_malloc(lol_gpu_multi* m, size_t bytes, void** out);
+int  lol_gpu_multi_free(lol_gpu_multi* m, void* ptr);
+int  lol_gpu_multi_memcpy_d2h(lol_gpu_multi* m, void* host, const void* dev, size_t bytes);
+/*
+ * The root's assembly step on its own: `parts` holds n_parts compact parts back to back (part r starts at
+ * row sum of lol_gpu_part_rows of the parts before it, w pixels per row); un-interleave them into `dst`.
+ * Asynchronous on `stream` (NULL = the context's stream).  Exposed so the band logic can be checked on a
+ * single device against a whole-frame render.
+ */
+int  lol_gpu_assemble_parts(lol_gpu* ctx, const void* parts, int n_parts, int band_rows, int w, int h,
+                            void* dst, size_t pitch_bytes, void* stream);
 
 #ifdef __cplusplus
 }

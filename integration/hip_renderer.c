@@ -8,7 +8,10 @@
  *   render_prepare  once, main thread, workers already parked on the entry
  *                   semaphore (main.c:147-161): create the GPU context,
  *                   flatten the scene, upload it.  Renderer flags start at
- *                   argv[3] (main.c:223-242): --device N, --max-steps N, and
+ *                   argv[3] (main.c:223-242): --device N (one GPU),
+ *                   --devices A,B,... (the frame's rows are dealt in bands over
+ *                   these GPUs and the parts gathered with RCCL on the first one,
+ *                   include/lol_gpu.h lol_gpu_multi_*), --max-steps N, and
  *                   --dump-kernel BASE, the counterpart of the JIT renderer's
  *                   -j/--jitdump (tracing_jit_renderer.dasc:424-433): writes the
  *                   scene-specialised kernel as BASE.hip (generated source) and
@@ -36,8 +39,9 @@
 #include "lol_scene.h"
 
 struct hip_renderer {
-	lol_gpu*    gpu;
-	lol_program program;
+	lol_gpu*       gpu;        /* --device N */
+	lol_gpu_multi* multi;      /* --devices A,B,...: used instead of `gpu` */
+	lol_program    program;
 	int         max_steps;      /* MAX_STEPS, naive_renderer.c:49 */
 	int         ready;
 };
@@ -45,14 +49,32 @@ struct hip_renderer {
 void render_prepare(struct render_data* data, int argc, const char* argv[]) {
 	struct hip_renderer* r = calloc(1, sizeof *r);
 	int device = 0;
+	int devices[LOL_GPU_MULTI_MAX_DEVICES], n_devices = 0;
 	const char* dump = NULL;
 	HOST_PRIVATE(data) = r;
 	if (!r) { fprintf(stderr, "hip_renderer: out of memory\n"); return; }
 	r->max_steps = 256;
-	for (int i = 3; i + 1 < argc; i++) {
-		if (!strcmp(argv[i], "--device")) device = atoi(argv[++i]);
-		else if (!strcmp(argv[i], "--max-steps")) r->max_steps = atoi(argv[++i]);
-		else if (!strcmp(argv[i], "--dump-kernel")) dump = argv[++i];
+	for (int i = 3; i < argc; i++) {
+		const int is_device = !strcmp(argv[i], "--device"), is_devices = !strcmp(argv[i], "--devices");
+		const int is_steps = !strcmp(argv[i], "--max-steps"), is_dump = !strcmp(argv[i], "--dump-kernel");
+		if (!(is_device || is_devices || is_steps || is_dump)) continue;      /* the host's own flags */
+		if (i + 1 >= argc) { fprintf(stderr, "hip_renderer: %s needs a value, ignored\n", argv[i]); break; }
+		const char* v = argv[++i];
+		if (is_device) device = atoi(v);
+		else if (is_steps) r->max_steps = atoi(v);
+		else if (is_dump) dump = v;
+		else {
+			n_devices = 0;
+			for (const char* p = v; *p && n_devices < LOL_GPU_MULTI_MAX_DEVICES;) {
+				char* end;
+				long d = strtol(p, &end, 10);
+				if (end == p) break;
+				devices[n_devices++] = (int)d;
+				p = *end == ',' ? end + 1 : end;
+				if (*end != ',' ) break;
+			}
+			if (n_devices == 0) fprintf(stderr, "hip_renderer: --devices wants a list like 0,1,2,3\n");
+		}
 	}
 
 	const lol_scene* scene = HOST_SCENE_TO_LOL(data->scene);
@@ -68,10 +90,17 @@ void render_prepare(struct render_data* data, int argc, const char* argv[]) {
 			fprintf(stderr, "hip_renderer: --dump-kernel failed: %s\n", log);
 	}
 
-	st = lol_gpu_create(device, &r->gpu);
-	if (st != LOL_GPU_OK) { fprintf(stderr, "hip_renderer: no usable HIP device %d (status %d)\n", device, st); return; }
-	st = lol_gpu_upload_program(r->gpu, &r->program);
-	if (st != LOL_GPU_OK) { fprintf(stderr, "hip_renderer: %s\n", lol_gpu_error(r->gpu)); return; }
+	if (n_devices > 0) {
+		st = lol_gpu_multi_create(devices, n_devices, &r->multi);
+		if (st != LOL_GPU_OK) { fprintf(stderr, "hip_renderer: cannot set up %d device(s) (status %d)\n", n_devices, st); return; }
+		st = lol_gpu_multi_upload_program(r->multi, &r->program);
+		if (st != LOL_GPU_OK) { fprintf(stderr, "hip_renderer: %s\n", lol_gpu_multi_error(r->multi)); return; }
+	} else {
+		st = lol_gpu_create(device, &r->gpu);
+		if (st != LOL_GPU_OK) { fprintf(stderr, "hip_renderer: no usable HIP device %d (status %d)\n", device, st); return; }
+		st = lol_gpu_upload_program(r->gpu, &r->program);
+		if (st != LOL_GPU_OK) { fprintf(stderr, "hip_renderer: %s\n", lol_gpu_error(r->gpu)); return; }
+	}
 	r->ready = 1;
 }
 
@@ -98,10 +127,11 @@ int render_thread(void* ptr) {
 				lol_frame_camera fc;
 				HOST_SCENE_CAMERA(data->scene, &cam);   /* the host moves the camera between frames (main.c:180) */
 				lol_frame_camera_init(&fc, &cam, width, height);
-				int st = lol_gpu_render_host(r->gpu, &fc, width, height, r->max_steps,
-				                             surf->pixels, (size_t)surf->pitch);
+				int st = r->multi
+					? lol_gpu_multi_render_host(r->multi, &fc, width, height, r->max_steps, surf->pixels, (size_t)surf->pitch)
+					: lol_gpu_render_host(r->gpu, &fc, width, height, r->max_steps, surf->pixels, (size_t)surf->pitch);
 				if (st != LOL_GPU_OK)
-					fprintf(stderr, "hip_renderer: %s\n", lol_gpu_error(r->gpu));
+					fprintf(stderr, "hip_renderer: %s\n", r->multi ? lol_gpu_multi_error(r->multi) : lol_gpu_error(r->gpu));
 			}
 		}
 
@@ -112,6 +142,7 @@ int render_thread(void* ptr) {
 void render_destroy(struct render_data* data) {
 	struct hip_renderer* r = HOST_PRIVATE(data);
 	if (!r) return;
+	lol_gpu_multi_destroy(r->multi);
 	lol_gpu_destroy(r->gpu);
 	free(r);
 	HOST_PRIVATE(data) = NULL;

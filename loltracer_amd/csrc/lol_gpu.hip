@@ -298,10 +298,9 @@ std::string generate_source(const lol_program& P, const FastPaths* fast) {
 struct Roctx {
 	int  (*push)(const char*) = nullptr;
 	int  (*pop)() = nullptr;
-	bool tried = false;
-	void init() {
-		if (tried) return;
-		tried = true;
+	std::once_flag once;
+	void init() { std::call_once(once, [this] { resolve(); }); }      /* frames may be launched from several host threads */
+	void resolve() {
 		const char* e = getenv("LOL_GPU_ROCTX");
 		if (!e || e[0] != '1') return;
 		for (const char* name : { "librocprofiler-sdk-roctx.so", "libroctx64.so" }) {
@@ -514,6 +513,8 @@ void lol_gpu_destroy(lol_gpu* ctx) {
 
 const char* lol_gpu_error(const lol_gpu* ctx) { return ctx ? ctx->err : "null context"; }
 
+int lol_gpu_device(const lol_gpu* ctx) { return ctx ? ctx->device : -1; }
+
 int lol_gpu_set_specialize(lol_gpu* ctx, int enable) {
 	if (!ctx) return LOL_GPU_ERR_ARG;
 	/* 0 interpreter, plain | 1 specialised + proven fast paths (default) | 3 specialised, plain | 4 interpreter + fast paths */
@@ -526,8 +527,10 @@ int lol_gpu_set_miss_skip(lol_gpu* ctx, int enable) {
 	if (!ctx) return LOL_GPU_ERR_ARG;
 	ctx->want_miss_skip = enable ? 1 : 0;
 	if (ctx->have_prog) {
-		ctx->miss_skip = ctx->want_miss_skip && miss_skip_ok(ctx->h_prog);
-		ctx->dark_skip = ctx->want_miss_skip && dark_skip_ok(ctx->h_prog);
+		const char* ms = getenv("LOL_GPU_MISS_SKIP");              /* the environment switch still wins */
+		const bool allowed = ctx->want_miss_skip && !(ms && ms[0] == '0');
+		ctx->miss_skip = allowed && miss_skip_ok(ctx->h_prog);
+		ctx->dark_skip = allowed && dark_skip_ok(ctx->h_prog);
 	}
 	return LOL_GPU_OK;
 }
@@ -577,8 +580,9 @@ int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog) {
 			return fail(ctx, LOL_GPU_ERR_ARG, "material index out of range");
 
 	LOL_HIP(ctx, hipSetDevice(ctx->device));
-	/* ordered after frames already queued on the context stream */
-	LOL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	/* frames already queued — on the context's stream or on a caller's — still read the old tables and code
+	 * object: drain the whole device before replacing them */
+	LOL_HIP(ctx, hipDeviceSynchronize());
 	ctx->h_prog = *prog;
 	ctx->have_prog = true;
 	/* The interpreter's copy: smooth unions whose blend factor is proven become OP_SMINF* with {k, 2k, .5/k};
@@ -633,9 +637,8 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	int n_rows = lol_gpu_part_rows(h, R);
 	if (n_rows < 0) return fail(ctx, LOL_GPU_ERR_ARG, "bad row partition");
 	if (n_rows == 0) return LOL_GPU_OK;
-	/* a partial last band is only laid out compactly when it is the part's last one */
-	if (R->n_parts > 1 && h % R->band_rows != 0)
-		return fail(ctx, LOL_GPU_ERR_ARG, "h must be a multiple of band_rows when n_parts > 1");
+	/* h need not be a multiple of band_rows: the one partial band is the frame's last, hence also the last of
+	 * the part that owns it, so every part's local rows stay dense (lol_gpu_part_frame_row is the mapping) */
 
 	lol::Launch L;
 	memset(&L, 0, sizeof L);
@@ -665,7 +668,7 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	const int block = tile_w * tile_h;
 	dim3 grid((w + tile_w - 1) / tile_w, (n_rows + tile_h - 1) / tile_h);
 	size_t common = (size_t)(lol::common_lds_dwords(P.n_lights, P.n_materials, P.n_roots) - lol::TILE_W * lol::TILE_H + block) * 4;
-	hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+	hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;      /* LOL_GPU_STREAM_DEFAULT == hipStreamLegacy */
 	LOL_HIP(ctx, hipSetDevice(ctx->device));
 	hipError_t e;
 	g_roctx.init();

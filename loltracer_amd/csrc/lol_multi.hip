@@ -1,0 +1,444 @@
+/*
+ * lol_multi.hip — several devices behind the renderer.h boundary (include/lol_gpu.h, "Several devices").
+ *
+ * The reference spreads a frame over workers by letting them claim rows from an atomic counter
+ * (naive_renderer.c:216) and joins them with the exit semaphore (main.c:189-194).  Across GPUs the same
+ * independence of rows is used statically: bands of rows dealt round-robin over the devices, each device
+ * renders its part compactly, and ONE grouped RCCL exchange (ncclSend on every device, ncclRecv on the
+ * root) brings the parts to the root, which un-interleaves them — the "row-tile partition + RCCL gather
+ * over xGMI" BASELINE.json names.  Single process, ncclCommInitAll, no host staging.
+ *
+ * Streams per device d:  render[d]  — the frame kernels (lol_gpu_render_device)
+ *                        xchg[d]    — ncclSend / ncclRecv, the un-interleave and the D2H copy on the root
+ * and two part buffers, so that while frame i's parts travel, frame i+1 renders:
+ *   render[d]: wait sent[slot] (frame i-2 has left the buffer) → kernel → record rendered[slot]
+ *   xchg[d]:   wait rendered[slot] → ncclSend(part[slot] → root) → record sent[slot]
+ *   xchg[0]:   … → ncclRecv(staging[slot] ← every d) → assemble_kernel(staging[slot] → dst) → record done[slot]
+ * RCCL itself is resolved with dlopen in lol_gpu_multi_create: librccl is a 570 MB library that a
+ * single-device host should not have to map.
+ */
+#include "lol_gpu.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+namespace {
+
+struct Rccl {
+	void* handle = nullptr;
+	ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+	ncclResult_t (*GroupStart)() = nullptr;
+	ncclResult_t (*GroupEnd)() = nullptr;
+	ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+	const char*  (*GetErrorString)(ncclResult_t) = nullptr;
+	bool load(char* err, size_t cap) {
+		for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
+			handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+			if (handle) break;
+		}
+		if (!handle) { snprintf(err, cap, "cannot load RCCL: %s", dlerror()); return false; }
+		auto sym = [&](const char* n) { return dlsym(handle, n); };
+		CommInitAll = reinterpret_cast<decltype(CommInitAll)>(sym("ncclCommInitAll"));
+		CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+		GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+		GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+		Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
+		Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
+		GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+		if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Send || !Recv || !GetErrorString) {
+			snprintf(err, cap, "RCCL library lacks a required entry point");
+			return false;
+		}
+		return true;
+	}
+};
+
+constexpr int SLOTS = 2;
+
+struct Device {
+	int          id = -1;
+	lol_gpu*     ctx = nullptr;
+	hipStream_t  render = nullptr, xchg = nullptr;
+	ncclComm_t   comm = nullptr;
+	uint32_t*    part[SLOTS] = { nullptr, nullptr };
+	size_t       part_bytes = 0;
+	hipEvent_t   rendered[SLOTS] = { nullptr, nullptr }, sent[SLOTS] = { nullptr, nullptr };
+};
+
+/* Offsets (in rows) of the parts inside the staging buffer, by value in the kernel arguments. */
+struct PartTable { uint32_t row0[LOL_GPU_MULTI_MAX_DEVICES]; };
+
+/* dst row y ← the row of the part that rendered it.  One thread per 4 pixels (uint4) when VEC, else per pixel. */
+template <bool VEC>
+__global__ __launch_bounds__(256) void assemble_kernel(const uint32_t* __restrict__ parts, PartTable tab, int n_parts,
+                                                        int band_rows, int w, int h, uint32_t* __restrict__ dst,
+                                                        uint32_t pitch_px) {
+	const int y = blockIdx.y;
+	const int band = y / band_rows, part = band % n_parts;
+	const int local = (band / n_parts) * band_rows + (y - band * band_rows);
+	const uint32_t* src = parts + ((size_t)tab.row0[part] + local) * w;
+	uint32_t* out = dst + (size_t)y * pitch_px;
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (VEC) {
+		if (i * 4 < w) reinterpret_cast<uint4*>(out)[i] = reinterpret_cast<const uint4*>(src)[i];
+	} else {
+		if (i < w) out[i] = src[i];
+	}
+}
+
+hipError_t launch_assemble(const void* parts, const PartTable& tab, int n_parts, int band_rows, int w, int h, void* dst,
+                           size_t pitch_bytes, hipStream_t s) {
+	const bool vec = w % 4 == 0 && pitch_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(parts) % 16) == 0 &&
+	                 (reinterpret_cast<uintptr_t>(dst) % 16) == 0;
+	const int per_row = vec ? w / 4 : w;
+	dim3 grid((per_row + 255) / 256, h);
+	if (vec) hipLaunchKernelGGL(assemble_kernel<true>, grid, dim3(256), 0, s, static_cast<const uint32_t*>(parts), tab, n_parts,
+	                            band_rows, w, h, static_cast<uint32_t*>(dst), (uint32_t)(pitch_bytes / 4));
+	else     hipLaunchKernelGGL(assemble_kernel<false>, grid, dim3(256), 0, s, static_cast<const uint32_t*>(parts), tab, n_parts,
+	                            band_rows, w, h, static_cast<uint32_t*>(dst), (uint32_t)(pitch_bytes / 4));
+	return hipGetLastError();
+}
+
+bool fill_table(PartTable& tab, int n_parts, int band_rows, int h) {
+	uint32_t row = 0;
+	for (int r = 0; r < n_parts; r++) {
+		lol_gpu_rows R = { band_rows, n_parts, r };
+		int n = lol_gpu_part_rows(h, &R);
+		if (n < 0) return false;
+		tab.row0[r] = row;
+		row += (uint32_t)n;
+	}
+	return row == (uint32_t)h;
+}
+
+}  // namespace
+
+struct lol_gpu_multi {
+	int       n = 0;
+	Device    dev[LOL_GPU_MULTI_MAX_DEVICES];
+	Rccl      rccl;
+	bool      comms_up = false;
+	int       band_override = 0;
+	uint32_t* staging[SLOTS] = { nullptr, nullptr };   /* root: every part of a frame, back to back */
+	size_t    staging_bytes = 0;
+	hipEvent_t done[SLOTS] = { nullptr, nullptr };     /* root: frame of this slot assembled (staging free again) */
+	uint32_t* d_frame = nullptr;                       /* root: framebuffer of the host-surface path */
+	size_t    frame_bytes = 0;
+	unsigned long frames = 0;
+	char      err[512] = { 0 };
+};
+
+namespace {
+
+int mfail(lol_gpu_multi* m, int status, const char* what, const char* detail = nullptr) {
+	if (m) {
+		if (detail) snprintf(m->err, sizeof m->err, "%s: %s", what, detail);
+		else snprintf(m->err, sizeof m->err, "%s", what);
+	}
+	return status;
+}
+
+#define M_HIP(m, call)                                                                             \
+	do {                                                                                           \
+		hipError_t e_ = (call);                                                                    \
+		if (e_ != hipSuccess) return mfail((m), LOL_GPU_ERR_HIP, #call, hipGetErrorString(e_));    \
+	} while (0)
+#define M_NCCL(m, call)                                                                            \
+	do {                                                                                           \
+		ncclResult_t r_ = (call);                                                                  \
+		if (r_ != ncclSuccess) return mfail((m), LOL_GPU_ERR_HIP, #call, (m)->rccl.GetErrorString(r_)); \
+	} while (0)
+
+/* (re)size the per-device part buffers and the root's staging for frames of w x h */
+int ensure_buffers(lol_gpu_multi* m, int w, int h, int band_rows) {
+	size_t need_staging = (size_t)w * h * 4;
+	for (int d = 0; d < m->n; d++) {
+		Device& D = m->dev[d];
+		lol_gpu_rows R = { band_rows, m->n, d };
+		size_t need = (size_t)lol_gpu_part_rows(h, &R) * w * 4;
+		if (need > D.part_bytes) {
+			M_HIP(m, hipSetDevice(D.id));
+			M_HIP(m, hipDeviceSynchronize());
+			for (int s = 0; s < SLOTS; s++) {
+				if (D.part[s]) (void)hipFree(D.part[s]);
+				D.part[s] = nullptr;
+				M_HIP(m, hipMalloc(reinterpret_cast<void**>(&D.part[s]), need));
+			}
+			D.part_bytes = need;
+		}
+	}
+	if (need_staging > m->staging_bytes) {
+		M_HIP(m, hipSetDevice(m->dev[0].id));
+		M_HIP(m, hipDeviceSynchronize());
+		for (int s = 0; s < SLOTS; s++) {
+			if (m->staging[s]) (void)hipFree(m->staging[s]);
+			m->staging[s] = nullptr;
+			M_HIP(m, hipMalloc(reinterpret_cast<void**>(&m->staging[s]), need_staging));
+		}
+		m->staging_bytes = need_staging;
+	}
+	return LOL_GPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lol_gpu_choose_band_rows(int h, int n_devices) {
+	if (h <= 0 || n_devices <= 0) return 0;
+	if (n_devices == 1) return h;
+	/* equal parts first (multiples of the kernel's 4-row wave patch, so no wave straddles two bands) ... */
+	for (int band = 16; band >= 4; band -= 4)
+		if (h % (band * n_devices) == 0) return band;
+	/* ... else the tallest band that still deals every device at least eight bands (parts then differ by one band) */
+	for (int band = 16; band >= 4; band -= 4)
+		if (h / band >= 8 * n_devices) return band;
+	return 4;
+}
+
+int lol_gpu_part_frame_row(int h, const lol_gpu_rows* rows, int local_row) {
+	if (!rows) return local_row >= 0 && local_row < h ? local_row : -1;
+	if (local_row < 0 || local_row >= lol_gpu_part_rows(h, rows)) return -1;
+	const int band = local_row / rows->band_rows;
+	return (band * rows->n_parts + rows->part) * rows->band_rows + (local_row - band * rows->band_rows);
+}
+
+int lol_gpu_assemble_parts(lol_gpu* ctx, const void* parts, int n_parts, int band_rows, int w, int h,
+                           void* dst, size_t pitch_bytes, void* stream) {
+	if (!ctx || !parts || !dst) return LOL_GPU_ERR_ARG;
+	if (n_parts < 1 || n_parts > LOL_GPU_MULTI_MAX_DEVICES || band_rows < 1 || w < 1 || h < 1 ||
+	    pitch_bytes % 4 || pitch_bytes < (size_t)w * 4)
+		return LOL_GPU_ERR_ARG;
+	PartTable tab;
+	if (!fill_table(tab, n_parts, band_rows, h)) return LOL_GPU_ERR_ARG;
+	if (hipSetDevice(lol_gpu_device(ctx)) != hipSuccess) return LOL_GPU_ERR_HIP;
+	hipStream_t s = static_cast<hipStream_t>(stream);
+	if (!s) {
+		/* the context's private stream is not reachable from here: drain it, then use the legacy default stream */
+		int st = lol_gpu_sync(ctx);
+		if (st != LOL_GPU_OK) return st;
+		s = hipStreamLegacy;
+	}
+	return launch_assemble(parts, tab, n_parts, band_rows, w, h, dst, pitch_bytes, s) == hipSuccess ? LOL_GPU_OK : LOL_GPU_ERR_HIP;
+}
+
+int lol_gpu_multi_create(const int* devices, int n, lol_gpu_multi** out) {
+	if (!out) return LOL_GPU_ERR_ARG;
+	*out = nullptr;
+	if (!devices || n < 1 || n > LOL_GPU_MULTI_MAX_DEVICES) return LOL_GPU_ERR_ARG;
+	const int have = lol_gpu_device_count();
+	if (have <= 0) return LOL_GPU_ERR_NO_DEVICE;
+	for (int i = 0; i < n; i++) {
+		if (devices[i] < 0 || devices[i] >= have) return LOL_GPU_ERR_NO_DEVICE;
+		for (int j = 0; j < i; j++)
+			if (devices[j] == devices[i]) return LOL_GPU_ERR_ARG;      /* RCCL needs distinct devices */
+	}
+	lol_gpu_multi* m = new (std::nothrow) lol_gpu_multi;
+	if (!m) return LOL_GPU_ERR_HIP;
+	m->n = n;
+	auto bail = [&](const char* what, const char* detail) {
+		fprintf(stderr, "lol_gpu_multi_create: %s%s%s\n", what, detail ? ": " : "", detail ? detail : "");
+		lol_gpu_multi_destroy(m);
+		return LOL_GPU_ERR_HIP;
+	};
+	if (!m->rccl.load(m->err, sizeof m->err)) return bail(m->err, nullptr);
+	for (int i = 0; i < n; i++) {
+		Device& D = m->dev[i];
+		D.id = devices[i];
+		if (lol_gpu_create(D.id, &D.ctx) != LOL_GPU_OK) return bail("lol_gpu_create failed", nullptr);
+		hipError_t e = hipSetDevice(D.id);
+		if (e == hipSuccess) e = hipStreamCreateWithFlags(&D.render, hipStreamNonBlocking);
+		if (e == hipSuccess) e = hipStreamCreateWithFlags(&D.xchg, hipStreamNonBlocking);
+		for (int s = 0; s < SLOTS && e == hipSuccess; s++) {
+			e = hipEventCreateWithFlags(&D.rendered[s], hipEventDisableTiming);
+			if (e == hipSuccess) e = hipEventCreateWithFlags(&D.sent[s], hipEventDisableTiming);
+		}
+		if (e != hipSuccess) return bail("stream/event setup", hipGetErrorString(e));
+	}
+	{
+		hipError_t e = hipSetDevice(m->dev[0].id);
+		for (int s = 0; s < SLOTS && e == hipSuccess; s++) e = hipEventCreateWithFlags(&m->done[s], hipEventDisableTiming);
+		if (e != hipSuccess) return bail("event setup", hipGetErrorString(e));
+	}
+	ncclComm_t comms[LOL_GPU_MULTI_MAX_DEVICES];
+	ncclResult_t r = m->rccl.CommInitAll(comms, n, devices);
+	if (r != ncclSuccess) return bail("ncclCommInitAll", m->rccl.GetErrorString(r));
+	for (int i = 0; i < n; i++) m->dev[i].comm = comms[i];
+	m->comms_up = true;
+	*out = m;
+	return LOL_GPU_OK;
+}
+
+void lol_gpu_multi_destroy(lol_gpu_multi* m) {
+	if (!m) return;
+	for (int i = 0; i < m->n; i++) {
+		Device& D = m->dev[i];
+		if (D.id < 0) continue;
+		(void)hipSetDevice(D.id);
+		if (D.render) (void)hipStreamSynchronize(D.render);
+		if (D.xchg) (void)hipStreamSynchronize(D.xchg);
+	}
+	if (m->comms_up)
+		for (int i = 0; i < m->n; i++)
+			if (m->dev[i].comm) (void)m->rccl.CommDestroy(m->dev[i].comm);
+	for (int i = 0; i < m->n; i++) {
+		Device& D = m->dev[i];
+		if (D.id < 0) continue;
+		(void)hipSetDevice(D.id);
+		for (int s = 0; s < SLOTS; s++) {
+			if (D.part[s]) (void)hipFree(D.part[s]);
+			if (D.rendered[s]) (void)hipEventDestroy(D.rendered[s]);
+			if (D.sent[s]) (void)hipEventDestroy(D.sent[s]);
+		}
+		if (D.render) (void)hipStreamDestroy(D.render);
+		if (D.xchg) (void)hipStreamDestroy(D.xchg);
+		if (i == 0) {
+			for (int s = 0; s < SLOTS; s++) {
+				if (m->staging[s]) (void)hipFree(m->staging[s]);
+				if (m->done[s]) (void)hipEventDestroy(m->done[s]);
+			}
+			if (m->d_frame) (void)hipFree(m->d_frame);
+		}
+		lol_gpu_destroy(D.ctx);
+	}
+	/* the RCCL library stays mapped: unloading it under live HIP state is not worth the risk */
+	delete m;
+}
+
+const char* lol_gpu_multi_error(const lol_gpu_multi* m) { return m ? m->err : "null context"; }
+int lol_gpu_multi_device_count(const lol_gpu_multi* m) { return m ? m->n : 0; }
+lol_gpu* lol_gpu_multi_context(lol_gpu_multi* m, int i) { return m && i >= 0 && i < m->n ? m->dev[i].ctx : nullptr; }
+
+int lol_gpu_multi_set_band_rows(lol_gpu_multi* m, int band_rows) {
+	if (!m || band_rows < 0) return LOL_GPU_ERR_ARG;
+	m->band_override = band_rows;
+	return LOL_GPU_OK;
+}
+
+int lol_gpu_multi_upload_program(lol_gpu_multi* m, const lol_program* prog) {
+	if (!m || !prog) return LOL_GPU_ERR_ARG;
+	int st = lol_gpu_multi_sync(m);        /* frames in flight still read the old tables / code object */
+	if (st != LOL_GPU_OK) return st;
+	for (int i = 0; i < m->n; i++) {
+		st = lol_gpu_upload_program(m->dev[i].ctx, prog);
+		if (st != LOL_GPU_OK) return mfail(m, st, "lol_gpu_upload_program", lol_gpu_error(m->dev[i].ctx));
+	}
+	return LOL_GPU_OK;
+}
+
+int lol_gpu_multi_render_device(lol_gpu_multi* m, const lol_frame_camera* cam, int w, int h, int max_steps,
+                                void* dst, size_t pitch_bytes) {
+	if (!m || !cam || !dst) return LOL_GPU_ERR_ARG;
+	if (w <= 0 || h <= 0 || pitch_bytes % 4 || pitch_bytes < (size_t)w * 4) return mfail(m, LOL_GPU_ERR_ARG, "bad frame geometry");
+	const int n = m->n;
+	const int band = m->band_override > 0 ? m->band_override : lol_gpu_choose_band_rows(h, n);
+	int st = ensure_buffers(m, w, h, band);
+	if (st != LOL_GPU_OK) return st;
+	PartTable tab;
+	if (!fill_table(tab, n, band, h)) return mfail(m, LOL_GPU_ERR_ARG, "bad row partition");
+	const int slot = (int)(m->frames % SLOTS);
+	m->frames++;
+	Device& root = m->dev[0];
+
+	/* every device renders its part; the root's own part takes the same road as the others (a send to itself),
+	 * so that one code path serves any number of devices, one included */
+	size_t count[LOL_GPU_MULTI_MAX_DEVICES];
+	for (int d = 0; d < n; d++) {
+		Device& D = m->dev[d];
+		lol_gpu_rows R = { band, n, d };
+		const int rows = lol_gpu_part_rows(h, &R);
+		count[d] = (size_t)rows * w;
+		M_HIP(m, hipSetDevice(D.id));
+		M_HIP(m, hipStreamWaitEvent(D.render, D.sent[slot], 0));      /* the frame two back has left part[slot] */
+		if (rows > 0) {
+			st = lol_gpu_render_device(D.ctx, cam, w, h, max_steps, &R, D.part[slot], (size_t)w * 4, nullptr, D.render);
+			if (st != LOL_GPU_OK) return mfail(m, st, "lol_gpu_render_device", lol_gpu_error(D.ctx));
+		}
+		M_HIP(m, hipEventRecord(D.rendered[slot], D.render));
+		M_HIP(m, hipStreamWaitEvent(D.xchg, D.rendered[slot], 0));
+	}
+	/* the exchange: one group, every device sends, the root receives every part (its own included) */
+	M_HIP(m, hipSetDevice(root.id));
+	M_HIP(m, hipStreamWaitEvent(root.xchg, m->done[slot], 0));        /* staging[slot] was assembled two frames ago */
+	M_NCCL(m, m->rccl.GroupStart());
+	for (int d = 0; d < n; d++) {
+		if (count[d] == 0) continue;
+		M_NCCL(m, m->rccl.Send(m->dev[d].part[slot], count[d], ncclUint32, 0, m->dev[d].comm, m->dev[d].xchg));
+		M_NCCL(m, m->rccl.Recv(m->staging[slot] + (size_t)tab.row0[d] * w, count[d], ncclUint32, d, root.comm, root.xchg));
+	}
+	M_NCCL(m, m->rccl.GroupEnd());
+	for (int d = 0; d < n; d++) {
+		M_HIP(m, hipSetDevice(m->dev[d].id));
+		M_HIP(m, hipEventRecord(m->dev[d].sent[slot], m->dev[d].xchg));
+	}
+	M_HIP(m, hipSetDevice(root.id));
+	M_HIP(m, launch_assemble(m->staging[slot], tab, n, band, w, h, dst, pitch_bytes, root.xchg));
+	M_HIP(m, hipEventRecord(m->done[slot], root.xchg));
+	return LOL_GPU_OK;
+}
+
+int lol_gpu_multi_sync(lol_gpu_multi* m) {
+	if (!m) return LOL_GPU_ERR_ARG;
+	for (int d = 0; d < m->n; d++) {
+		M_HIP(m, hipSetDevice(m->dev[d].id));
+		M_HIP(m, hipStreamSynchronize(m->dev[d].render));
+		M_HIP(m, hipStreamSynchronize(m->dev[d].xchg));
+	}
+	M_HIP(m, hipSetDevice(m->dev[0].id));
+	return LOL_GPU_OK;
+}
+
+int lol_gpu_multi_render_host(lol_gpu_multi* m, const lol_frame_camera* cam, int w, int h, int max_steps,
+                              void* host_pixels, size_t pitch_bytes) {
+	if (!m || !host_pixels) return LOL_GPU_ERR_ARG;
+	if (w <= 0 || h <= 0 || pitch_bytes < (size_t)w * 4) return mfail(m, LOL_GPU_ERR_ARG, "bad frame geometry");
+	const size_t need = (size_t)w * h * 4;
+	Device& root = m->dev[0];
+	M_HIP(m, hipSetDevice(root.id));
+	if (need > m->frame_bytes) {                 /* the surface may be resized between frames (main.c:182-187) */
+		int st = lol_gpu_multi_sync(m);
+		if (st != LOL_GPU_OK) return st;
+		if (m->d_frame) (void)hipFree(m->d_frame);
+		m->d_frame = nullptr; m->frame_bytes = 0;
+		M_HIP(m, hipMalloc(reinterpret_cast<void**>(&m->d_frame), need));
+		m->frame_bytes = need;
+	}
+	int st = lol_gpu_multi_render_device(m, cam, w, h, max_steps, m->d_frame, (size_t)w * 4);
+	if (st != LOL_GPU_OK) return st;
+	M_HIP(m, hipSetDevice(root.id));
+	M_HIP(m, hipMemcpy2DAsync(host_pixels, pitch_bytes, m->d_frame, (size_t)w * 4, (size_t)w * 4, h,
+	                          hipMemcpyDeviceToHost, root.xchg));
+	M_HIP(m, hipStreamSynchronize(root.xchg));
+	return LOL_GPU_OK;
+}
+
+int lol_gpu_multi_malloc(lol_gpu_multi* m, size_t bytes, void** out) {
+	if (!m || !out) return LOL_GPU_ERR_ARG;
+	M_HIP(m, hipSetDevice(m->dev[0].id));
+	M_HIP(m, hipMalloc(out, bytes));
+	return LOL_GPU_OK;
+}
+
+int lol_gpu_multi_free(lol_gpu_multi* m, void* ptr) {
+	if (!m) return LOL_GPU_ERR_ARG;
+	M_HIP(m, hipSetDevice(m->dev[0].id));
+	M_HIP(m, hipFree(ptr));
+	return LOL_GPU_OK;
+}
+
+int lol_gpu_multi_memcpy_d2h(lol_gpu_multi* m, void* host, const void* dev, size_t bytes) {
+	if (!m || !host || !dev) return LOL_GPU_ERR_ARG;
+	int st = lol_gpu_multi_sync(m);
+	if (st != LOL_GPU_OK) return st;
+	M_HIP(m, hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
+	return LOL_GPU_OK;
+}
+
+}  // extern "C"

@@ -29,6 +29,17 @@ class Debug(C.Structure):
     _fields_ = [("rgb", C.c_void_p), ("hit_dist", C.c_void_p), ("hit_id", C.c_void_p), ("steps", C.c_void_p)]
 
 
+STREAM_DEFAULT = 1        # LOL_GPU_STREAM_DEFAULT: HIP's legacy default stream (hipStreamLegacy)
+
+
+def _stream_arg(stream):
+    """None → NULL (the context's own stream).  A handle of 0 is how HIP (and torch.cuda.current_stream()
+    .cuda_stream for the default stream) spells the legacy default stream: pass it on as such, never as NULL."""
+    if stream is None:
+        return None
+    return C.c_void_p(STREAM_DEFAULT if stream == 0 else stream)
+
+
 class GpuError(RuntimeError):
     def __init__(self, status: int, message: str):
         super().__init__(f"lol_gpu: {_STATUS.get(status, status)}: {message}")
@@ -89,6 +100,41 @@ def gpu_lib() -> C.CDLL:
         lib.lol_gpu_set_miss_skip.restype = C.c_int
         lib.lol_gpu_miss_skip_active.argtypes = [vp]
         lib.lol_gpu_miss_skip_active.restype = C.c_int
+        lib.lol_gpu_device.argtypes = [vp]
+        lib.lol_gpu_device.restype = C.c_int
+        # several devices (include/lol_gpu.h, "Several devices behind the same boundary")
+        lib.lol_gpu_multi_create.argtypes = [P(C.c_int), C.c_int, P(vp)]
+        lib.lol_gpu_multi_create.restype = C.c_int
+        lib.lol_gpu_multi_destroy.argtypes = [vp]
+        lib.lol_gpu_multi_destroy.restype = None
+        lib.lol_gpu_multi_error.argtypes = [vp]
+        lib.lol_gpu_multi_error.restype = C.c_char_p
+        lib.lol_gpu_multi_device_count.argtypes = [vp]
+        lib.lol_gpu_multi_device_count.restype = C.c_int
+        lib.lol_gpu_multi_context.argtypes = [vp, C.c_int]
+        lib.lol_gpu_multi_context.restype = vp
+        lib.lol_gpu_multi_upload_program.argtypes = [vp, P(S.Program)]
+        lib.lol_gpu_multi_upload_program.restype = C.c_int
+        lib.lol_gpu_choose_band_rows.argtypes = [C.c_int, C.c_int]
+        lib.lol_gpu_choose_band_rows.restype = C.c_int
+        lib.lol_gpu_multi_set_band_rows.argtypes = [vp, C.c_int]
+        lib.lol_gpu_multi_set_band_rows.restype = C.c_int
+        lib.lol_gpu_part_frame_row.argtypes = [C.c_int, P(Rows), C.c_int]
+        lib.lol_gpu_part_frame_row.restype = C.c_int
+        lib.lol_gpu_multi_render_device.argtypes = [vp, P(S.FrameCamera), C.c_int, C.c_int, C.c_int, vp, C.c_size_t]
+        lib.lol_gpu_multi_render_device.restype = C.c_int
+        lib.lol_gpu_multi_render_host.argtypes = [vp, P(S.FrameCamera), C.c_int, C.c_int, C.c_int, vp, C.c_size_t]
+        lib.lol_gpu_multi_render_host.restype = C.c_int
+        lib.lol_gpu_multi_sync.argtypes = [vp]
+        lib.lol_gpu_multi_sync.restype = C.c_int
+        lib.lol_gpu_multi_malloc.argtypes = [vp, C.c_size_t, P(vp)]
+        lib.lol_gpu_multi_malloc.restype = C.c_int
+        lib.lol_gpu_multi_free.argtypes = [vp, vp]
+        lib.lol_gpu_multi_free.restype = C.c_int
+        lib.lol_gpu_multi_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+        lib.lol_gpu_multi_memcpy_d2h.restype = C.c_int
+        lib.lol_gpu_assemble_parts.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]
+        lib.lol_gpu_assemble_parts.restype = C.c_int
         _lib = lib
     return _lib
 
@@ -98,7 +144,11 @@ EXPORTED_SYMBOLS = [
     "lol_gpu_part_rows", "lol_gpu_render_device", "lol_gpu_render_host", "lol_gpu_sync", "lol_gpu_malloc",
     "lol_gpu_free", "lol_gpu_memcpy_d2h", "lol_gpu_kernel_name", "lol_gpu_set_specialize",
     "lol_gpu_specialize_log", "lol_gpu_compile_offline", "lol_gpu_verify_fast_paths", "lol_gpu_set_miss_skip",
-    "lol_gpu_miss_skip_active", "lol_gpu_powf_batch",
+    "lol_gpu_miss_skip_active", "lol_gpu_powf_batch", "lol_gpu_device",
+    "lol_gpu_multi_create", "lol_gpu_multi_destroy", "lol_gpu_multi_error", "lol_gpu_multi_device_count",
+    "lol_gpu_multi_context", "lol_gpu_multi_upload_program", "lol_gpu_choose_band_rows", "lol_gpu_multi_set_band_rows",
+    "lol_gpu_part_frame_row", "lol_gpu_multi_render_device", "lol_gpu_multi_render_host", "lol_gpu_multi_sync",
+    "lol_gpu_multi_malloc", "lol_gpu_multi_free", "lol_gpu_multi_memcpy_d2h", "lol_gpu_assemble_parts",
 ]
 
 
@@ -152,7 +202,7 @@ class Renderer:
             C.byref(rows) if rows is not None else None,
             C.c_void_p(dst_ptr), pitch_bytes if pitch_bytes is not None else w * 4,
             C.byref(debug) if debug is not None else None,
-            C.c_void_p(stream) if stream else None))
+            _stream_arg(stream)))
 
     def render_host(self, host_ptr: int, w: int, h: int, max_steps: int = 256, camera: S.Camera | None = None,
                     pitch_bytes: int | None = None):
@@ -176,7 +226,7 @@ class Renderer:
     def powf_batch(self, x_ptr: int, y_ptr: int, out_ptr: int, n: int, stream: int | None = None):
         """out[i] = the kernel's powf(x[i], y[i]) on device arrays (diagnostic for tests)."""
         self._check(self._lib.lol_gpu_powf_batch(self._ctx, C.c_void_p(x_ptr), C.c_void_p(y_ptr), C.c_void_p(out_ptr), n,
-                                                 C.c_void_p(stream) if stream else None))
+                                                 _stream_arg(stream)))
 
     def set_miss_skip(self, enable: bool):
         self._check(self._lib.lol_gpu_set_miss_skip(self._ctx, 1 if enable else 0))
@@ -193,6 +243,65 @@ class Renderer:
         if getattr(self, "_ctx", None) and self._ctx.value:
             self._lib.lol_gpu_destroy(self._ctx)
             self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiRenderer:
+    """ctypes mirror of the lol_gpu_multi_* entry points: one frame over several devices of this process,
+    parts exchanged with RCCL and assembled on devices[0] (include/lol_gpu.h)."""
+
+    def __init__(self, devices, specialize: bool | int = True):
+        self._lib = gpu_lib()
+        self._m = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        st = self._lib.lol_gpu_multi_create(arr, len(devices), C.byref(self._m))
+        if st != LOL_GPU_OK:
+            self._m = C.c_void_p()
+            raise GpuError(st, f"lol_gpu_multi_create(devices={list(devices)}) failed")
+        for i in range(len(devices)):
+            self._lib.lol_gpu_set_specialize(self._lib.lol_gpu_multi_context(self._m, i), int(specialize))
+        self.scene = None
+        self.program = None
+
+    def _check(self, st: int):
+        if st != LOL_GPU_OK:
+            raise GpuError(st, self._lib.lol_gpu_multi_error(self._m).decode())
+
+    def prepare(self, scene: S.Scene):
+        self.scene = scene
+        self.program = scene.flatten()
+        self._check(self._lib.lol_gpu_multi_upload_program(self._m, C.byref(self.program)))
+
+    def set_band_rows(self, band_rows: int):
+        self._check(self._lib.lol_gpu_multi_set_band_rows(self._m, band_rows))
+
+    def render_into(self, dst_ptr: int, w: int, h: int, max_steps: int = 256, camera: S.Camera | None = None,
+                    pitch_bytes: int | None = None, frame_camera: S.FrameCamera | None = None):
+        fc = frame_camera if frame_camera is not None else self.scene.frame_camera(w, h, camera)
+        self._check(self._lib.lol_gpu_multi_render_device(self._m, C.byref(fc), w, h, max_steps, C.c_void_p(dst_ptr),
+                                                          pitch_bytes if pitch_bytes is not None else w * 4))
+
+    def render_host(self, host_ptr: int, w: int, h: int, max_steps: int = 256, camera: S.Camera | None = None,
+                    pitch_bytes: int | None = None):
+        fc = self.scene.frame_camera(w, h, camera)
+        self._check(self._lib.lol_gpu_multi_render_host(self._m, C.byref(fc), w, h, max_steps, C.c_void_p(host_ptr),
+                                                        pitch_bytes if pitch_bytes is not None else w * 4))
+
+    def sync(self):
+        self._check(self._lib.lol_gpu_multi_sync(self._m))
+
+    def kernel_name(self, i: int = 0) -> str:
+        return self._lib.lol_gpu_kernel_name(self._lib.lol_gpu_multi_context(self._m, i)).decode()
+
+    def close(self):
+        if getattr(self, "_m", None) and self._m.value:
+            self._lib.lol_gpu_multi_destroy(self._m)
+            self._m = C.c_void_p()
 
     def __del__(self):
         try:
