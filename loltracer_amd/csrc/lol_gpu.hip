@@ -35,20 +35,18 @@
 /* lol_kernel.h's text, embedded at build time (csrc/Makefile: lol_kernel_src.inc) for hipRTC */
 #include "lol_kernel_src.inc"
 
-static_assert(sizeof(lol_op) == lol::OP_DWORDS * 4, "lol_op layout");
 static_assert(sizeof(lol_light) == lol::LIGHT_DWORDS * 4, "lol_light layout");
 static_assert(sizeof(lol_material) == lol::MATERIAL_DWORDS * 4, "lol_material layout");
 static_assert(sizeof(lol_frame_camera) == sizeof(lol::Cam), "lol_frame_camera layout");
-static_assert(offsetof(lol_op, f) == 8 && offsetof(lol_op, id) == 4, "lol_op fields");
-static_assert(LOL_OP_SPHERE == lol::OP_SPHERE && LOL_OP_RBOX == lol::OP_RBOX && LOL_OP_PLANE == lol::OP_PLANE &&
-              LOL_OP_SMIN == lol::OP_SMIN && LOL_OP_SMIN_R == lol::OP_SMIN_R && LOL_OP_TOP == lol::OP_TOP, "opcodes");
 
 constexpr uint32_t LOL_SPEC_MAX_OPS = 128;
 
 struct lol_gpu {
 	int          device = -1;
 	hipStream_t  stream = nullptr;
-	lol_program* d_prog = nullptr;       /* device */
+	lol_program* d_prog = nullptr;       /* device: lights, materials, root_material tables */
+	uint32_t*    d_mops = nullptr;       /* device: the interpreter's macro-op list (lol_kernel.h, Interp) */
+	uint32_t     n_mops = 0;
 	lol_program  h_prog;                 /* host mirror (counts, max_stack) */
 	bool         have_prog = false;
 	uint32_t*    d_frame = nullptr;      /* framebuffer for lol_gpu_render_host */
@@ -86,12 +84,13 @@ int fail(lol_gpu* ctx, int status, const char* what, hipError_t e = hipSuccess) 
 		if (e_ != hipSuccess) return fail((ctx), LOL_GPU_ERR_HIP, #call, e_);     \
 	} while (0)
 
-template <int STACK>
+template <int SSIZE>
 hipError_t launch_interp(const lol::Launch& L, dim3 grid, size_t lds, hipStream_t s, int sqrt_kind) {
-	if (sqrt_kind == 3) hipLaunchKernelGGL((lol::render_interp<STACK, 3>), grid, dim3(lol::BLOCK), lds, s, L);
-	else                hipLaunchKernelGGL((lol::render_interp<STACK, 0>), grid, dim3(lol::BLOCK), lds, s, L);
+	if (sqrt_kind == 3) hipLaunchKernelGGL((lol::render_interp<SSIZE, 3>), grid, dim3(lol::BLOCK), lds, s, L);
+	else                hipLaunchKernelGGL((lol::render_interp<SSIZE, 0>), grid, dim3(lol::BLOCK), lds, s, L);
 	return hipGetLastError();
 }
+
 
 /* Conditions under which an escaped ray's colour is exactly clamp(ambient * materials[0].ambient), so
  * that waves of escaped rays may skip normal + lights (lol_kernel.h, FLAG_MISS_SKIP): material #0 has
@@ -207,6 +206,64 @@ struct FastPaths {
 		return false;
 	}
 };
+
+/*
+ * Post-order program → macro-ops of the interpreter (lol_kernel.h, Interp).  The accumulator is the top of the
+ * post-order operand stack:
+ *   primitive followed by SMIN / SMIN_R  → one macro-op: x = primitive, combined with acc at once.  In post-order
+ *                                           SMIN pops b (top) then a; the primitive is the top, so x = b and the
+ *                                           combine is sminf(acc, x); SMIN_R (top is a) gives sminf(x, acc);
+ *   primitive otherwise                   → SET when nothing is on the stack yet, else PUSH (acc goes under);
+ *   SMIN / SMIN_R after a non-primitive   → x = the popped entry under acc: SMIN has a = x, b = acc → sminf(x, acc);
+ *                                           SMIN_R has a = acc, b = x → sminf(acc, x);
+ *   TOP                                   → a flag on the macro-op that produced the value.
+ * `fast` lists the smoothness constants whose fast blend factor was proven on the device.
+ */
+std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast) {
+	std::vector<uint32_t> out;
+	auto fbits32 = [](float v) { uint32_t u; memcpy(&u, &v, 4); return u; };
+	int depth = 0;                                   /* post-order stack depth before the current op */
+	size_t last = 0;                                 /* start of the macro-op that produced the current acc */
+	for (uint32_t i = 0; i < P.n_ops; i++) {
+		const lol_op& o = P.ops[i];
+		auto smin_fields = [&](uint32_t* m, const lol_op& sm) {
+			m[9] = fbits32(sm.f[0]);
+			if (fast && fast->has(sm.f[0])) {
+				m[0] |= lol::MOP_FASTDIV;
+				m[10] = fbits32(2.0f * sm.f[0]);
+				m[11] = fbits32(0.5f * (1.0f / sm.f[0]));
+			}
+		};
+		if (o.op <= LOL_OP_PLANE) {
+			uint32_t m[lol::MOP_DWORDS] = { 0 };
+			const uint32_t kind = o.op == LOL_OP_SPHERE ? lol::MOP_SPHERE : o.op == LOL_OP_RBOX ? lol::MOP_RBOX : lol::MOP_PLANE;
+			for (int j = 0; j < 7; j++) m[2 + j] = fbits32(o.f[j]);
+			const lol_op* nx = i + 1 < P.n_ops ? &P.ops[i + 1] : nullptr;
+			if (nx && (nx->op == LOL_OP_SMIN || nx->op == LOL_OP_SMIN_R) && depth >= 1) {
+				m[0] = lol::mop_header(kind, nx->op == LOL_OP_SMIN ? lol::MOP_SMIN : lol::MOP_SMIN_X);
+				smin_fields(m, *nx);
+				i++;                                    /* the smooth min is part of this macro-op; depth unchanged */
+			} else {
+				m[0] = lol::mop_header(kind, depth == 0 ? lol::MOP_SET : lol::MOP_PUSH);
+				depth++;
+			}
+			last = out.size();
+			out.insert(out.end(), m, m + lol::MOP_DWORDS);
+		} else if (o.op == LOL_OP_SMIN || o.op == LOL_OP_SMIN_R) {
+			uint32_t m[lol::MOP_DWORDS] = { 0 };
+			m[0] = lol::mop_header(lol::MOP_POP, o.op == LOL_OP_SMIN ? lol::MOP_SMIN_X : lol::MOP_SMIN);
+			smin_fields(m, o);
+			depth--;
+			last = out.size();
+			out.insert(out.end(), m, m + lol::MOP_DWORDS);
+		} else {                                         /* LOL_OP_TOP */
+			out[last] |= lol::MOP_TOP;
+			out[last + 1] = o.id;
+			depth = 0;
+		}
+	}
+	return out;
+}
 
 /* Emits one `struct <name>` with eval(): one SSA temporary per op, same operation order as the interpreter. */
 void emit_sdf(std::string& s, const lol_program& P, const char* name, const FastPaths* fast) {
@@ -491,6 +548,7 @@ int lol_gpu_create(int device, lol_gpu** out) {
 	hipError_t e = hipSetDevice(device);
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_prog), sizeof(lol_program));
+	if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_mops), (size_t)LOL_MAX_OPS * lol::MOP_DWORDS * 4);
 	if (e != hipSuccess) {
 		fprintf(stderr, "lol_gpu_create: %s\n", hipGetErrorString(e));
 		lol_gpu_destroy(ctx);
@@ -506,6 +564,7 @@ void lol_gpu_destroy(lol_gpu* ctx) {
 	if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
 	if (ctx->spec_module) (void)hipModuleUnload(ctx->spec_module);
 	if (ctx->d_prog) (void)hipFree(ctx->d_prog);
+	if (ctx->d_mops) (void)hipFree(ctx->d_mops);
 	if (ctx->d_frame) (void)hipFree(ctx->d_frame);
 	if (ctx->d_bad) (void)hipFree(ctx->d_bad);
 	delete ctx;
@@ -585,23 +644,17 @@ int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog) {
 	LOL_HIP(ctx, hipDeviceSynchronize());
 	ctx->h_prog = *prog;
 	ctx->have_prog = true;
-	/* The interpreter's copy: smooth unions whose blend factor is proven become OP_SMINF* with {k, 2k, .5/k};
-	 * the proven sqrt is selected by instantiation at launch. */
+	/* tables for both kernels, and the interpreter's macro-op list: smooth unions whose blend factor is proven on
+	 * this device carry {k, 2k, .5/k}; the proven sqrt is selected by instantiation at launch */
 	{
 		FastPaths fast = prove_fast_paths(ctx, *prog);
 		ctx->interp_sqrt_kind = fast.sqrt_kind == 3 ? 3 : 0;
-		lol_program* patched = new (std::nothrow) lol_program(*prog);
-		if (!patched) return fail(ctx, LOL_GPU_ERR_HIP, "out of memory");
-		for (uint32_t i = 0; i < patched->n_ops; i++) {
-			lol_op& o = patched->ops[i];
-			if ((o.op == LOL_OP_SMIN || o.op == LOL_OP_SMIN_R) && fast.has(o.f[0])) {
-				o.op = o.op == LOL_OP_SMIN ? lol::OP_SMINF : lol::OP_SMINF_R;
-				o.f[1] = 2.0f * o.f[0];
-				o.f[2] = 0.5f * (1.0f / o.f[0]);
-			}
-		}
-		hipError_t e = hipMemcpy(ctx->d_prog, patched, sizeof *patched, hipMemcpyHostToDevice);
-		delete patched;
+		std::vector<uint32_t> mops = build_mops(*prog, &fast);
+		ctx->n_mops = (uint32_t)(mops.size() / lol::MOP_DWORDS);
+		if (ctx->n_mops > LOL_MAX_OPS) return fail(ctx, LOL_GPU_ERR_UNSUPPORTED, "program exceeds interpreter limits");
+		hipError_t e = hipMemcpy(ctx->d_prog, prog, sizeof *prog, hipMemcpyHostToDevice);
+		if (e == hipSuccess && !mops.empty())
+			e = hipMemcpy(ctx->d_mops, mops.data(), mops.size() * 4, hipMemcpyHostToDevice);
 		if (e != hipSuccess) return fail(ctx, LOL_GPU_ERR_HIP, "hipMemcpy(program)", e);
 	}
 	const char* ms = getenv("LOL_GPU_MISS_SKIP");
@@ -648,9 +701,9 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	L.n_rows = n_rows;
 	L.band_rows = R->band_rows; L.n_parts = R->n_parts; L.part = R->part;
 	const lol_program& P = ctx->h_prog;
-	L.n_ops = P.n_ops; L.n_lights = P.n_lights; L.n_materials = P.n_materials; L.n_roots = P.n_roots;
+	L.n_ops = ctx->n_mops; L.n_lights = P.n_lights; L.n_materials = P.n_materials; L.n_roots = P.n_roots;
 	const char* base = reinterpret_cast<const char*>(ctx->d_prog);
-	L.ops           = reinterpret_cast<const uint32_t*>(base + offsetof(lol_program, ops));
+	L.ops           = ctx->d_mops;
 	L.lights        = reinterpret_cast<const uint32_t*>(base + offsetof(lol_program, lights));
 	L.materials     = reinterpret_cast<const uint32_t*>(base + offsetof(lol_program, materials));
 	L.root_material = reinterpret_cast<const uint32_t*>(base + offsetof(lol_program, root_material));
@@ -681,12 +734,11 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 		void* args[] = { &L };
 		e = hipModuleLaunchKernel(ctx->spec_fn, grid.x, grid.y, 1, block, 1, 1, (unsigned)common, s, args, nullptr);
 	} else {
-		size_t lds = common + (size_t)P.n_ops * lol::OP_DWORDS * 4;
-		uint32_t need = P.max_stack;
+		const uint32_t need = P.max_stack > 1 ? P.max_stack - 1 : 1;      /* the accumulator holds the top entry */
 		const int kind = ctx->interp_sqrt_kind;
-		if (need <= 2)      e = launch_interp<2>(L, grid, lds, s, kind);
-		else if (need <= 4) e = launch_interp<4>(L, grid, lds, s, kind);
-		else                e = launch_interp<LOL_MAX_STACK>(L, grid, lds, s, kind);
+		if (need <= 1)      e = launch_interp<1>(L, grid, common, s, kind);
+		else if (need <= 3) e = launch_interp<3>(L, grid, common, s, kind);
+		else                e = launch_interp<LOL_MAX_STACK - 1>(L, grid, common, s, kind);
 	}
 	if (g_roctx.pop) g_roctx.pop();
 	if (e != hipSuccess) return fail(ctx, LOL_GPU_ERR_HIP, "kernel launch", e);

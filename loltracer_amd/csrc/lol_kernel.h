@@ -11,9 +11,9 @@
  * frames come out bit-identical to the CPU oracle's, packed pixels included.
  *
  * The file is compiled twice:
- *  - ahead of time by hipcc (lol_gpu.hip) with Interp<STACK, KIND>: the flattened SDF
- *    program is staged once per block into LDS and interpreted with
- *    wave-uniform scalar branches and a register operand stack;
+ *  - ahead of time by hipcc (lol_gpu.hip) with Interp<SSIZE, KIND>: the flattened SDF
+ *    program, as a list of macro-ops, is fetched with wave-uniform scalar loads and
+ *    interpreted with scalar branches, an accumulator and a register operand stack;
  *  - at render_prepare time by hipRTC (lol_gpu.hip: specialise()) together with
  *    a generated `SpecSdf` whose eval() is the scene's SDF as straight-line
  *    code with every constant an immediate — the GPU counterpart of the
@@ -60,10 +60,8 @@ constexpr int TILE_W = WAVE_W * LOL_WAVES_X;   /* pixels per block row  */
 constexpr int TILE_H = WAVE_H;                 /* pixel rows per block  */
 constexpr int BLOCK  = TILE_W * TILE_H;        /* 64 * WAVES_X threads; wave k owns columns [WAVE_W*k, WAVE_W*(k+1)) */
 
-/* dword layouts of lol_op / lol_light / lol_material (lol_scene.h); checked by static_asserts in lol_gpu.hip */
-constexpr int OP_DWORDS = 10, LIGHT_DWORDS = 9, MATERIAL_DWORDS = 10;
-enum { OP_SPHERE = 0, OP_RBOX = 1, OP_PLANE = 2, OP_SMIN = 3, OP_SMIN_R = 4, OP_TOP = 5,
-       OP_SMINF = 6, OP_SMINF_R = 7 };   /* device-only: smooth min with a proven fast blend factor */
+/* dword layouts of lol_light / lol_material (lol_scene.h); checked by static_asserts in lol_gpu.hip */
+constexpr int LIGHT_DWORDS = 9, MATERIAL_DWORDS = 10;
 
 /* Launch.flags */
 constexpr u32 FLAG_MISS_SKIP = 1u;   /* a wave whose rays all escaped may skip normal + lights (see shade_pixel) */
@@ -80,8 +78,8 @@ struct Launch {
 	i32    max_steps;
 	i32    n_rows;               /* local rows this launch renders */
 	i32    band_rows, n_parts, part;
-	u32    n_ops, n_lights, n_materials, n_roots;
-	const u32* ops;              /* device copies of the flattened scene's tables */
+	u32    n_ops, n_lights, n_materials, n_roots;   /* n_ops: macro-ops in `ops` (interpreter kernel only) */
+	const u32* ops;              /* device copies of the flattened scene's tables (ops: the macro-op list) */
 	const u32* lights;
 	const u32* materials;
 	const u32* root_material;
@@ -362,57 +360,111 @@ __device__ __forceinline__ float sd_round_box_fast(V3 p, float cx, float cy, flo
 }
 
 /* ------------------------------------------------------------ SDF interpreter
- * Runs the post-order program (lol_scene.h) for one point per lane.  `ops`
- * points into LDS; every lane reads the same address, and the opcode is moved
- * to an SGPR so the switch is a scalar branch.  STACK is the register stack
- * depth (>= program max_stack); push = shift, so nothing goes to scratch. */
-template <int STACK, int KIND = 0>
+ * Runs the scene's SDF for one point per lane from a list of MACRO-OPS (lol_gpu.hip: build_mops translates the
+ * post-order program of lol_scene.h).  The machine has an accumulator `acc` (the top of the operand stack) and a
+ * small register stack under it; one macro-op is "produce x, combine it into acc, maybe finish a root":
+ *   x     = sphere | round box | plane distance of this lane's point, or the popped stack entry
+ *   comb  = SET (acc = x) | PUSH (push acc; acc = x) | SMIN (acc = sminf(acc, x)) | SMIN_X (acc = sminf(x, acc))
+ *   top   : if (acc < best) { best = acc; best_id = id }            — sdf(), strict '<' (naive_renderer.c:39)
+ * so a chain of smooth unions whose one child is a primitive never touches the stack, and scene4's ten
+ * post-order ops are seven macro-ops.
+ *
+ * The records (12 dwords) are wave-uniform data and are fetched with SCALAR loads straight into SGPRs
+ * (constant address space, uniform index → s_load_dwordx4 through the scalar cache): measured on MI355X
+ * (tools/salu_rate.hip) a scalar-cache dword costs ~2 cycles per SIMD against 8.6 for a ds_read_b32 in which all
+ * 64 lanes read one LDS address, and it needs no LDS-address VGPR and no v_readfirstlane; the header word is
+ * then already scalar, so the dispatch is s_cmp / s_cbranch.  This replaced the LDS-staged op list of round 1
+ * (VALU 2.4x, SALU 11x the specialised kernel's; profiles/README.md). */
+constexpr int MOP_DWORDS = 12;
+enum { MOP_SPHERE = 0, MOP_RBOX = 1, MOP_PLANE = 2, MOP_POP = 3 };          /* what x is          */
+enum { MOP_SET = 0, MOP_PUSH = 1, MOP_SMIN = 2, MOP_SMIN_X = 3 };           /* how it is combined */
+/* header word: one bit per decision */
+constexpr u32 MOPB_SPHERE = 1u, MOPB_RBOX = 2u, MOPB_PLANE = 4u, MOPB_POP = 8u;
+constexpr u32 MOP_FASTDIV = 16u;     /* the smooth min's blend factor was proven for this k: f[8] = 2k, f[9] = .5/k */
+constexpr u32 MOP_TOP = 32u;         /* acc is a finished top-level object: id in word 1                           */
+constexpr u32 MOPB_PUSH = 64u, MOPB_SMIN = 128u, MOPB_X_IS_A = 256u;   /* SET = none of PUSH / SMIN */
+__host__ __device__ constexpr u32 mop_header(u32 kind, u32 comb) {
+	return (1u << kind) | (comb == MOP_PUSH ? MOPB_PUSH : comb == MOP_SMIN ? MOPB_SMIN : comb == MOP_SMIN_X ? (MOPB_SMIN | MOPB_X_IS_A) : 0u);
+}
+
+/* scalar (constant address space) view of the list; loaded dword by dword — the compiler merges the loads into
+ * s_load_dwordx8 + x4 (vector-typed loads of such records miscompile under hipcc 7.2: lane .y read as .x) */
+typedef const __attribute__((address_space(4))) u32* mop_ptr;
+
+template <int SSIZE, int KIND = 0>
 struct Interp {
-	const u32* ops;      /* LDS */
-	u32        n_ops;
+	const u32* mops;     /* global memory, MOP_DWORDS per macro-op, 16-byte aligned */
+	u32        n_mops;
 	Range      rg;       /* KIND != 0: range of the squared lengths given to the proven fast sqrt (see above) */
 
-	__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id) {
-		float s[STACK];
+	/* Inlined into the march / normal / shadow loops: as a real (noinline) function it was 8 % slower — arguments
+	 * travel in VGPRs and need v_readfirstlane, plus call / return and the callee's register shuffling. */
+	__device__ __forceinline__ void eval(V3 p, float& best_out, u32& id_out) {
+		/* everything the loop carries is a local: the trip count and the list pointer must stay provably
+		 * wave-uniform (scalar loop, scalar loads, scalar branches), which they do not when they live behind
+		 * `this` next to per-lane results written through references */
+		const u32 n = n_mops;
+		mop_ptr rec = (mop_ptr)(unsigned long long)mops;
+		Range r = rg;
+		float s[SSIZE];
 #pragma unroll
-		for (int i = 0; i < STACK; i++) s[i] = 0.f;
-		best = __builtin_inff();
-		best_id = 0;
-		for (u32 i = 0; i < n_ops; i++) {
-			const u32* o = ops + i * OP_DWORDS;
-			const float* f = reinterpret_cast<const float*>(o + 2);
-			/* (prefetching op i+1 while op i executes was tried: more VGPRs, lower occupancy, 20 % slower) */
-			const u32 w0 = o[0], w1 = o[1];
-			u32 op = __builtin_amdgcn_readfirstlane(w0);
-			if (op <= OP_PLANE) {
-				float d;
-				if (op == OP_SPHERE)
-					d = KIND ? sd_sphere_fast<KIND ? KIND : 1>(p, f[0], f[1], f[2], f[3], rg)
-					         : sd_sphere(p, f[0], f[1], f[2], f[3]);
-				else if (op == OP_RBOX)
-					d = KIND ? sd_round_box_fast<KIND ? KIND : 1>(p, f[0], f[1], f[2], f[3], f[4], f[5], f[6], rg)
-					         : sd_round_box(p, f[0], f[1], f[2], f[3], f[4], f[5], f[6]);
-				else
-					d = p.y - f[0];                              /* plane: (p - (0,y,0)).y */
+		for (int i = 0; i < SSIZE; i++) s[i] = 0.f;
+		float acc = 0.f;
+		float best = __builtin_inff();
+		u32 best_id = 0;
+		for (u32 i = 0; i < n; i++, rec += MOP_DWORDS) {
+			const u32 hdr = rec[0];
+			auto F = [&](int j) { return __builtin_bit_cast(float, rec[j]); };
+			/* one-hot header bits, tested one by one (s_bitcmp1 + s_cbranch each) with no else-chains: every `if`
+			 * is a plain skip-ahead, which the compiler lowers without the flag registers it needs for if / else-if */
+			/* LOL_KEEP_BRANCH: an empty volatile asm keeps the compiler from turning a rarely taken uniform branch into
+			 * v_cndmask selects that every macro-op would then pay for (half-rate VALU, 4 cycles each) */
+#define LOL_KEEP_BRANCH() asm volatile("" ::: "memory")
+			float x = 0.f;
+			if (hdr & MOPB_SPHERE)
+				x = KIND ? sd_sphere_fast<KIND ? KIND : 1>(p, F(2), F(3), F(4), F(5), r) : sd_sphere(p, F(2), F(3), F(4), F(5));
+			if (hdr & (MOPB_RBOX | MOPB_PLANE | MOPB_POP)) {         /* grouped: a sphere macro-op pays one test for these */
+				LOL_KEEP_BRANCH();
+				if (hdr & MOPB_RBOX)
+					x = KIND ? sd_round_box_fast<KIND ? KIND : 1>(p, F(2), F(3), F(4), F(5), F(6), F(7), F(8), r)
+					         : sd_round_box(p, F(2), F(3), F(4), F(5), F(6), F(7), F(8));
+				if (hdr & MOPB_PLANE)
+					x = p.y - F(2);                              /* plane: (p - (0,y,0)).y */
+				if (hdr & MOPB_POP) {
+					LOL_KEEP_BRANCH();
+					x = s[0];
 #pragma unroll
-				for (int j = STACK - 1; j > 0; j--) s[j] = s[j - 1];
-				s[0] = d;
-			} else if (op == OP_TOP) {                           /* sdf(): strict '<', naive_renderer.c:39 */
-				u32 id = __builtin_amdgcn_readfirstlane(w1);
-				if (s[0] < best) { best = s[0]; best_id = id; }
-#pragma unroll
-				for (int j = 0; j < STACK - 1; j++) s[j] = s[j + 1];
-			} else {                                             /* SMIN*: top is b; SMIN*_R: top is a */
-				float top = s[0], under = s[1];
-				const bool swapped = op == OP_SMIN_R || op == OP_SMINF_R;
-				float a = swapped ? top : under;
-				float b = swapped ? under : top;
-				/* OP_SMINF*: lol_gpu.hip rewrote the op after proving the fast blend factor for this k: f = {k, 2k, .5/k} */
-				s[0] = op >= OP_SMINF ? sminf_fastdiv(a, b, f[0], f[1], f[2]) : sminf_(a, b, f[0]);
-#pragma unroll
-				for (int j = 1; j < STACK - 1; j++) s[j] = s[j + 1];
+					for (int j = 0; j < SSIZE - 1; j++) s[j] = s[j + 1];
+				}
 			}
+			if (hdr & MOPB_SMIN) {
+				if (hdr & MOPB_X_IS_A) {
+					LOL_KEEP_BRANCH();
+					x = (hdr & MOP_FASTDIV) ? sminf_fastdiv(x, acc, F(9), F(10), F(11)) : sminf_(x, acc, F(9));
+				} else {
+					LOL_KEEP_BRANCH();
+					x = (hdr & MOP_FASTDIV) ? sminf_fastdiv(acc, x, F(9), F(10), F(11)) : sminf_(acc, x, F(9));
+				}
+			}
+			if (hdr & (MOPB_PUSH | MOP_TOP)) {
+				LOL_KEEP_BRANCH();
+				if (hdr & MOPB_PUSH) {
+					LOL_KEEP_BRANCH();
+#pragma unroll
+					for (int j = SSIZE - 1; j > 0; j--) s[j] = s[j - 1];
+					s[0] = acc;
+				}
+				if (hdr & MOP_TOP) {
+					LOL_KEEP_BRANCH();
+					if (x < best) { best = x; best_id = rec[1]; }
+				}
+			}
+			acc = x;
+#undef LOL_KEEP_BRANCH
 		}
+		rg = r;
+		best_out = best;
+		id_out = best_id;
 	}
 };
 
@@ -625,25 +677,24 @@ __device__ __forceinline__ void stage_common(const Launch& L, u32* lds) {
 	for (u32 i = threadIdx.x; i < L.n_roots; i += BLOCK) l_rootm[i] = L.root_material[i];
 }
 
-/* Generic kernel: LDS = ops | common.  KIND != 0 selects the proven fast sqrt (the host launches that
- * instantiation only after the exhaustive check passed on the device); a wave that fed it a squared length
- * outside its proven domain shades its pixels again with the plain interpreter, as in the specialised kernel. */
-template <int STACK, int KIND>
+/* Generic kernel (ahead of time): the SDF is interpreted from the macro-op list in global memory (scalar loads);
+ * LDS holds lights | materials | root_material | out tile like in the specialised kernel.  KIND != 0 selects the
+ * proven fast sqrt (the host launches that instantiation only after the exhaustive check passed on the device); a
+ * wave that fed it a squared length outside its proven domain shades its pixels again with the plain interpreter,
+ * as in the specialised kernel. */
+template <int SSIZE, int KIND>
 __global__ __launch_bounds__(BLOCK)
 void render_interp(const Launch L) {
 	extern __shared__ u32 lds[];
-	u32* l_ops = lds;
-	u32* l_common = l_ops + L.n_ops * OP_DWORDS;
-	for (u32 i = threadIdx.x; i < L.n_ops * OP_DWORDS; i += BLOCK) l_ops[i] = L.ops[i];
-	stage_common(L, l_common);
+	stage_common(L, lds);
 	__syncthreads();
-	Interp<STACK, KIND> sdf{ l_ops, L.n_ops, {} };
-	Pixel P = shade_pixel(L, sdf, l_common);
+	Interp<SSIZE, KIND> sdf{ L.ops, L.n_ops, {} };
+	Pixel P = shade_pixel(L, sdf, lds);
 	if (KIND != 0 && __ballot(sdf.rg.outside()) != 0) {
-		Interp<STACK, 0> exact{ l_ops, L.n_ops, {} };
-		P = shade_pixel(L, exact, l_common);
+		Interp<SSIZE, 0> exact{ L.ops, L.n_ops, {} };
+		P = shade_pixel(L, exact, lds);
 	}
-	store_pixel(L, P, l_common);
+	store_pixel(L, P, lds);
 }
 
 }  // namespace lol
