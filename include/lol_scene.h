@@ -149,10 +149,14 @@ typedef struct lol_op {
 	uint32_t _pad;   /* keeps the record at 40 B = 10 dwords */
 } lol_op;
 
-#define LOL_MAX_OPS        256
-#define LOL_MAX_LIGHTS     16
-#define LOL_MAX_MATERIALS  64
-#define LOL_MAX_STACK      8
+/* Capacity of one program.  The reference's scene vectors grow without bound (vector.h:16-66); here a scene
+ * beyond these limits is refused loudly by lol_scene_flatten (LOL_ERR_UNSUPPORTED) — nothing is truncated.
+ * 1024 ops = e.g. 340 smooth-unioned primitives in one object, or 512 flat objects; a stack of 12 covers any
+ * tree of that size (children are emitted deeper-first, so depth d needs 2^(d-1) primitives). */
+#define LOL_MAX_OPS        1024
+#define LOL_MAX_LIGHTS     64
+#define LOL_MAX_MATERIALS  256
+#define LOL_MAX_STACK      12
 
 typedef struct lol_program {
 	uint32_t     n_ops;

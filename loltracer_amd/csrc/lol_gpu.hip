@@ -39,7 +39,6 @@ static_assert(sizeof(lol_light) == lol::LIGHT_DWORDS * 4, "lol_light layout");
 static_assert(sizeof(lol_material) == lol::MATERIAL_DWORDS * 4, "lol_material layout");
 static_assert(sizeof(lol_frame_camera) == sizeof(lol::Cam), "lol_frame_camera layout");
 
-constexpr uint32_t LOL_SPEC_MAX_OPS = 128;
 
 struct lol_gpu {
 	int          device = -1;
@@ -265,15 +264,24 @@ std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast) {
 	return out;
 }
 
-/* Emits one `struct <name>` with eval(): one SSA temporary per op, same operation order as the interpreter. */
-void emit_sdf(std::string& s, const lol_program& P, const char* name, const FastPaths* fast) {
+/* Emits one `struct <name>` with eval(): one SSA temporary per op, same operation order as the post-order program.
+ * out_of_line: the body becomes ONE real function (`<name>_fn`, __noinline__) that the march, normal and shadow
+ * loops call, instead of being inlined into each of them — for large scenes, whose straight-line SDF would
+ * otherwise be replicated six times (three loops x fast / exact) and outgrow the instruction cache. */
+void emit_sdf(std::string& s, const lol_program& P, const char* name, const FastPaths* fast, bool out_of_line) {
 	char line[640];
 	const int fsqrt = fast ? fast->sqrt_kind : 0;
 	char fs[32] = "";
 	if (fsqrt) snprintf(fs, sizeof fs, "_fast<%d>", fsqrt);
-	snprintf(line, sizeof line, "struct %s {\n\tRange rg;\n", name);
-	s += line;
-	s += "\t__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id) {\n";
+	if (out_of_line) {
+		snprintf(line, sizeof line, "__device__ __noinline__ SdfOut %s_fn(float px, float py, float pz, u32 rg_lo, u32 rg_hi) {\n"
+		         "\t\tconst V3 p = { px, py, pz };\n\t\tRange rg; rg.lo = rg_lo; rg.hi = rg_hi;\n\t\tfloat best; u32 best_id;\n", name);
+		s += line;
+	} else {
+		snprintf(line, sizeof line, "struct %s {\n\tRange rg;\n", name);
+		s += line;
+		s += "\t__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id) {\n";
+	}
 	s += "\t\tbest = __builtin_inff(); best_id = 0u;\n";
 	std::vector<int> stack;
 	int t = 0;
@@ -312,7 +320,15 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 		}
 		}
 	}
-	s += "\t}\n};\n";
+	if (out_of_line) {
+		s += "\t\treturn { best, best_id, rg.lo, rg.hi };\n}\n";
+		snprintf(line, sizeof line, "struct %s {\n\tRange rg;\n\t__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id) {\n"
+		         "\t\tconst SdfOut o = %s_fn(p.x, p.y, p.z, rg.lo, rg.hi);\n"
+		         "\t\tbest = o.best; best_id = o.id; rg.lo = o.lo; rg.hi = o.hi;\n\t}\n};\n", name, name);
+		s += line;
+	} else {
+		s += "\t}\n};\n";
+	}
 }
 
 /*
@@ -320,13 +336,27 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
  * [SQRT_FAST_MIN, inf) (a sample within 2^-48 of a sphere centre, or an overflow) shades its pixels
  * again with the plain SDF, so the shortcut never decides a result.
  */
+/* Scenes above this many ops get their SDF as an out-of-line function (emit_sdf).  Measured on MI355X
+ * (tools/large_scene_ab.py, profiles/): inlined code is 10-20 % faster up to 256 ops (1.1 s to compile); beyond
+ * that compile time and code size (six copies of the SDF) grow linearly while the call overhead stays fixed.
+ * LOL_GPU_SPEC_INLINE_MAX overrides. */
+constexpr uint32_t LOL_SPEC_INLINE_MAX_OPS = 256;
+
+bool spec_out_of_line(const lol_program& P) {
+	uint32_t limit = LOL_SPEC_INLINE_MAX_OPS;
+	if (const char* e = getenv("LOL_GPU_SPEC_INLINE_MAX")) limit = (uint32_t)strtoul(e, nullptr, 10);
+	return P.n_ops > limit;
+}
+
 std::string generate_source(const lol_program& P, const FastPaths* fast) {
 	std::string s;
+	const bool ool = spec_out_of_line(P);
 	s += "#include \"lol_kernel.h\"\n";
 	s += "namespace lol {\n";
-	emit_sdf(s, P, "SpecSdfExact", nullptr);
+	if (ool) s += "struct SdfOut { float best; u32 id; u32 lo, hi; };\n";
+	emit_sdf(s, P, "SpecSdfExact", nullptr, ool);
 	const bool any_fast = fast && (fast->sqrt_kind || !fast->div_ok.empty());
-	if (any_fast) emit_sdf(s, P, "SpecSdfFast", fast);
+	if (any_fast) emit_sdf(s, P, "SpecSdfFast", fast, ool);
 	s += "}  // namespace lol\n";
 	s += "extern \"C\" __global__ __launch_bounds__(lol::BLOCK) void lol_render_spec(const lol::Launch L) {\n";
 	s += "\textern __shared__ lol::u32 lds[];\n";
@@ -473,13 +503,7 @@ bool specialise(lol_gpu* ctx) {
 	ctx->spec_log.clear();
 	const char* env = getenv("LOL_GPU_SPECIALIZE");
 	if (!ctx->want_spec || (env && env[0] == '0')) return false;
-	/* straight-line code grows with the scene (the SDF is inlined in the march, normal and shadow loops, twice):
-	 * past LOL_SPEC_MAX_OPS it would outgrow the instruction cache and take tens of seconds to compile, so
-	 * large scenes stay on the interpreter. */
-	if (ctx->h_prog.n_ops > LOL_SPEC_MAX_OPS) {
-		ctx->spec_log = "scene too large to specialise; using the interpreter kernel";
-		return false;
-	}
+	/* every program the library accepts is specialised; large ones get their SDF out of line (emit_sdf) */
 
 	hipDeviceProp_t prop;
 	std::string arch = "gfx950";
@@ -738,6 +762,7 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 		const int kind = ctx->interp_sqrt_kind;
 		if (need <= 1)      e = launch_interp<1>(L, grid, common, s, kind);
 		else if (need <= 3) e = launch_interp<3>(L, grid, common, s, kind);
+		else if (need <= 7) e = launch_interp<7>(L, grid, common, s, kind);
 		else                e = launch_interp<LOL_MAX_STACK - 1>(L, grid, common, s, kind);
 	}
 	if (g_roctx.pop) g_roctx.pop();

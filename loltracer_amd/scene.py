@@ -14,10 +14,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 
-LOL_MAX_OPS = 256
-LOL_MAX_LIGHTS = 16
-LOL_MAX_MATERIALS = 64
-LOL_MAX_STACK = 8
+LOL_MAX_OPS = 1024
+LOL_MAX_LIGHTS = 64
+LOL_MAX_MATERIALS = 256
+LOL_MAX_STACK = 12
 
 (LOL_OK, LOL_ERR_IO, LOL_ERR_SYNTAX, LOL_ERR_PROPERTY, LOL_ERR_TYPE, LOL_ERR_COMPONENT,
  LOL_ERR_MATERIAL, LOL_ERR_NOMEM, LOL_ERR_UNSUPPORTED) = range(9)

@@ -34,7 +34,8 @@ def test_struct_sizes_match_the_headers():
     # the Python mirrors must match the C layouts (lol_op is 10 dwords, see lol_scene.h)
     assert C.sizeof(S.Op) == 40 and C.sizeof(S.Light) == 36 and C.sizeof(S.Material) == 40
     assert C.sizeof(S.Node) == 48 and C.sizeof(S.FrameCamera) == 56
-    assert C.sizeof(S.Program) == 5 * 4 + 12 + 40 * 256 + 36 * 16 + 40 * 64 + 4 * 256
+    assert (S.LOL_MAX_OPS, S.LOL_MAX_LIGHTS, S.LOL_MAX_MATERIALS, S.LOL_MAX_STACK) == (1024, 64, 256, 12)
+    assert C.sizeof(S.Program) == 5 * 4 + 12 + 40 * S.LOL_MAX_OPS + 36 * S.LOL_MAX_LIGHTS + 40 * S.LOL_MAX_MATERIALS + 4 * S.LOL_MAX_OPS
 
 
 def test_part_rows_is_pure_host_logic():

@@ -127,23 +127,59 @@ def test_orbit_frames_match_the_oracle(torch_cuda, scenes):
     r.close()
 
 
-def test_large_scene_falls_back_to_the_interpreter(torch_cuda):
-    """More than LOL_SPEC_MAX_OPS (128) ops: no specialisation (code size / compile time), same pixels."""
-    rng = np.random.default_rng(3)
+def chain_scene(n_unions, seed=3):
+    """One object: a right-leaning chain of n smooth unions of spheres (2n + 2 ops), over a plane, lit and in view."""
+    rng = np.random.default_rng(seed)
     body = "sphere { point = (0,0,-5), radius = 1 }"
-    for i in range(69):
+    for i in range(n_unions):
         body = "smooth_union { smoothness = 1, a = sphere { point = %s, radius = %s }, b = %s }" % (
             fmt(rng.normal(size=3) * [3, 2, 3] + [0, 0, -7]), num(rng.uniform(0.3, 1.2)), body)
     text = ("materials { { shininess = 2, diffuse = (0,0,0), specular = (0,0,0), ambient = (0,0,0) },"
             " { shininess = 8, diffuse = (.5,.5,.5), specular = (.2,.2,.2), ambient = (.1,.1,.1) } }\n"
-            "scene { point_light { point = (0,9,0), diffuse_intensity = (2,2,2), specular_intensity = (2,2,2) }, "
-            + body.replace("{", "{ material = #1,", 1) + " }")
-    sc = S.Scene.parse_string(text)
-    assert sc.flatten().n_ops == 140
+            "scene { camera { point = (0, 3, 6), direction = (0, -0.25, -1), fov = 100 },"
+            " point_light { point = (0,9,0), diffuse_intensity = (2,2,2), specular_intensity = (2,2,2) }, "
+            + body.replace("{", "{ material = #1,", 1) + ", plane { y = -4, material = #1 } }")
+    return S.Scene.parse_string(text)
+
+
+@pytest.mark.parametrize("n_unions,inline_max", [(69, None), (69, 0), (130, None), (130, 0)],
+                         ids=["142ops-inline", "142ops-out-of-line", "264ops-default", "264ops-out-of-line"])
+def test_large_scenes_are_specialised_too(torch_cuda, monkeypatch, n_unions, inline_max):
+    """Round 1 left scenes above 128 ops to the interpreter.  Every program the library accepts is now specialised:
+    the SDF inlined up to 256 ops, as one out-of-line function beyond (LOL_GPU_SPEC_INLINE_MAX) — same pixels."""
+    if inline_max is not None:
+        monkeypatch.setenv("LOL_GPU_SPEC_INLINE_MAX", str(inline_max))
+    sc = chain_scene(n_unions)
+    assert sc.flatten().n_ops == 2 * n_unions + 4
     r = gpu.Renderer(0)
     r.prepare(sc)
-    assert r.kernel_name() == "render_interp" and "too large" in r.specialize_log()
-    r.want_kernel = "render_interp"
+    assert r.kernel_name() == "lol_render_spec", r.specialize_log()
     g = gpu_render(torch_cuda, r, sc, 48, 32)
     check_against_oracle(g, sc, 48, 32)
     r.close()
+
+
+def test_deep_tree_needs_the_big_operand_stack(torch_cuda):
+    """A perfectly balanced smooth-union tree of 512 spheres (1024 ops): operand stack depth 10 — the interpreter's
+    largest instantiation and the out-of-line specialised SDF; both against the oracle."""
+    rng = np.random.default_rng(11)
+
+    def tree(d):
+        if d == 0:
+            return "sphere { point = %s, radius = %s }" % (fmt(rng.normal(size=3) * [4, 2, 3] + [0, 0, -9]), num(rng.uniform(0.2, 0.8)))
+        return "smooth_union { smoothness = 0.5, a = %s, b = %s }" % (tree(d - 1), tree(d - 1))
+    text = ("materials { { shininess = 2, diffuse = (0,0,0), specular = (0,0,0), ambient = (.02,.02,.02) },"
+            " { shininess = 8, diffuse = (.5,.5,.5), specular = (.2,.2,.2), ambient = (.1,.1,.1) } }\n"
+            "scene { camera { point = (0, 1, 4), direction = (0, -0.1, -1), fov = 100 },"
+            " point_light { point = (0,9,0), diffuse_intensity = (2,2,2), specular_intensity = (2,2,2) }, "
+            + tree(9).replace("{", "{ material = #1,", 1) + " }")
+    sc = S.Scene.parse_string(text)
+    prog = sc.flatten()
+    assert prog.n_ops == S.LOL_MAX_OPS and prog.max_stack == 10
+    for mode, name in ((4, "render_interp"), (1, "lol_render_spec")):
+        r = gpu.Renderer(0, specialize=mode)
+        r.prepare(sc)
+        assert r.kernel_name() == name, r.specialize_log()
+        g = gpu_render(torch_cuda, r, sc, 32, 20)
+        check_against_oracle(g, sc, 32, 20)
+        r.close()
