@@ -1,5 +1,6 @@
 # Convenience targets; the real build rules live in loltracer_amd/csrc/Makefile and oracle/Makefile.
-.PHONY: build test test-gpu bench clean
+.PHONY: all build test test-gpu bench clean
+all: build
 build:
 	python -c "import __graft_entry__ as g; g.build()"
 test: build

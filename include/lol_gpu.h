@@ -160,6 +160,14 @@ int         lol_gpu_miss_skip_active(const lol_gpu* ctx);
  */
 int         lol_gpu_powf_batch(lol_gpu* ctx, const float* x_dev, const float* y_dev, float* out_dev, size_t n,
                                void* stream);
+/*
+ * Diagnostic: the scene SDF alone — sdf() of naive_renderer.c:31-44, i.e. get_obj_dist over every top-level object
+ * with the first strict minimum — at n arbitrary points: pts = n x {x, y, z}, dist[i] / id[i] out (device pointers,
+ * asynchronous on `stream`).  Runs the SAME SDF code the frames run (the specialised module's or the interpreter's,
+ * fast paths and their fallback included), so a test can hold the device's distances against known answers
+ * (tests/golden/ref_sdf_points.json) without a march in between.
+ */
+int         lol_gpu_sdf_batch(lol_gpu* ctx, const float* pts_dev, float* dist_dev, uint32_t* id_dev, size_t n, void* stream);
 /* No device needed: writes <out_base>.hip (generated source) and <out_base>.co (code object for `arch`).
  * assume_fast != 0 generates the shortcuts without proof — for ISA inspection only, never for rendering. */
 int         lol_gpu_compile_offline(const lol_program* prog, const char* arch, const char* out_base,

@@ -53,6 +53,7 @@ struct lol_gpu {
 	int          want_spec = 1;
 	hipModule_t  spec_module = nullptr;
 	hipFunction_t spec_fn = nullptr;
+	hipFunction_t spec_sdf_fn = nullptr; /* lol_sdf_spec of the same module (lol_gpu_sdf_batch) */
 	std::string  spec_log;
 	int          want_fast = 1;          /* allow the proven-exact shortcuts in the specialised kernel */
 	int          want_miss_skip = 1;     /* allow FLAG_MISS_SKIP when the program qualifies */
@@ -82,6 +83,15 @@ int fail(lol_gpu* ctx, int status, const char* what, hipError_t e = hipSuccess) 
 		hipError_t e_ = (call);                                                   \
 		if (e_ != hipSuccess) return fail((ctx), LOL_GPU_ERR_HIP, #call, e_);     \
 	} while (0)
+
+template <int SSIZE>
+hipError_t launch_sdf_interp(const uint32_t* mops, uint32_t n_mops, const float* pts, float* dist, uint32_t* id, uint32_t n,
+                             hipStream_t s, int sqrt_kind) {
+	dim3 grid((n + 63) / 64);
+	if (sqrt_kind == 3) hipLaunchKernelGGL((lol::sdf_points_interp<SSIZE, 3>), grid, dim3(64), 0, s, mops, n_mops, pts, dist, id, n);
+	else                hipLaunchKernelGGL((lol::sdf_points_interp<SSIZE, 0>), grid, dim3(64), 0, s, mops, n_mops, pts, dist, id, n);
+	return hipGetLastError();
+}
 
 template <int SSIZE>
 hipError_t launch_interp(const lol::Launch& L, dim3 grid, size_t lds, hipStream_t s, int sqrt_kind) {
@@ -375,6 +385,12 @@ std::string generate_source(const lol_program& P, const FastPaths* fast) {
 	}
 	s += "\tlol::store_pixel(L, P, lds);\n";
 	s += "}\n";
+	/* the SDF alone at arbitrary points (lol_gpu_sdf_batch) */
+	s += "extern \"C\" __global__ __launch_bounds__(64) void lol_sdf_spec(const float* pts, float* dist, lol::u32* id, lol::u32 n) {\n";
+	s += "\tlol::SpecSdfExact exact;\n";
+	if (any_fast) s += "\tlol::SpecSdfFast fast;\n\tlol::sdf_points(fast, exact, true, pts, dist, id, n);\n";
+	else          s += "\tlol::sdf_points(exact, exact, false, pts, dist, id, n);\n";
+	s += "}\n";
 	return s;
 }
 
@@ -499,6 +515,7 @@ FastPaths prove_fast_paths(lol_gpu* ctx, const lol_program& prog) {
 /* Compile + load the specialised kernel for ctx's program.  On failure the context keeps the interpreter. */
 bool specialise(lol_gpu* ctx) {
 	if (ctx->spec_module) { (void)hipModuleUnload(ctx->spec_module); ctx->spec_module = nullptr; ctx->spec_fn = nullptr; }
+	ctx->spec_sdf_fn = nullptr;
 	snprintf(ctx->kernel_name, sizeof ctx->kernel_name, "render_interp");
 	ctx->spec_log.clear();
 	const char* env = getenv("LOL_GPU_SPECIALIZE");
@@ -547,6 +564,7 @@ bool specialise(lol_gpu* ctx) {
 		ctx->spec_module = nullptr; ctx->spec_fn = nullptr;
 		return complain();
 	}
+	if (hipModuleGetFunction(&ctx->spec_sdf_fn, ctx->spec_module, "lol_sdf_spec") != hipSuccess) ctx->spec_sdf_fn = nullptr;
 	snprintf(ctx->kernel_name, sizeof ctx->kernel_name, "lol_render_spec");
 	return true;
 }
@@ -828,6 +846,29 @@ int lol_gpu_powf_batch(lol_gpu* ctx, const float* x_dev, const float* y_dev, flo
 	hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
 	hipLaunchKernelGGL(powf_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x_dev, y_dev, out_dev, n);
 	LOL_HIP(ctx, hipGetLastError());
+	return LOL_GPU_OK;
+}
+
+int lol_gpu_sdf_batch(lol_gpu* ctx, const float* pts_dev, float* dist_dev, uint32_t* id_dev, size_t n, void* stream) {
+	if (!ctx || !pts_dev || !dist_dev || !id_dev || n > 0xFFFFFFFFu) return LOL_GPU_ERR_ARG;
+	if (!ctx->have_prog) return fail(ctx, LOL_GPU_ERR_NO_PROGRAM, "no scene program uploaded");
+	if (n == 0) return LOL_GPU_OK;
+	LOL_HIP(ctx, hipSetDevice(ctx->device));
+	hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+	uint32_t n32 = (uint32_t)n;
+	hipError_t e;
+	if (ctx->spec_fn && ctx->spec_sdf_fn) {
+		void* args[] = { &pts_dev, &dist_dev, &id_dev, &n32 };
+		e = hipModuleLaunchKernel(ctx->spec_sdf_fn, (n32 + 63) / 64, 1, 1, 64, 1, 1, 0, s, args, nullptr);
+	} else {
+		const uint32_t need = ctx->h_prog.max_stack > 1 ? ctx->h_prog.max_stack - 1 : 1;
+		const int kind = ctx->interp_sqrt_kind;
+		if (need <= 1)      e = launch_sdf_interp<1>(ctx->d_mops, ctx->n_mops, pts_dev, dist_dev, id_dev, n32, s, kind);
+		else if (need <= 3) e = launch_sdf_interp<3>(ctx->d_mops, ctx->n_mops, pts_dev, dist_dev, id_dev, n32, s, kind);
+		else if (need <= 7) e = launch_sdf_interp<7>(ctx->d_mops, ctx->n_mops, pts_dev, dist_dev, id_dev, n32, s, kind);
+		else                e = launch_sdf_interp<LOL_MAX_STACK - 1>(ctx->d_mops, ctx->n_mops, pts_dev, dist_dev, id_dev, n32, s, kind);
+	}
+	if (e != hipSuccess) return fail(ctx, LOL_GPU_ERR_HIP, "sdf kernel launch", e);
 	return LOL_GPU_OK;
 }
 

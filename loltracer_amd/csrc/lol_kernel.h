@@ -697,4 +697,29 @@ void render_interp(const Launch L) {
 	store_pixel(L, P, lds);
 }
 
+/* Diagnostic: the scene SDF alone — sdf() of naive_renderer.c:31-44 — at arbitrary points, one per lane, through the
+ * same Sdf policies the frames use (lol_gpu_sdf_batch).  `fast` / `exact` as in the render kernels: a wave that fed
+ * the proven fast sqrt a squared length outside its domain evaluates again with the plain SDF. */
+template <class SdfFast, class SdfExact>
+__device__ __forceinline__ void sdf_points(SdfFast& fast, SdfExact& exact, bool have_fast, const float* pts, float* dist, u32* id, u32 n) {
+	const u32 i = blockIdx.x * 64u + threadIdx.x, j = i < n ? i : n - 1;
+	const V3 p = { pts[3 * j], pts[3 * j + 1], pts[3 * j + 2] };
+	float d; u32 k;
+	if (have_fast) {
+		fast.eval(p, d, k);
+		if (__ballot(fast.rg.outside()) != 0) exact.eval(p, d, k);
+	} else {
+		exact.eval(p, d, k);
+	}
+	if (i < n) { dist[i] = d; id[i] = k; }
+}
+
+template <int SSIZE, int KIND>
+__global__ __launch_bounds__(64)
+void sdf_points_interp(const u32* mops, u32 n_mops, const float* pts, float* dist, u32* id, u32 n) {
+	Interp<SSIZE, KIND> fast{ mops, n_mops, {} };
+	Interp<SSIZE, 0> exact{ mops, n_mops, {} };
+	sdf_points(fast, exact, KIND != 0, pts, dist, id, n);
+}
+
 }  // namespace lol

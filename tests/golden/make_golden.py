@@ -13,6 +13,13 @@ Outputs (all DATA — inputs and expected outputs, no reference source text):
                         grammar actions of scene-parser.y:99-145) and every block is handed to
                         scene.c's *_from_definition_list through liblol_ref.so; the resulting
                         struct scene is dumped field by field (floats as hex bit patterns).
+  ref_sdf_points.json   the scene SDF of the four example scenes at ~2000 points each, COMPOSED from the
+                        reference's own compiled pieces: the `struct object` tree built by scene.c is walked
+                        (this script, following naive_renderer.c:11-44: q = p - point; sphere / round box /
+                        plane; smooth_union = sminf(a, b, k) on the untranslated p; top level: first strict
+                        minimum, ids 1-based in file order) and every arithmetic step is a call into
+                        liblol_ref.so (v3sub, sdSphere, sdRoundBox, sminf).  Extends the pin from the primitives
+                        to rows a4/a5 of SURVEY.md §8 (tests/test_oracle.py checks lol_oracle_sdf against it).
   oracle_frames.npz     XRGB8888 frames + float RGB of the CPU ORACLE (not of the reference:
                         naive_renderer.c cannot be built here) — regression fixtures that
                         pin the oracle's output across toolchains / on the GPU box.
@@ -53,6 +60,7 @@ def load_ref():
     sig = {
         "ref_minf": ([f, f], f), "ref_maxf": ([f, f], f), "ref_clamp": ([f, f, f], f),
         "ref_lerp": ([f, f, f], f), "ref_sminf": ([f, f, f], f),
+        "ref_v3sub": ([f3, f3, f3], None),
         "ref_v3dot": ([f3, f3], f), "ref_v3len": ([f3], f), "ref_v3normalize": ([f3, f3], None),
         "ref_v3cross": ([f3, f3, f3], None), "ref_v3clamp": ([f3, f, f, f3], None),
         "ref_v3pow": ([f3, f, f3], None),
@@ -258,6 +266,62 @@ def dump_scene(ref, sc):
     return out
 
 
+# ---------------------------------------------- composed scene SDF from the reference's pieces
+
+def ref_object_dist(ref, optr, p3):
+    """get_obj_dist (naive_renderer.c:11-28) over the reference's own struct object, arithmetic by liblol_ref.so."""
+    t, m = C.c_int(), C.c_size_t()
+    pt, half = (C.c_float * 3)(), (C.c_float * 3)()
+    rad, smooth = C.c_float(), C.c_float()
+    a, b = C.c_void_p(), C.c_void_p()
+    ref.ref_object_fields(optr, C.byref(t), C.byref(m), pt, C.cast(C.byref(rad), C.POINTER(C.c_float)), half,
+                          C.cast(C.byref(smooth), C.POINTER(C.c_float)), C.byref(a), C.byref(b))
+    kind = TYPES[t.value]
+    if kind == "smooth_union":                      # children get the untranslated p; a before b
+        da = ref_object_dist(ref, a, p3)
+        db = ref_object_dist(ref, b, p3)
+        return ref.ref_sminf(da, db, smooth.value)
+    q = (C.c_float * 3)()
+    ref.ref_v3sub(p3, pt, q)
+    if kind == "sphere":
+        return ref.ref_sd_sphere(q, rad.value)
+    if kind == "box":
+        return ref.ref_sd_round_box(q, half, rad.value)
+    assert kind == "plane", kind
+    return q[1]
+
+
+def ref_scene_sdf(ref, sc, p):
+    """sdf() (naive_renderer.c:31-44): {+inf, 0}, strict '<' over the top-level objects, ids 1-based."""
+    p3 = (C.c_float * 3)(*p)
+    best, best_id = float("inf"), 0
+    for i in range(ref.ref_scene_counts(sc, 2)):
+        d = ref_object_dist(ref, ref.ref_scene_object(sc, i), p3)
+        if d < best:
+            best, best_id = d, i + 1
+    return best, best_id
+
+
+def gen_sdf_points(ref, sc, cam, seed):
+    rng = np.random.default_rng(seed)
+    pts = []
+    for _ in range(1200):                                         # the volume the example scenes live in
+        pts.append(rng.uniform([-16, -3, -22], [16, 12, 6]))
+    o, d = np.array(cam[:3], dtype=np.float64), np.array(cam[3:6], dtype=np.float64)
+    for _ in range(700):                                          # along view rays, where the renderer samples
+        r = d / np.linalg.norm(d) + rng.normal(size=3) * 0.8
+        pts.append(o + r / np.linalg.norm(r) * rng.uniform(0, 40))
+    for v in ([0, 0, 0], [0, -1, 0], [0, 1, -6], [1e-30, -1, 3e-39], [1e6, 2e6, -3e6], [-0.0, -0.0, -0.0],
+              [float("inf"), 0, 0], [float("nan"), 1, 1], [3e38, 3e38, 3e38]):
+        pts.append(np.array(v, dtype=np.float64))
+    out = []
+    for p in pts:
+        pf = [float(np.float32(v)) for v in p]
+        dist, oid = ref_scene_sdf(ref, sc, pf)
+        out.append([[f2h(v) for v in pf], f2h(dist), oid])
+    return out
+
+
 def main():
     if not os.path.exists(REF_SO):
         raise SystemExit("oracle/_ref/liblol_ref.so missing: run `make -C oracle ref` where /root/reference exists")
@@ -267,12 +331,18 @@ def main():
         json.dump({"source": "reference float.h/vec.h/sdf.h via oracle/_ref/liblol_ref.so", "vectors": gen_primitives(ref)},
                   f, separators=(",", ":"))
 
-    scenes = {}
-    for name in ("scene", "scene2", "scene3", "scene4"):
+    scenes, sdf_points = {}, {}
+    for k, name in enumerate(("scene", "scene2", "scene3", "scene4")):
         text = open(os.path.join(HERE, "scenes", name + ".lol")).read()
         sc = Walker(ref, text).run()
         scenes[name] = dump_scene(ref, sc)
+        sdf_points[name] = gen_sdf_points(ref, sc, [h2f(v) for v in scenes[name]["camera"]], 20261004 + k)
         ref.ref_scene_free(sc)
+    with open(os.path.join(HERE, "ref_sdf_points.json"), "w") as f:
+        json.dump({"source": "scene SDF composed from the reference's scene.c object tree + float.h/vec.h/sdf.h functions "
+                             "via oracle/_ref/liblol_ref.so (walk: make_golden.py ref_scene_sdf, after naive_renderer.c:11-44)",
+                   "format": "[[px,py,pz], dist, id] — floats as binary32 hex", "points": sdf_points},
+                  f, separators=(",", ":"))
     sizes = dict(zip(["material", "light", "object", "camera", "scene", "vector"], [ref.ref_sizeof(i) for i in range(6)]))
     with open(os.path.join(HERE, "ref_scenes.json"), "w") as f:
         json.dump({"source": "reference scene.c builders via oracle/_ref/liblol_ref.so", "abi_sizes": sizes,
@@ -289,7 +359,7 @@ def main():
         if w == 64:
             frames[f"{name}_{w}x{h}_rgb"] = rgb
     np.savez_compressed(os.path.join(HERE, "oracle_frames.npz"), **frames)
-    print("wrote ref_primitives.json, ref_scenes.json, oracle_frames.npz")
+    print("wrote ref_primitives.json, ref_scenes.json, ref_sdf_points.json, oracle_frames.npz")
 
 
 if __name__ == "__main__":

@@ -109,7 +109,9 @@ def test_frame_matches_oracle(torch_cuda, renderer, scenes, name, w, h):
     sc = scenes[name]
     g = gpu_render(torch_cuda, renderer, sc, w, h)
     mism = check_against_oracle(g, sc, w, h)
-    assert mism <= max(4, w * h // 2000), f"{mism} packed pixels differ (1-LSB powf straddles expected to be rare)"
+    # On an FMA host (the GPU box is one) check_against_oracle has already required bit-identical colours and packed
+    # pixels; elsewhere the host's other powf variant may move a channel by one step where c*255 straddles an integer.
+    assert mism == 0 if HOST_LIBM_IS_FMA_VARIANT else mism <= max(4, w * h // 2000), f"{mism} packed pixels differ"
 
 
 def test_hit_distance_and_id_bit_exact(torch_cuda, renderer, scenes):

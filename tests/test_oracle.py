@@ -5,8 +5,9 @@
    the oracle's restated primitives must agree bit for bit.
 2. Known answers recorded by the survey from the unmodified naive_renderer.c:
    centre / corner pixels and the per-pixel work counters (sdf evaluations, march steps, shadow steps).
-   The survey's whole-frame hashes are NOT reproduced by this oracle (see test below and DESIGN.md).
-3. tests/golden/oracle_frames.npz — regression frames of the oracle itself (pins it across toolchains).
+   (The survey's five whole-frame hashes are not used: they do not describe the shipped scene files.)
+3. tests/golden/ref_sdf_points.json — the scene SDF composed from the reference's own object tree and primitives.
+4. tests/golden/oracle_frames.npz — regression frames of the oracle itself (pins it across toolchains).
 """
 import ctypes as C
 import json
@@ -125,14 +126,28 @@ def test_survey_step_split_at_960x540(scenes):
     assert round(c.march_steps / c.pixels, 1) == 26.7 and round(c.shadow_steps / c.pixels, 1) == 8.4
 
 
-def test_survey_frame_hashes_are_not_reproduced(scenes):
-    """Recorded honestly: the survey's FNV hashes of whole frames (scenes entered by hand there) do not
-    match this oracle's frames, although the known pixels and work counters above do.  If this test ever
-    starts failing (= a hash matches), upgrade it to an equality pin."""
-    survey = {("scene", 256, 256): 0x0BB4455C37481D40, ("scene4", 256, 256): 0x33D944995ECB6BAB}
-    for (name, w, h), want in survey.items():
-        x, _, _ = O.render(scenes[name], w, h, threads=4)
-        assert O.hash_xrgb(x) != want
+# ---- the scene SDF, composed from the reference's own pieces (tests/golden/ref_sdf_points.json) ---------
+
+@pytest.mark.parametrize("name", ["scene", "scene2", "scene3", "scene4"])
+def test_scene_sdf_matches_the_reference_composition(scenes, name):
+    """Rows a4 / a5 of SURVEY.md §8: sdf() and get_obj_dist() (naive_renderer.c:11-44).  The fixture holds, for ~1900
+    points per example scene (volume samples, points along view rays, NaN / inf / denormal coordinates), the distance
+    and object id obtained by walking the reference's OWN struct object tree (built by its scene.c) with its OWN
+    compiled v3sub / sdSphere / sdRoundBox / sminf — see tests/golden/make_golden.py.  The oracle's sdf (tree walk,
+    smooth-union operand order, strict '<' with 1-based ids) must agree bit for bit, id included."""
+    pts = json.load(open(os.path.join(HERE, "golden", "ref_sdf_points.json")))["points"][name]
+    assert len(pts) > 1500
+    l = O.lib()
+    l.lol_oracle_sdf.restype = C.c_float
+    l.lol_oracle_sdf.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_uint32)]
+    ids_seen = set()
+    for p, want, want_id in pts:
+        oid = C.c_uint32(99)
+        got = l.lol_oracle_sdf(scenes[name].ptr, h2f(p[0]), h2f(p[1]), h2f(p[2]), C.byref(oid))
+        assert same(got, want), (name, p, f2h(got), want)
+        assert oid.value == want_id, (name, p, oid.value, want_id)
+        ids_seen.add(want_id)
+    assert len(ids_seen) >= 2                       # more than one object wins somewhere
 
 
 # ---- regression frames of the oracle ---------------------------------------------------------------
