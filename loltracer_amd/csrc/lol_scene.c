@@ -157,9 +157,14 @@ struct def { enum tok prop; struct value v; };
 
 struct deflist { struct def* d; size_t n, cap; };
 
+/* Objects nest through `a = smooth_union { ... }`.  parse_value / parse_deflist recurse once per level, so the
+ * depth is bounded: a chain this deep could never be flattened anyway (2 ops per level, LOL_MAX_OPS = 1024). */
+#define LOL_PARSE_MAX_DEPTH 1024
+
 struct parser {
 	struct lexer lx;
 	lol_scene*   scene;
+	int          depth;      /* current object nesting */
 	int          status;
 	char*        err;
 	size_t       errcap;
@@ -379,8 +384,14 @@ static void parse_value(struct parser* p, struct value* v, struct caps* caps) {
 		enum comp type = (enum comp)(t - T_AMBIENT);
 		lex_next(&p->lx);
 		if (!expect(p, T_LBRACE)) return;
+		if (p->depth >= LOL_PARSE_MAX_DEPTH) {
+			fail(p, LOL_ERR_UNSUPPORTED, "objects nested deeper than %d levels", LOL_PARSE_MAX_DEPTH);
+			return;
+		}
 		struct deflist dl = { 0, 0, 0 };
+		p->depth++;
 		parse_deflist(p, &dl, caps);
+		p->depth--;
 		if (p->status == LOL_OK) expect(p, T_RBRACE);
 		if (p->status == LOL_OK) {
 			/* object_from_definition_list, scene.c:266-281 */
@@ -566,23 +577,29 @@ int lol_scene_validate_materials(const lol_scene* s) {
 
 /* --------------------------------------------------------------- flatten */
 
-static int su_need(const lol_scene* s, int32_t idx, int depth) {
+/* Sethi-Ullman number of every node reachable from `idx`, memoised in need[] (0 = not yet computed): the operand
+ * stack depth its subtree needs when the deeper child is emitted first.  -1: bad index or deeper than 4096 levels. */
+static int su_need(const lol_scene* s, int32_t idx, int depth, int16_t* need) {
 	if (idx < 0 || (size_t)idx >= s->n_nodes || depth > 4096) return -1;
+	if (need[idx]) return need[idx];
 	const lol_node* n = &s->nodes[idx];
-	if (n->type != LOL_NODE_SMOOTH_UNION) return 1;
-	int l = su_need(s, n->a, depth + 1), r = su_need(s, n->b, depth + 1);
-	if (l < 0 || r < 0) return -1;
-	return l == r ? l + 1 : (l > r ? l : r);
+	int v = 1;
+	if (n->type == LOL_NODE_SMOOTH_UNION) {
+		int l = su_need(s, n->a, depth + 1, need), r = su_need(s, n->b, depth + 1, need);
+		if (l < 0 || r < 0) return -1;
+		v = l == r ? l + 1 : (l > r ? l : r);
+	}
+	need[idx] = (int16_t)v;
+	return v;
 }
 
-static int emit(const lol_scene* s, int32_t idx, lol_program* out) {
+static int emit(const lol_scene* s, int32_t idx, lol_program* out, const int16_t* need) {
 	const lol_node* n = &s->nodes[idx];
+	const int swap = n->type == LOL_NODE_SMOOTH_UNION && need[n->b] > need[n->a];
 	if (n->type == LOL_NODE_SMOOTH_UNION) {
-		int l = su_need(s, n->a, 0), r = su_need(s, n->b, 0);
-		int swap = r > l;
-		int st = emit(s, swap ? n->b : n->a, out);
+		int st = emit(s, swap ? n->b : n->a, out, need);
 		if (st != LOL_OK) return st;
-		st = emit(s, swap ? n->a : n->b, out);
+		st = emit(s, swap ? n->a : n->b, out, need);
 		if (st != LOL_OK) return st;
 	}
 	if (out->n_ops >= LOL_MAX_OPS) return LOL_ERR_UNSUPPORTED;
@@ -605,7 +622,7 @@ static int emit(const lol_scene* s, int32_t idx, lol_program* out) {
 		op->f[0] = n->point.y;
 		break;
 	case LOL_NODE_SMOOTH_UNION:
-		op->op = su_need(s, n->b, 0) > su_need(s, n->a, 0) ? LOL_OP_SMIN_R : LOL_OP_SMIN;
+		op->op = swap ? LOL_OP_SMIN_R : LOL_OP_SMIN;
 		op->f[0] = n->smoothness;
 		break;
 	default:
@@ -629,20 +646,24 @@ int lol_scene_flatten(const lol_scene* s, lol_program* out) {
 	memcpy(out->lights, s->lights, s->n_lights * sizeof *s->lights);
 	memcpy(out->materials, s->materials, s->n_materials * sizeof *s->materials);
 
-	for (size_t i = 0; i < s->n_roots; i++) {
-		int need = su_need(s, s->roots[i], 0);
-		if (need < 0 || need > LOL_MAX_STACK) return LOL_ERR_UNSUPPORTED;
+	int16_t* memo = calloc(s->n_nodes ? s->n_nodes : 1, sizeof *memo);
+	if (!memo) return LOL_ERR_NOMEM;
+	int status = LOL_OK;
+	for (size_t i = 0; i < s->n_roots && status == LOL_OK; i++) {
+		int need = su_need(s, s->roots[i], 0, memo);
+		if (need < 0 || need > LOL_MAX_STACK) { status = LOL_ERR_UNSUPPORTED; break; }
 		if ((uint32_t)need > out->max_stack) out->max_stack = (uint32_t)need;
-		int st = emit(s, s->roots[i], out);
-		if (st != LOL_OK) return st;
-		if (out->n_ops >= LOL_MAX_OPS) return LOL_ERR_UNSUPPORTED;
+		status = emit(s, s->roots[i], out, memo);
+		if (status != LOL_OK) break;
+		if (out->n_ops >= LOL_MAX_OPS) { status = LOL_ERR_UNSUPPORTED; break; }
 		lol_op* top = &out->ops[out->n_ops++];
 		memset(top, 0, sizeof *top);
 		top->op = LOL_OP_TOP;
 		top->id = (uint32_t)(i + 1);
 		out->root_material[i] = s->nodes[s->roots[i]].material;
 	}
-	return LOL_OK;
+	free(memo);
+	return status;
 }
 
 /* ---------------------------------------------------------------- camera */
