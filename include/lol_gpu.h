@@ -154,6 +154,13 @@ int         lol_gpu_verify_fast_paths(lol_gpu* ctx, float k, unsigned long long 
 int         lol_gpu_set_miss_skip(lol_gpu* ctx, int enable);
 int         lol_gpu_miss_skip_active(const lol_gpu* ctx);
 /*
+ * Exact culling of top-level objects in the specialised kernel (lol_gpu.hip, "exact culling"): sdf() is a strict-'<'
+ * minimum over the objects (naive_renderer.c:31-44), so an object that a bounding sphere PROVES farther away than the
+ * running minimum is not evaluated — for a whole wavefront at a time, and only then.  Same pixels, same step counts.
+ * On by default; set_cull(ctx, 0) before the upload or LOL_GPU_CULL=0 turn it off.
+ */
+int         lol_gpu_set_cull(lol_gpu* ctx, int enable);
+/*
  * Diagnostic: out[i] = the renderer's powf(x[i], y[i]) (device pointers, asynchronous on `stream`, NULL = the
  * context's stream).  The kernel's powf restates the algorithm of the CPU libm's powf so that colours round
  * identically on both sides (lol_kernel.h, powf_glibc); this entry point lets a test compare the two bit for bit.

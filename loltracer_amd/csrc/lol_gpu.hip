@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 #include <dlfcn.h>
+#include <cmath>
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
@@ -57,6 +58,7 @@ struct lol_gpu {
 	std::string  spec_log;
 	int          want_fast = 1;          /* allow the proven-exact shortcuts in the specialised kernel */
 	int          want_miss_skip = 1;     /* allow FLAG_MISS_SKIP when the program qualifies */
+	int          want_cull = 1;          /* allow the exact culling of top-level objects (plan_culling) */
 	bool         miss_skip = false;      /* the uploaded program qualifies (miss_skip_ok) */
 	bool         dark_skip = false;      /* the uploaded program qualifies (dark_skip_ok) */
 	int          interp_sqrt_kind = 0;   /* fast sqrt of the interpreter: 3 (sqrt_r2) when proven and allowed, else 0 */
@@ -274,66 +276,242 @@ std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast) {
 	return out;
 }
 
-/* Emits one `struct <name>` with eval(): one SSA temporary per op, same operation order as the post-order program.
+/* ------------------------------------------------ exact culling of top-level objects
+ * sdf() (naive_renderer.c:31-44) is a strict-'<' minimum over the top-level objects.  An object whose distance is
+ * PROVABLY greater than the running minimum cannot change it, so its evaluation may be skipped — exactly, not
+ * approximately.  The proof is a bounding sphere (C, R) per object, computed here in double precision:
+ *   sphere(c, r):            value = |p-c| - r                                        → (c, max(r, 0))
+ *   round box(c, b, r):      value >= |p-c| - |b| - r   (b >= 0, r >= 0)               → (c, |b| + r)
+ *   smooth_union(a, b, k>0): value >= min(a, b) - k/4   (h(1-h) <= 1/4 on the clamped h) → sphere enclosing both + k/4
+ *   plane, k <= 0, non-finite or absurdly large fields:                                 no bound — never skipped
+ * so value(p) >= |p-C| - R in exact arithmetic.  The kernel's binary32 evaluation differs from that by a few ulps
+ * of the magnitudes involved (<= 2^-19 relative to |p-C| + R), which the test below swallows:
+ *   R' = R (1 + 2^-10) + (|C|_max + 1) 2^-20, rounded up;   u = (best + R') (1 + 2^-12);
+ *   skip  iff  u > 0  and  |p-C|^2 > u^2      (all in binary32; any NaN makes the comparisons false = no skip)
+ * which implies |p-C| > (best + R')(1 + 2^-14), hence value(p) > best.  The decision is taken per WAVE: the
+ * object is evaluated unless every lane that still cares about the result may skip it (lanes that may skip but
+ * run anyway compute a value > best and change nothing).
+ *
+ * To have a running minimum to compare with, objects WITHOUT a bound (planes: one subtraction) are evaluated first
+ * and the bounded ones after them, each group in file order.  The reference's tie rule — the FIRST object of
+ * equal distance wins — is kept by comparing ids on ties wherever an object is evaluated after one that follows
+ * it in the file:  t < best || (t == best && best_id > id)   (best_id = 0 only while best = +inf, where the
+ * reference's inf < inf is false too). */
+struct RootBound {
+	uint32_t first = 0, top = 0;        /* ops [first, top) compute the object, ops[top] is its LOL_OP_TOP */
+	uint32_t id = 0, prims = 0;
+	bool     bounded = false;
+	double   c[3] = { 0, 0, 0 }, r = 0;
+};
+
+struct Sphere { bool ok; double c[3], r; };
+
+Sphere enclose(const Sphere& a, const Sphere& b) {
+	if (!a.ok || !b.ok) return { false, { 0, 0, 0 }, 0 };
+	const double dx = b.c[0] - a.c[0], dy = b.c[1] - a.c[1], dz = b.c[2] - a.c[2];
+	const double d = sqrt(dx * dx + dy * dy + dz * dz);
+	if (d + b.r <= a.r) return a;
+	if (d + a.r <= b.r) return b;
+	const double R = 0.5 * (d + a.r + b.r), t = d > 0 ? (R - a.r) / d : 0.0;
+	return { true, { a.c[0] + dx * t, a.c[1] + dy * t, a.c[2] + dz * t }, R * (1.0 + 1e-12) };
+}
+
+std::vector<RootBound> analyse_roots(const lol_program& P) {
+	std::vector<RootBound> roots;
+	std::vector<Sphere> st;
+	auto sane = [](double v) { return v - v == 0.0 && fabs(v) < 1e15; };
+	RootBound cur;
+	for (uint32_t i = 0; i < P.n_ops; i++) {
+		const lol_op& o = P.ops[i];
+		switch (o.op) {
+		case LOL_OP_SPHERE: {
+			const bool ok = sane(o.f[0]) && sane(o.f[1]) && sane(o.f[2]) && sane(o.f[3]);
+			st.push_back({ ok, { o.f[0], o.f[1], o.f[2] }, o.f[3] > 0 ? (double)o.f[3] : 0.0 });
+			cur.prims++;
+			break;
+		}
+		case LOL_OP_RBOX: {
+			bool ok = true;
+			for (int j = 0; j < 7; j++) ok = ok && sane(o.f[j]);
+			ok = ok && o.f[3] >= 0 && o.f[4] >= 0 && o.f[5] >= 0 && o.f[6] >= 0;
+			const double hb = sqrt((double)o.f[3] * o.f[3] + (double)o.f[4] * o.f[4] + (double)o.f[5] * o.f[5]);
+			st.push_back({ ok, { o.f[0], o.f[1], o.f[2] }, hb * (1.0 + 1e-12) + o.f[6] });
+			cur.prims++;
+			break;
+		}
+		case LOL_OP_PLANE:
+			st.push_back({ false, { 0, 0, 0 }, 0 });
+			cur.prims++;
+			break;
+		case LOL_OP_SMIN: case LOL_OP_SMIN_R: {
+			Sphere b = st.back(); st.pop_back();
+			Sphere a = st.back(); st.pop_back();
+			Sphere u = enclose(a, b);
+			if (!(sane(o.f[0]) && o.f[0] > 0)) u.ok = false;
+			u.r += 0.25 * (double)o.f[0];
+			st.push_back(u);
+			break;
+		}
+		case LOL_OP_TOP: {
+			Sphere v = st.back(); st.pop_back();
+			cur.top = i; cur.id = o.id;
+			cur.bounded = v.ok && sane(v.r);
+			cur.c[0] = v.c[0]; cur.c[1] = v.c[1]; cur.c[2] = v.c[2]; cur.r = v.r;
+			roots.push_back(cur);
+			cur = RootBound();
+			cur.first = i + 1;
+			break;
+		}
+		}
+	}
+	return roots;
+}
+
+struct CullTest { float c[3]; float rm; };
+
+/* the in-kernel test's constants from a double-precision bound: centre rounded to binary32, radius inflated
+ * (see the derivation above; the centre's rounding error is covered by the |C| 2^-20 term) */
+CullTest make_test(const Sphere& b) {
+	CullTest t;
+	double cmax = 0;
+	for (int j = 0; j < 3; j++) { t.c[j] = (float)b.c[j]; cmax = fmax(cmax, fabs(b.c[j])); }
+	const double rm = b.r * (1.0 + 0x1p-10) + (cmax + 1.0) * 0x1p-20;
+	t.rm = nextafterf((float)rm, INFINITY);
+	return t;
+}
+
+struct CullPlan {
+	std::vector<uint32_t> order;          /* evaluation order: indices into the root list */
+	size_t   n_unbounded = 0;             /* the first n_unbounded entries of `order` have no bound */
+	bool     group = false;               /* one test in front of the whole bounded block */
+	CullTest group_test{};
+	std::vector<int> own_test;            /* per root (by index into roots): index into `tests` or -1 */
+	std::vector<CullTest> tests;
+};
+
+bool culling_enabled(int want) {
+	const char* e = getenv("LOL_GPU_CULL");
+	return want && !(e && e[0] == '0');
+}
+
+CullPlan plan_culling(const std::vector<RootBound>& roots, bool enabled) {
+	CullPlan plan;
+	plan.own_test.assign(roots.size(), -1);
+	std::vector<uint32_t> bounded;
+	if (enabled)
+		for (uint32_t i = 0; i < roots.size(); i++) (roots[i].bounded ? bounded : plan.order).push_back(i);
+	else
+		for (uint32_t i = 0; i < roots.size(); i++) plan.order.push_back(i);
+	plan.n_unbounded = plan.order.size();
+	if (!enabled || bounded.empty()) return plan;
+	plan.order.insert(plan.order.end(), bounded.begin(), bounded.end());
+	/* a running minimum exists once something has been evaluated: the group test needs an unbounded object in
+	 * front; an object's own test needs anything in front, and pays only for objects of several primitives */
+	if (plan.n_unbounded > 0) {
+		Sphere g = { true, { roots[bounded[0]].c[0], roots[bounded[0]].c[1], roots[bounded[0]].c[2] }, roots[bounded[0]].r };
+		for (size_t k = 1; k < bounded.size(); k++) {
+			const RootBound& r = roots[bounded[k]];
+			g = enclose(g, { true, { r.c[0], r.c[1], r.c[2] }, r.r });
+		}
+		plan.group = true;
+		plan.group_test = make_test(g);
+	}
+	if (bounded.size() >= 2)
+		for (size_t k = 0; k < bounded.size(); k++) {
+			const RootBound& r = roots[bounded[k]];
+			if (r.prims < 3 || (k == 0 && plan.n_unbounded == 0)) continue;
+			plan.own_test[bounded[k]] = (int)plan.tests.size();
+			plan.tests.push_back(make_test({ true, { r.c[0], r.c[1], r.c[2] }, r.r }));
+		}
+	return plan;
+}
+
+/* Emits one `struct <name>` with eval(): one SSA temporary per op, same operation order WITHIN every top-level object
+ * as the post-order program; the objects themselves in the order of `plan` (file order when culling is off).
  * out_of_line: the body becomes ONE real function (`<name>_fn`, __noinline__) that the march, normal and shadow
  * loops call, instead of being inlined into each of them — for large scenes, whose straight-line SDF would
  * otherwise be replicated six times (three loops x fast / exact) and outgrow the instruction cache. */
-void emit_sdf(std::string& s, const lol_program& P, const char* name, const FastPaths* fast, bool out_of_line) {
-	char line[640];
+void emit_sdf(std::string& s, const lol_program& P, const char* name, const FastPaths* fast, bool out_of_line,
+              const std::vector<RootBound>& roots, const CullPlan& plan) {
+	char line[768];
 	const int fsqrt = fast ? fast->sqrt_kind : 0;
 	char fs[32] = "";
 	if (fsqrt) snprintf(fs, sizeof fs, "_fast<%d>", fsqrt);
 	if (out_of_line) {
-		snprintf(line, sizeof line, "__device__ __noinline__ SdfOut %s_fn(float px, float py, float pz, u32 rg_lo, u32 rg_hi) {\n"
+		snprintf(line, sizeof line, "__device__ __noinline__ SdfOut %s_fn(float px, float py, float pz, u32 rg_lo, u32 rg_hi, bool care) {\n"
 		         "\t\tconst V3 p = { px, py, pz };\n\t\tRange rg; rg.lo = rg_lo; rg.hi = rg_hi;\n\t\tfloat best; u32 best_id;\n", name);
 		s += line;
 	} else {
 		snprintf(line, sizeof line, "struct %s {\n\tRange rg;\n", name);
 		s += line;
-		s += "\t__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id) {\n";
+		s += "\t__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id, bool care = true) {\n";
 	}
 	s += "\t\tbest = __builtin_inff(); best_id = 0u;\n";
-	std::vector<int> stack;
-	int t = 0;
-	for (uint32_t i = 0; i < P.n_ops; i++) {
-		const lol_op& o = P.ops[i];
-		switch (o.op) {
-		case LOL_OP_SPHERE:
-			snprintf(line, sizeof line, "\t\tconst float t%d = sd_sphere%s(p, %s, %s, %s, %s%s);\n", t, fs,
-			         fbits(o.f[0]).c_str(), fbits(o.f[1]).c_str(), fbits(o.f[2]).c_str(), fbits(o.f[3]).c_str(),
-			         fsqrt ? ", rg" : "");
-			s += line; stack.push_back(t++); break;
-		case LOL_OP_RBOX:
-			snprintf(line, sizeof line, "\t\tconst float t%d = sd_round_box%s(p, %s, %s, %s, %s, %s, %s, %s%s);\n", t,
-			         fs,
-			         fbits(o.f[0]).c_str(), fbits(o.f[1]).c_str(), fbits(o.f[2]).c_str(), fbits(o.f[3]).c_str(),
-			         fbits(o.f[4]).c_str(), fbits(o.f[5]).c_str(), fbits(o.f[6]).c_str(), fsqrt ? ", rg" : "");
-			s += line; stack.push_back(t++); break;
-		case LOL_OP_PLANE:
-			snprintf(line, sizeof line, "\t\tconst float t%d = p.y - %s;\n", t, fbits(o.f[0]).c_str());
-			s += line; stack.push_back(t++); break;
-		case LOL_OP_SMIN: case LOL_OP_SMIN_R: {
-			int top = stack.back(); stack.pop_back();
-			int under = stack.back(); stack.pop_back();
-			int a = o.op == LOL_OP_SMIN ? under : top, b = o.op == LOL_OP_SMIN ? top : under;
-			if (fast && fast->has(o.f[0]))
-				snprintf(line, sizeof line, "\t\tconst float t%d = sminf_fastdiv(t%d, t%d, %s, %s, %s);\n", t, a, b,
-				         fbits(o.f[0]).c_str(), fbits(2.0f * o.f[0]).c_str(), fbits(0.5f * (1.0f / o.f[0])).c_str());
-			else
-				snprintf(line, sizeof line, "\t\tconst float t%d = sminf_(t%d, t%d, %s);\n", t, a, b, fbits(o.f[0]).c_str());
-			s += line; stack.push_back(t++); break;
+	int t = 0, n_tests = 0;
+	auto open_test = [&](const CullTest& ct) {
+		const int k = n_tests++;
+		snprintf(line, sizeof line,
+		         "\t\t{ const float cx%d = p.x - %s, cy%d = p.y - %s, cz%d = p.z - %s;\n"
+		         "\t\t  const float cl%d = (cx%d * cx%d + cy%d * cy%d) + cz%d * cz%d;\n"
+		         "\t\t  const float cu%d = (best + %s) * %s;\n"
+		         "\t\t  const bool skip%d = cl%d > cu%d * cu%d && cu%d > 0.f;\n"
+		         "\t\t  if (__ballot(care && !skip%d) != 0) {\n",
+		         k, fbits(ct.c[0]).c_str(), k, fbits(ct.c[1]).c_str(), k, fbits(ct.c[2]).c_str(),
+		         k, k, k, k, k, k, k, k, fbits(ct.rm).c_str(), fbits(1.0f + 0x1p-12f).c_str(), k, k, k, k, k, k);
+		s += line;
+	};
+	uint32_t max_id_seen = 0;
+	for (size_t oi = 0; oi < plan.order.size(); oi++) {
+		const RootBound& R = roots[plan.order[oi]];
+		if (plan.group && oi == plan.n_unbounded) open_test(plan.group_test);
+		const int own = plan.own_test[plan.order[oi]];
+		if (own >= 0) open_test(plan.tests[own]);
+		std::vector<int> stack;
+		for (uint32_t i = R.first; i < R.top; i++) {
+			const lol_op& o = P.ops[i];
+			switch (o.op) {
+			case LOL_OP_SPHERE:
+				snprintf(line, sizeof line, "\t\tconst float t%d = sd_sphere%s(p, %s, %s, %s, %s%s);\n", t, fs,
+				         fbits(o.f[0]).c_str(), fbits(o.f[1]).c_str(), fbits(o.f[2]).c_str(), fbits(o.f[3]).c_str(),
+				         fsqrt ? ", rg" : "");
+				s += line; stack.push_back(t++); break;
+			case LOL_OP_RBOX:
+				snprintf(line, sizeof line, "\t\tconst float t%d = sd_round_box%s(p, %s, %s, %s, %s, %s, %s, %s%s);\n", t,
+				         fs,
+				         fbits(o.f[0]).c_str(), fbits(o.f[1]).c_str(), fbits(o.f[2]).c_str(), fbits(o.f[3]).c_str(),
+				         fbits(o.f[4]).c_str(), fbits(o.f[5]).c_str(), fbits(o.f[6]).c_str(), fsqrt ? ", rg" : "");
+				s += line; stack.push_back(t++); break;
+			case LOL_OP_PLANE:
+				snprintf(line, sizeof line, "\t\tconst float t%d = p.y - %s;\n", t, fbits(o.f[0]).c_str());
+				s += line; stack.push_back(t++); break;
+			case LOL_OP_SMIN: case LOL_OP_SMIN_R: {
+				int top = stack.back(); stack.pop_back();
+				int under = stack.back(); stack.pop_back();
+				int a = o.op == LOL_OP_SMIN ? under : top, b = o.op == LOL_OP_SMIN ? top : under;
+				if (fast && fast->has(o.f[0]))
+					snprintf(line, sizeof line, "\t\tconst float t%d = sminf_fastdiv(t%d, t%d, %s, %s, %s);\n", t, a, b,
+					         fbits(o.f[0]).c_str(), fbits(2.0f * o.f[0]).c_str(), fbits(0.5f * (1.0f / o.f[0])).c_str());
+				else
+					snprintf(line, sizeof line, "\t\tconst float t%d = sminf_(t%d, t%d, %s);\n", t, a, b, fbits(o.f[0]).c_str());
+				s += line; stack.push_back(t++); break;
+			}
+			default: break;
+			}
 		}
-		case LOL_OP_TOP: {
-			int d = stack.back(); stack.pop_back();
-			snprintf(line, sizeof line, "\t\tif (t%d < best) { best = t%d; best_id = %uu; }\n", d, d, o.id);
-			s += line; break;
-		}
-		}
+		const int d = stack.back();
+		if (R.id < max_id_seen)      /* evaluated after an object that follows it in the file: ties go to the lower id */
+			snprintf(line, sizeof line, "\t\tif (t%d < best || (t%d == best && best_id > %uu)) { best = t%d; best_id = %uu; }\n", d, d, R.id, d, R.id);
+		else
+			snprintf(line, sizeof line, "\t\tif (t%d < best) { best = t%d; best_id = %uu; }\n", d, d, R.id);
+		s += line;
+		if (R.id > max_id_seen) max_id_seen = R.id;
+		if (own >= 0) s += "\t\t} }\n";
 	}
+	if (plan.group) s += "\t\t} }\n";
 	if (out_of_line) {
 		s += "\t\treturn { best, best_id, rg.lo, rg.hi };\n}\n";
-		snprintf(line, sizeof line, "struct %s {\n\tRange rg;\n\t__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id) {\n"
-		         "\t\tconst SdfOut o = %s_fn(p.x, p.y, p.z, rg.lo, rg.hi);\n"
+		snprintf(line, sizeof line, "struct %s {\n\tRange rg;\n\t__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id, bool care = true) {\n"
+		         "\t\tconst SdfOut o = %s_fn(p.x, p.y, p.z, rg.lo, rg.hi, care);\n"
 		         "\t\tbest = o.best; best_id = o.id; rg.lo = o.lo; rg.hi = o.hi;\n\t}\n};\n", name, name);
 		s += line;
 	} else {
@@ -358,15 +536,17 @@ bool spec_out_of_line(const lol_program& P) {
 	return P.n_ops > limit;
 }
 
-std::string generate_source(const lol_program& P, const FastPaths* fast) {
+std::string generate_source(const lol_program& P, const FastPaths* fast, bool cull) {
 	std::string s;
 	const bool ool = spec_out_of_line(P);
+	const std::vector<RootBound> roots = analyse_roots(P);
+	const CullPlan plan = plan_culling(roots, cull);
 	s += "#include \"lol_kernel.h\"\n";
 	s += "namespace lol {\n";
 	if (ool) s += "struct SdfOut { float best; u32 id; u32 lo, hi; };\n";
-	emit_sdf(s, P, "SpecSdfExact", nullptr, ool);
+	emit_sdf(s, P, "SpecSdfExact", nullptr, ool, roots, plan);
 	const bool any_fast = fast && (fast->sqrt_kind || !fast->div_ok.empty());
-	if (any_fast) emit_sdf(s, P, "SpecSdfFast", fast, ool);
+	if (any_fast) emit_sdf(s, P, "SpecSdfFast", fast, ool, roots, plan);
 	s += "}  // namespace lol\n";
 	s += "extern \"C\" __global__ __launch_bounds__(lol::BLOCK) void lol_render_spec(const lol::Launch L) {\n";
 	s += "\textern __shared__ lol::u32 lds[];\n";
@@ -422,8 +602,8 @@ std::mutex g_cache_mutex;
 std::unordered_map<std::string, std::vector<char>> g_code_cache;
 
 bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string& arch, std::vector<char>& code,
-                  std::string& log, std::string* src_out = nullptr, const int* shape = nullptr) {
-	std::string src = generate_source(P, fast);
+                  std::string& log, std::string* src_out = nullptr, const int* shape = nullptr, bool cull = true) {
+	std::string src = generate_source(P, fast, cull);
 	if (src_out) *src_out = src;
 	std::string key = arch + "|" + (getenv("LOL_GPU_RTC_FLAGS") ? getenv("LOL_GPU_RTC_FLAGS") : "") + "|";
 	if (shape) key += std::to_string(shape[0]) + "x" + std::to_string(shape[1]) + "x" + std::to_string(shape[2]);
@@ -551,7 +731,7 @@ bool specialise(lol_gpu* ctx) {
 		fprintf(stderr, "lol_gpu: scene specialisation failed, using the interpreter kernel: %s\n", ctx->spec_log.c_str());
 		return false;
 	};
-	if (!compile_spec(ctx->h_prog, &fast, arch, code, ctx->spec_log, nullptr, shape)) return complain();
+	if (!compile_spec(ctx->h_prog, &fast, arch, code, ctx->spec_log, nullptr, shape, culling_enabled(ctx->want_cull))) return complain();
 	ctx->spec_log = note + ctx->spec_log;
 	if (hipModuleLoadData(&ctx->spec_module, code.data()) != hipSuccess) {
 		ctx->spec_log = "hipModuleLoadData failed";
@@ -633,6 +813,12 @@ int lol_gpu_set_miss_skip(lol_gpu* ctx, int enable) {
 		ctx->miss_skip = allowed && miss_skip_ok(ctx->h_prog);
 		ctx->dark_skip = allowed && dark_skip_ok(ctx->h_prog);
 	}
+	return LOL_GPU_OK;
+}
+
+int lol_gpu_set_cull(lol_gpu* ctx, int enable) {
+	if (!ctx) return LOL_GPU_ERR_ARG;
+	ctx->want_cull = enable ? 1 : 0;          /* takes effect at the next lol_gpu_upload_program */
 	return LOL_GPU_OK;
 }
 
@@ -886,7 +1072,7 @@ int lol_gpu_compile_offline(const lol_program* prog, const char* arch, const cha
 			if ((prog->ops[i].op == LOL_OP_SMIN || prog->ops[i].op == LOL_OP_SMIN_R) && !fast.has(prog->ops[i].f[0]))
 				fast.div_ok.push_back(prog->ops[i].f[0]);
 	}
-	bool ok = compile_spec(*prog, &fast, arch, code, lg, &src);
+	bool ok = compile_spec(*prog, &fast, arch, code, lg, &src, nullptr, culling_enabled(1));
 	if (log && logcap) snprintf(log, logcap, "%s", lg.c_str());
 	if (out_base && out_base[0]) {
 		std::string base = out_base;

@@ -399,7 +399,8 @@ struct Interp {
 
 	/* Inlined into the march / normal / shadow loops: as a real (noinline) function it was 8 % slower — arguments
 	 * travel in VGPRs and need v_readfirstlane, plus call / return and the callee's register shuffling. */
-	__device__ __forceinline__ void eval(V3 p, float& best_out, u32& id_out) {
+	__device__ __forceinline__ void eval(V3 p, float& best_out, u32& id_out, bool care = true) {
+		(void)care;      /* which lanes still need the result: only the specialised SDF's object culling uses it */
 		/* everything the loop carries is a local: the trip count and the list pointer must stay provably
 		 * wave-uniform (scalar loop, scalar loads, scalar branches), which they do not when they live behind
 		 * `this` next to per-lane results written through references */
@@ -483,7 +484,7 @@ __device__ __forceinline__ Hit march(Sdf& sdf, V3 ro, V3 rd, int max_steps) {
 		if (__ballot(alive) == 0) break;              /* every lane has hit or escaped */
 		V3 p = add(ro, scale(rd, dist));
 		float d; u32 did;
-		sdf.eval(p, d, did);
+		sdf.eval(p, d, did, alive);        /* lanes that are done do not care: they do not keep an object from being culled */
 		if (alive) {
 			dist += d;
 			id = did;
@@ -506,7 +507,7 @@ __device__ __forceinline__ float soft_shadow(Sdf& sdf, V3 p, V3 dir, float max_d
 		if (__ballot(alive) == 0) break;
 		V3 q = add(ro, scale(dir, t));
 		float s; u32 sid;
-		sdf.eval(q, s, sid);
+		sdf.eval(q, s, sid, alive);
 		if (alive) {
 			res = minf_(res, 50.f * s / t);
 			t += s;
