@@ -218,64 +218,6 @@ struct FastPaths {
 	}
 };
 
-/*
- * Post-order program → macro-ops of the interpreter (lol_kernel.h, Interp).  The accumulator is the top of the
- * post-order operand stack:
- *   primitive followed by SMIN / SMIN_R  → one macro-op: x = primitive, combined with acc at once.  In post-order
- *                                           SMIN pops b (top) then a; the primitive is the top, so x = b and the
- *                                           combine is sminf(acc, x); SMIN_R (top is a) gives sminf(x, acc);
- *   primitive otherwise                   → SET when nothing is on the stack yet, else PUSH (acc goes under);
- *   SMIN / SMIN_R after a non-primitive   → x = the popped entry under acc: SMIN has a = x, b = acc → sminf(x, acc);
- *                                           SMIN_R has a = acc, b = x → sminf(acc, x);
- *   TOP                                   → a flag on the macro-op that produced the value.
- * `fast` lists the smoothness constants whose fast blend factor was proven on the device.
- */
-std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast) {
-	std::vector<uint32_t> out;
-	auto fbits32 = [](float v) { uint32_t u; memcpy(&u, &v, 4); return u; };
-	int depth = 0;                                   /* post-order stack depth before the current op */
-	size_t last = 0;                                 /* start of the macro-op that produced the current acc */
-	for (uint32_t i = 0; i < P.n_ops; i++) {
-		const lol_op& o = P.ops[i];
-		auto smin_fields = [&](uint32_t* m, const lol_op& sm) {
-			m[9] = fbits32(sm.f[0]);
-			if (fast && fast->has(sm.f[0])) {
-				m[0] |= lol::MOP_FASTDIV;
-				m[10] = fbits32(2.0f * sm.f[0]);
-				m[11] = fbits32(0.5f * (1.0f / sm.f[0]));
-			}
-		};
-		if (o.op <= LOL_OP_PLANE) {
-			uint32_t m[lol::MOP_DWORDS] = { 0 };
-			const uint32_t kind = o.op == LOL_OP_SPHERE ? lol::MOP_SPHERE : o.op == LOL_OP_RBOX ? lol::MOP_RBOX : lol::MOP_PLANE;
-			for (int j = 0; j < 7; j++) m[2 + j] = fbits32(o.f[j]);
-			const lol_op* nx = i + 1 < P.n_ops ? &P.ops[i + 1] : nullptr;
-			if (nx && (nx->op == LOL_OP_SMIN || nx->op == LOL_OP_SMIN_R) && depth >= 1) {
-				m[0] = lol::mop_header(kind, nx->op == LOL_OP_SMIN ? lol::MOP_SMIN : lol::MOP_SMIN_X);
-				smin_fields(m, *nx);
-				i++;                                    /* the smooth min is part of this macro-op; depth unchanged */
-			} else {
-				m[0] = lol::mop_header(kind, depth == 0 ? lol::MOP_SET : lol::MOP_PUSH);
-				depth++;
-			}
-			last = out.size();
-			out.insert(out.end(), m, m + lol::MOP_DWORDS);
-		} else if (o.op == LOL_OP_SMIN || o.op == LOL_OP_SMIN_R) {
-			uint32_t m[lol::MOP_DWORDS] = { 0 };
-			m[0] = lol::mop_header(lol::MOP_POP, o.op == LOL_OP_SMIN ? lol::MOP_SMIN_X : lol::MOP_SMIN);
-			smin_fields(m, o);
-			depth--;
-			last = out.size();
-			out.insert(out.end(), m, m + lol::MOP_DWORDS);
-		} else {                                         /* LOL_OP_TOP */
-			out[last] |= lol::MOP_TOP;
-			out[last + 1] = o.id;
-			depth = 0;
-		}
-	}
-	return out;
-}
-
 /* ------------------------------------------------ exact culling of top-level objects
  * sdf() (naive_renderer.c:31-44) is a strict-'<' minimum over the top-level objects.  An object whose distance is
  * PROVABLY greater than the running minimum cannot change it, so its evaluation may be skipped — exactly, not
@@ -426,6 +368,82 @@ CullPlan plan_culling(const std::vector<RootBound>& roots, bool enabled) {
 	return plan;
 }
 
+/*
+ * Post-order program → macro-ops of the interpreter (lol_kernel.h, Interp).  The accumulator is the top of the
+ * post-order operand stack:
+ *   primitive followed by SMIN / SMIN_R  → one macro-op: x = primitive, combined with acc at once.  In post-order
+ *                                           SMIN pops b (top) then a; the primitive is the top, so x = b and the
+ *                                           combine is sminf(acc, x); SMIN_R (top is a) gives sminf(x, acc);
+ *   primitive otherwise                   → SET when nothing is on the stack yet, else PUSH (acc goes under);
+ *   SMIN / SMIN_R after a non-primitive   → x = the popped entry under acc: SMIN has a = x, b = acc → sminf(x, acc);
+ *                                           SMIN_R has a = acc, b = x → sminf(acc, x);
+ *   TOP                                   → a flag on the macro-op that produced the value (+ MOP_TIE where the
+ *                                           object is evaluated after one that follows it in the file).
+ * The objects come in the order of `plan`; in front of the bounded block (and of objects with a test of their
+ * own) sits a CULL macro-op {C, R', how many macro-ops to skip} — the same exact test as in the specialised kernel.
+ * `fast` lists the smoothness constants whose fast blend factor was proven on the device.
+ */
+std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast, const std::vector<RootBound>& roots,
+                                 const CullPlan& plan) {
+	std::vector<uint32_t> out;
+	auto fbits32 = [](float v) { uint32_t u; memcpy(&u, &v, 4); return u; };
+	auto smin_fields = [&](uint32_t* m, const lol_op& sm) {
+		m[9] = fbits32(sm.f[0]);
+		if (fast && fast->has(sm.f[0])) {
+			m[0] |= lol::MOP_FASTDIV;
+			m[10] = fbits32(2.0f * sm.f[0]);
+			m[11] = fbits32(0.5f * (1.0f / sm.f[0]));
+		}
+	};
+	auto cull_mop = [&](const CullTest& ct) {
+		uint32_t m[lol::MOP_DWORDS] = { 0 };
+		m[0] = lol::MOPB_CULL;
+		for (int j = 0; j < 3; j++) m[2 + j] = fbits32(ct.c[j]);
+		m[5] = fbits32(ct.rm);
+		out.insert(out.end(), m, m + lol::MOP_DWORDS);
+		return out.size() - lol::MOP_DWORDS;          /* its word 1 (skip count) is patched when the block ends */
+	};
+	size_t group_at = (size_t)-1;
+	uint32_t max_id_seen = 0;
+	for (size_t oi = 0; oi < plan.order.size(); oi++) {
+		const RootBound& R = roots[plan.order[oi]];
+		if (plan.group && oi == plan.n_unbounded) group_at = cull_mop(plan.group_test);
+		const int own = plan.own_test[plan.order[oi]];
+		const size_t own_at = own >= 0 ? cull_mop(plan.tests[own]) : (size_t)-1;
+		int depth = 0;                                   /* post-order stack depth before the current op */
+		size_t last = 0;                                 /* start of the macro-op that produced the current acc */
+		for (uint32_t i = R.first; i < R.top; i++) {
+			const lol_op& o = P.ops[i];
+			uint32_t m[lol::MOP_DWORDS] = { 0 };
+			if (o.op <= LOL_OP_PLANE) {
+				const uint32_t kind = o.op == LOL_OP_SPHERE ? lol::MOP_SPHERE : o.op == LOL_OP_RBOX ? lol::MOP_RBOX : lol::MOP_PLANE;
+				for (int j = 0; j < 7; j++) m[2 + j] = fbits32(o.f[j]);
+				const lol_op* nx = i + 1 < R.top ? &P.ops[i + 1] : nullptr;
+				if (nx && (nx->op == LOL_OP_SMIN || nx->op == LOL_OP_SMIN_R) && depth >= 1) {
+					m[0] = lol::mop_header(kind, nx->op == LOL_OP_SMIN ? lol::MOP_SMIN : lol::MOP_SMIN_X);
+					smin_fields(m, *nx);
+					i++;                                /* the smooth min is part of this macro-op; depth unchanged */
+				} else {
+					m[0] = lol::mop_header(kind, depth == 0 ? lol::MOP_SET : lol::MOP_PUSH);
+					depth++;
+				}
+			} else {                                     /* SMIN / SMIN_R on two computed operands */
+				m[0] = lol::mop_header(lol::MOP_POP, o.op == LOL_OP_SMIN ? lol::MOP_SMIN_X : lol::MOP_SMIN);
+				smin_fields(m, o);
+				depth--;
+			}
+			last = out.size();
+			out.insert(out.end(), m, m + lol::MOP_DWORDS);
+		}
+		out[last] |= lol::MOP_TOP | (R.id < max_id_seen ? lol::MOP_TIE : 0u);
+		out[last + 1] = R.id;
+		if (R.id > max_id_seen) max_id_seen = R.id;
+		if (own >= 0) out[own_at + 1] = (uint32_t)((out.size() - own_at) / lol::MOP_DWORDS - 1);
+	}
+	if (group_at != (size_t)-1) out[group_at + 1] = (uint32_t)((out.size() - group_at) / lol::MOP_DWORDS - 1);
+	return out;
+}
+
 /* Emits one `struct <name>` with eval(): one SSA temporary per op, same operation order WITHIN every top-level object
  * as the post-order program; the objects themselves in the order of `plan` (file order when culling is off).
  * out_of_line: the body becomes ONE real function (`<name>_fn`, __noinline__) that the march, normal and shadow
@@ -437,27 +455,43 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 	const int fsqrt = fast ? fast->sqrt_kind : 0;
 	char fs[32] = "";
 	if (fsqrt) snprintf(fs, sizeof fs, "_fast<%d>", fsqrt);
+	const int total_tests = (plan.group ? 1 : 0) + (int)plan.tests.size();
+	char cool_decl[64] = "";
+	if (total_tests) snprintf(cool_decl, sizeof cool_decl, "\tu32 cool[%d] = {};\n", total_tests);
 	if (out_of_line) {
+		/* out of line the cool-down state is per call (always 0: every evaluation tests) */
 		snprintf(line, sizeof line, "__device__ __noinline__ SdfOut %s_fn(float px, float py, float pz, u32 rg_lo, u32 rg_hi, bool care) {\n"
-		         "\t\tconst V3 p = { px, py, pz };\n\t\tRange rg; rg.lo = rg_lo; rg.hi = rg_hi;\n\t\tfloat best; u32 best_id;\n", name);
+		         "\t\tconst V3 p = { px, py, pz };\n\t\tRange rg; rg.lo = rg_lo; rg.hi = rg_hi;\n\t\tfloat best; u32 best_id;\n\t%s", name, cool_decl);
 		s += line;
 	} else {
-		snprintf(line, sizeof line, "struct %s {\n\tRange rg;\n", name);
+		snprintf(line, sizeof line, "struct %s {\n\tRange rg;\n%s", name, cool_decl);
 		s += line;
 		s += "\t__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id, bool care = true) {\n";
 	}
 	s += "\t\tbest = __builtin_inff(); best_id = 0u;\n";
 	int t = 0, n_tests = 0;
+	/* After a test that did not allow the skip, the next `cooldown` evaluations of this SDF object do not test
+	 * again (a ray that is near the object now is near it on its next steps too): the test costs 11 VALU
+	 * instructions, and where it keeps failing that is pure overhead.  Never testing is always allowed — the
+	 * test only ever permits a skip — so this changes no result.  `cool` lives in the Sdf struct, wave-uniform. */
+	int cooldown = 3;
+	if (const char* e = getenv("LOL_GPU_CULL_COOLDOWN")) cooldown = atoi(e);
 	auto open_test = [&](const CullTest& ct) {
 		const int k = n_tests++;
 		snprintf(line, sizeof line,
-		         "\t\t{ const float cx%d = p.x - %s, cy%d = p.y - %s, cz%d = p.z - %s;\n"
+		         "\t\t{ bool need%d = true;\n"
+		         "\t\t  if (cool[%d] == 0u) {\n"
+		         "\t\t  const float cx%d = p.x - %s, cy%d = p.y - %s, cz%d = p.z - %s;\n"
 		         "\t\t  const float cl%d = (cx%d * cx%d + cy%d * cy%d) + cz%d * cz%d;\n"
 		         "\t\t  const float cu%d = (best + %s) * %s;\n"
 		         "\t\t  const bool skip%d = cl%d > cu%d * cu%d && cu%d > 0.f;\n"
-		         "\t\t  if (__ballot(care && !skip%d) != 0) {\n",
-		         k, fbits(ct.c[0]).c_str(), k, fbits(ct.c[1]).c_str(), k, fbits(ct.c[2]).c_str(),
-		         k, k, k, k, k, k, k, k, fbits(ct.rm).c_str(), fbits(1.0f + 0x1p-12f).c_str(), k, k, k, k, k, k);
+		         "\t\t  need%d = __ballot(care && !skip%d) != 0;\n"
+		         "\t\t  if (need%d) cool[%d] = %du;\n"
+		         "\t\t  } else cool[%d]--;\n"
+		         "\t\t  if (need%d) {\n",
+		         k, k, k, fbits(ct.c[0]).c_str(), k, fbits(ct.c[1]).c_str(), k, fbits(ct.c[2]).c_str(),
+		         k, k, k, k, k, k, k, k, fbits(ct.rm).c_str(), fbits(1.0f + 0x1p-12f).c_str(), k, k, k, k, k,
+		         k, k, k, k, cooldown, k, k);
 		s += line;
 	};
 	uint32_t max_id_seen = 0;
@@ -770,7 +804,8 @@ int lol_gpu_create(int device, lol_gpu** out) {
 	hipError_t e = hipSetDevice(device);
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_prog), sizeof(lol_program));
-	if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_mops), (size_t)LOL_MAX_OPS * lol::MOP_DWORDS * 4);
+	/* at most one macro-op per op, plus one CULL record per top-level object and one for the group */
+	if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_mops), (size_t)(2 * LOL_MAX_OPS + 1) * lol::MOP_DWORDS * 4);
 	if (e != hipSuccess) {
 		fprintf(stderr, "lol_gpu_create: %s\n", hipGetErrorString(e));
 		lol_gpu_destroy(ctx);
@@ -877,9 +912,10 @@ int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog) {
 	{
 		FastPaths fast = prove_fast_paths(ctx, *prog);
 		ctx->interp_sqrt_kind = fast.sqrt_kind == 3 ? 3 : 0;
-		std::vector<uint32_t> mops = build_mops(*prog, &fast);
+		const std::vector<RootBound> roots = analyse_roots(*prog);
+		std::vector<uint32_t> mops = build_mops(*prog, &fast, roots, plan_culling(roots, culling_enabled(ctx->want_cull)));
 		ctx->n_mops = (uint32_t)(mops.size() / lol::MOP_DWORDS);
-		if (ctx->n_mops > LOL_MAX_OPS) return fail(ctx, LOL_GPU_ERR_UNSUPPORTED, "program exceeds interpreter limits");
+		if (ctx->n_mops > 2 * LOL_MAX_OPS + 1) return fail(ctx, LOL_GPU_ERR_UNSUPPORTED, "program exceeds interpreter limits");
 		hipError_t e = hipMemcpy(ctx->d_prog, prog, sizeof *prog, hipMemcpyHostToDevice);
 		if (e == hipSuccess && !mops.empty())
 			e = hipMemcpy(ctx->d_mops, mops.data(), mops.size() * 4, hipMemcpyHostToDevice);
