@@ -160,6 +160,10 @@ int         lol_gpu_miss_skip_active(const lol_gpu* ctx);
  * On by default; set_cull(ctx, 0) before the upload or LOL_GPU_CULL=0 turn it off.
  */
 int         lol_gpu_set_cull(lol_gpu* ctx, int enable);
+/* The bound behind that test for top-level object `root` (0-based, file order); no device needed.  Returns 1 and
+ * the bounding sphere (centre, inflated radius R') when the object has one, 0 when it has none (planes, unions
+ * with a plane or with smoothness <= 0, non-finite fields) and is therefore never culled. */
+int         lol_gpu_cull_bounds(const lol_program* prog, uint32_t root, float c_out[3], float* r_out);
 /*
  * Diagnostic: out[i] = the renderer's powf(x[i], y[i]) (device pointers, asynchronous on `stream`, NULL = the
  * context's stream).  The kernel's powf restates the algorithm of the CPU libm's powf so that colours round

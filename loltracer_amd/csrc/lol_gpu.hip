@@ -218,6 +218,64 @@ struct FastPaths {
 	}
 };
 
+/*
+ * Post-order program → macro-ops of the interpreter (lol_kernel.h, Interp).  The accumulator is the top of the
+ * post-order operand stack:
+ *   primitive followed by SMIN / SMIN_R  → one macro-op: x = primitive, combined with acc at once.  In post-order
+ *                                           SMIN pops b (top) then a; the primitive is the top, so x = b and the
+ *                                           combine is sminf(acc, x); SMIN_R (top is a) gives sminf(x, acc);
+ *   primitive otherwise                   → SET when nothing is on the stack yet, else PUSH (acc goes under);
+ *   SMIN / SMIN_R after a non-primitive   → x = the popped entry under acc: SMIN has a = x, b = acc → sminf(x, acc);
+ *                                           SMIN_R has a = acc, b = x → sminf(acc, x);
+ *   TOP                                   → a flag on the macro-op that produced the value.
+ * `fast` lists the smoothness constants whose fast blend factor was proven on the device.
+ */
+std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast) {
+	std::vector<uint32_t> out;
+	auto fbits32 = [](float v) { uint32_t u; memcpy(&u, &v, 4); return u; };
+	int depth = 0;                                   /* post-order stack depth before the current op */
+	size_t last = 0;                                 /* start of the macro-op that produced the current acc */
+	for (uint32_t i = 0; i < P.n_ops; i++) {
+		const lol_op& o = P.ops[i];
+		auto smin_fields = [&](uint32_t* m, const lol_op& sm) {
+			m[9] = fbits32(sm.f[0]);
+			if (fast && fast->has(sm.f[0])) {
+				m[0] |= lol::MOP_FASTDIV;
+				m[10] = fbits32(2.0f * sm.f[0]);
+				m[11] = fbits32(0.5f * (1.0f / sm.f[0]));
+			}
+		};
+		if (o.op <= LOL_OP_PLANE) {
+			uint32_t m[lol::MOP_DWORDS] = { 0 };
+			const uint32_t kind = o.op == LOL_OP_SPHERE ? lol::MOP_SPHERE : o.op == LOL_OP_RBOX ? lol::MOP_RBOX : lol::MOP_PLANE;
+			for (int j = 0; j < 7; j++) m[2 + j] = fbits32(o.f[j]);
+			const lol_op* nx = i + 1 < P.n_ops ? &P.ops[i + 1] : nullptr;
+			if (nx && (nx->op == LOL_OP_SMIN || nx->op == LOL_OP_SMIN_R) && depth >= 1) {
+				m[0] = lol::mop_header(kind, nx->op == LOL_OP_SMIN ? lol::MOP_SMIN : lol::MOP_SMIN_X);
+				smin_fields(m, *nx);
+				i++;                                    /* the smooth min is part of this macro-op; depth unchanged */
+			} else {
+				m[0] = lol::mop_header(kind, depth == 0 ? lol::MOP_SET : lol::MOP_PUSH);
+				depth++;
+			}
+			last = out.size();
+			out.insert(out.end(), m, m + lol::MOP_DWORDS);
+		} else if (o.op == LOL_OP_SMIN || o.op == LOL_OP_SMIN_R) {
+			uint32_t m[lol::MOP_DWORDS] = { 0 };
+			m[0] = lol::mop_header(lol::MOP_POP, o.op == LOL_OP_SMIN ? lol::MOP_SMIN_X : lol::MOP_SMIN);
+			smin_fields(m, o);
+			depth--;
+			last = out.size();
+			out.insert(out.end(), m, m + lol::MOP_DWORDS);
+		} else {                                         /* LOL_OP_TOP */
+			out[last] |= lol::MOP_TOP;
+			out[last + 1] = o.id;
+			depth = 0;
+		}
+	}
+	return out;
+}
+
 /* ------------------------------------------------ exact culling of top-level objects
  * sdf() (naive_renderer.c:31-44) is a strict-'<' minimum over the top-level objects.  An object whose distance is
  * PROVABLY greater than the running minimum cannot change it, so its evaluation may be skipped — exactly, not
@@ -366,82 +424,6 @@ CullPlan plan_culling(const std::vector<RootBound>& roots, bool enabled) {
 			plan.tests.push_back(make_test({ true, { r.c[0], r.c[1], r.c[2] }, r.r }));
 		}
 	return plan;
-}
-
-/*
- * Post-order program → macro-ops of the interpreter (lol_kernel.h, Interp).  The accumulator is the top of the
- * post-order operand stack:
- *   primitive followed by SMIN / SMIN_R  → one macro-op: x = primitive, combined with acc at once.  In post-order
- *                                           SMIN pops b (top) then a; the primitive is the top, so x = b and the
- *                                           combine is sminf(acc, x); SMIN_R (top is a) gives sminf(x, acc);
- *   primitive otherwise                   → SET when nothing is on the stack yet, else PUSH (acc goes under);
- *   SMIN / SMIN_R after a non-primitive   → x = the popped entry under acc: SMIN has a = x, b = acc → sminf(x, acc);
- *                                           SMIN_R has a = acc, b = x → sminf(acc, x);
- *   TOP                                   → a flag on the macro-op that produced the value (+ MOP_TIE where the
- *                                           object is evaluated after one that follows it in the file).
- * The objects come in the order of `plan`; in front of the bounded block (and of objects with a test of their
- * own) sits a CULL macro-op {C, R', how many macro-ops to skip} — the same exact test as in the specialised kernel.
- * `fast` lists the smoothness constants whose fast blend factor was proven on the device.
- */
-std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast, const std::vector<RootBound>& roots,
-                                 const CullPlan& plan) {
-	std::vector<uint32_t> out;
-	auto fbits32 = [](float v) { uint32_t u; memcpy(&u, &v, 4); return u; };
-	auto smin_fields = [&](uint32_t* m, const lol_op& sm) {
-		m[9] = fbits32(sm.f[0]);
-		if (fast && fast->has(sm.f[0])) {
-			m[0] |= lol::MOP_FASTDIV;
-			m[10] = fbits32(2.0f * sm.f[0]);
-			m[11] = fbits32(0.5f * (1.0f / sm.f[0]));
-		}
-	};
-	auto cull_mop = [&](const CullTest& ct) {
-		uint32_t m[lol::MOP_DWORDS] = { 0 };
-		m[0] = lol::MOPB_CULL;
-		for (int j = 0; j < 3; j++) m[2 + j] = fbits32(ct.c[j]);
-		m[5] = fbits32(ct.rm);
-		out.insert(out.end(), m, m + lol::MOP_DWORDS);
-		return out.size() - lol::MOP_DWORDS;          /* its word 1 (skip count) is patched when the block ends */
-	};
-	size_t group_at = (size_t)-1;
-	uint32_t max_id_seen = 0;
-	for (size_t oi = 0; oi < plan.order.size(); oi++) {
-		const RootBound& R = roots[plan.order[oi]];
-		if (plan.group && oi == plan.n_unbounded) group_at = cull_mop(plan.group_test);
-		const int own = plan.own_test[plan.order[oi]];
-		const size_t own_at = own >= 0 ? cull_mop(plan.tests[own]) : (size_t)-1;
-		int depth = 0;                                   /* post-order stack depth before the current op */
-		size_t last = 0;                                 /* start of the macro-op that produced the current acc */
-		for (uint32_t i = R.first; i < R.top; i++) {
-			const lol_op& o = P.ops[i];
-			uint32_t m[lol::MOP_DWORDS] = { 0 };
-			if (o.op <= LOL_OP_PLANE) {
-				const uint32_t kind = o.op == LOL_OP_SPHERE ? lol::MOP_SPHERE : o.op == LOL_OP_RBOX ? lol::MOP_RBOX : lol::MOP_PLANE;
-				for (int j = 0; j < 7; j++) m[2 + j] = fbits32(o.f[j]);
-				const lol_op* nx = i + 1 < R.top ? &P.ops[i + 1] : nullptr;
-				if (nx && (nx->op == LOL_OP_SMIN || nx->op == LOL_OP_SMIN_R) && depth >= 1) {
-					m[0] = lol::mop_header(kind, nx->op == LOL_OP_SMIN ? lol::MOP_SMIN : lol::MOP_SMIN_X);
-					smin_fields(m, *nx);
-					i++;                                /* the smooth min is part of this macro-op; depth unchanged */
-				} else {
-					m[0] = lol::mop_header(kind, depth == 0 ? lol::MOP_SET : lol::MOP_PUSH);
-					depth++;
-				}
-			} else {                                     /* SMIN / SMIN_R on two computed operands */
-				m[0] = lol::mop_header(lol::MOP_POP, o.op == LOL_OP_SMIN ? lol::MOP_SMIN_X : lol::MOP_SMIN);
-				smin_fields(m, o);
-				depth--;
-			}
-			last = out.size();
-			out.insert(out.end(), m, m + lol::MOP_DWORDS);
-		}
-		out[last] |= lol::MOP_TOP | (R.id < max_id_seen ? lol::MOP_TIE : 0u);
-		out[last + 1] = R.id;
-		if (R.id > max_id_seen) max_id_seen = R.id;
-		if (own >= 0) out[own_at + 1] = (uint32_t)((out.size() - own_at) / lol::MOP_DWORDS - 1);
-	}
-	if (group_at != (size_t)-1) out[group_at + 1] = (uint32_t)((out.size() - group_at) / lol::MOP_DWORDS - 1);
-	return out;
 }
 
 /* Emits one `struct <name>` with eval(): one SSA temporary per op, same operation order WITHIN every top-level object
@@ -804,8 +786,7 @@ int lol_gpu_create(int device, lol_gpu** out) {
 	hipError_t e = hipSetDevice(device);
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_prog), sizeof(lol_program));
-	/* at most one macro-op per op, plus one CULL record per top-level object and one for the group */
-	if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_mops), (size_t)(2 * LOL_MAX_OPS + 1) * lol::MOP_DWORDS * 4);
+	if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_mops), (size_t)LOL_MAX_OPS * lol::MOP_DWORDS * 4);
 	if (e != hipSuccess) {
 		fprintf(stderr, "lol_gpu_create: %s\n", hipGetErrorString(e));
 		lol_gpu_destroy(ctx);
@@ -849,6 +830,20 @@ int lol_gpu_set_miss_skip(lol_gpu* ctx, int enable) {
 		ctx->dark_skip = allowed && dark_skip_ok(ctx->h_prog);
 	}
 	return LOL_GPU_OK;
+}
+
+/* Host-only view of the bound behind the culling test of top-level object `root` (0-based, file order):
+ * 1 = bounded (centre and inflated radius R' out), 0 = no bound (never culled), < 0 = bad argument. */
+int lol_gpu_cull_bounds(const lol_program* prog, uint32_t root, float c_out[3], float* r_out) {
+	if (!prog || !c_out || !r_out || root >= prog->n_roots || prog->n_ops > LOL_MAX_OPS) return LOL_GPU_ERR_ARG;
+	const std::vector<RootBound> roots = analyse_roots(*prog);
+	if (root >= roots.size()) return LOL_GPU_ERR_ARG;
+	const RootBound& R = roots[root];
+	if (!R.bounded) return 0;
+	const CullTest t = make_test({ true, { R.c[0], R.c[1], R.c[2] }, R.r });
+	c_out[0] = t.c[0]; c_out[1] = t.c[1]; c_out[2] = t.c[2];
+	*r_out = t.rm;
+	return 1;
 }
 
 int lol_gpu_set_cull(lol_gpu* ctx, int enable) {
@@ -912,10 +907,9 @@ int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog) {
 	{
 		FastPaths fast = prove_fast_paths(ctx, *prog);
 		ctx->interp_sqrt_kind = fast.sqrt_kind == 3 ? 3 : 0;
-		const std::vector<RootBound> roots = analyse_roots(*prog);
-		std::vector<uint32_t> mops = build_mops(*prog, &fast, roots, plan_culling(roots, culling_enabled(ctx->want_cull)));
+		std::vector<uint32_t> mops = build_mops(*prog, &fast);
 		ctx->n_mops = (uint32_t)(mops.size() / lol::MOP_DWORDS);
-		if (ctx->n_mops > 2 * LOL_MAX_OPS + 1) return fail(ctx, LOL_GPU_ERR_UNSUPPORTED, "program exceeds interpreter limits");
+		if (ctx->n_mops > LOL_MAX_OPS) return fail(ctx, LOL_GPU_ERR_UNSUPPORTED, "program exceeds interpreter limits");
 		hipError_t e = hipMemcpy(ctx->d_prog, prog, sizeof *prog, hipMemcpyHostToDevice);
 		if (e == hipSuccess && !mops.empty())
 			e = hipMemcpy(ctx->d_mops, mops.data(), mops.size() * 4, hipMemcpyHostToDevice);

@@ -383,11 +383,6 @@ constexpr u32 MOPB_SPHERE = 1u, MOPB_RBOX = 2u, MOPB_PLANE = 4u, MOPB_POP = 8u;
 constexpr u32 MOP_FASTDIV = 16u;     /* the smooth min's blend factor was proven for this k: f[8] = 2k, f[9] = .5/k */
 constexpr u32 MOP_TOP = 32u;         /* acc is a finished top-level object: id in word 1                           */
 constexpr u32 MOPB_PUSH = 64u, MOPB_SMIN = 128u, MOPB_X_IS_A = 256u;   /* SET = none of PUSH / SMIN */
-constexpr u32 MOP_TIE = 512u;        /* with MOP_TOP: evaluated after an object that follows it in the file → ties go to the lower id */
-constexpr u32 MOPB_CULL = 1024u;     /* not an SDF step: {C = f[0..2], R' = f[3]}, word 1 = macro-ops to skip when every
-                                        lane that cares is provably farther from C than best + R' (lol_gpu.hip, "exact culling") */
-constexpr float CULL_K = 1.0f + 0x1p-12f;
-constexpr u32 CULL_COOLDOWN = 3u;    /* after a test that did not allow the skip, this many evaluations do not test */
 __host__ __device__ constexpr u32 mop_header(u32 kind, u32 comb) {
 	return (1u << kind) | (comb == MOP_PUSH ? MOPB_PUSH : comb == MOP_SMIN ? MOPB_SMIN : comb == MOP_SMIN_X ? (MOPB_SMIN | MOPB_X_IS_A) : 0u);
 }
@@ -401,18 +396,19 @@ struct Interp {
 	const u32* mops;     /* global memory, MOP_DWORDS per macro-op, 16-byte aligned */
 	u32        n_mops;
 	Range      rg;       /* KIND != 0: range of the squared lengths given to the proven fast sqrt (see above) */
-	u32        cool;     /* evaluations left before the next CULL record tests again (wave-uniform) */
 
 	/* Inlined into the march / normal / shadow loops: as a real (noinline) function it was 8 % slower — arguments
 	 * travel in VGPRs and need v_readfirstlane, plus call / return and the callee's register shuffling. */
 	__device__ __forceinline__ void eval(V3 p, float& best_out, u32& id_out, bool care = true) {
+		(void)care;      /* which lanes still need the result: only the specialised SDF's object culling uses it.  Culling was
+		                  * tried here too (CULL records / block headers): the extra scalar work in this SALU-bound loop cost
+		                  * more (-11 %) than the skipped objects gave back (+9 %), so the interpreter evaluates every object. */
 		/* everything the loop carries is a local: the trip count and the list pointer must stay provably
 		 * wave-uniform (scalar loop, scalar loads, scalar branches), which they do not when they live behind
 		 * `this` next to per-lane results written through references */
 		const u32 n = n_mops;
 		mop_ptr rec = (mop_ptr)(unsigned long long)mops;
 		Range r = rg;
-		u32 cl = cool;
 		float s[SSIZE];
 #pragma unroll
 		for (int i = 0; i < SSIZE; i++) s[i] = 0.f;
@@ -427,27 +423,6 @@ struct Interp {
 			/* LOL_KEEP_BRANCH: an empty volatile asm keeps the compiler from turning a rarely taken uniform branch into
 			 * v_cndmask selects that every macro-op would then pay for (half-rate VALU, 4 cycles each) */
 #define LOL_KEEP_BRANCH() asm volatile("" ::: "memory")
-			if (hdr & MOPB_CULL) {
-				/* the exact object-culling test of lol_gpu.hip: skip the next rec[1] macro-ops when no lane that still
-				 * cares about this evaluation can be nearer to them than the running minimum */
-				LOL_KEEP_BRANCH();
-				if (cl == 0u) {
-					const float cx = p.x - F(2), cy = p.y - F(3), cz = p.z - F(4);
-					const float l2 = (cx * cx + cy * cy) + cz * cz;
-					const float u = (best + F(5)) * CULL_K;
-					const bool skip = l2 > u * u && u > 0.f;
-					if (__ballot(care && !skip) == 0) {
-						const u32 k = rec[1];
-						i += k;
-						rec += k * MOP_DWORDS;
-					} else {
-						cl = CULL_COOLDOWN;
-					}
-				} else {
-					cl--;
-				}
-				continue;
-			}
 			float x = 0.f;
 			if (hdr & MOPB_SPHERE)
 				x = KIND ? sd_sphere_fast<KIND ? KIND : 1>(p, F(2), F(3), F(4), F(5), r) : sd_sphere(p, F(2), F(3), F(4), F(5));
@@ -484,18 +459,13 @@ struct Interp {
 				}
 				if (hdr & MOP_TOP) {
 					LOL_KEEP_BRANCH();
-					const u32 id = rec[1];
-					if (hdr & MOP_TIE) {
-						LOL_KEEP_BRANCH();
-						if (x < best || (x == best && best_id > id)) { best = x; best_id = id; }
-					} else if (x < best) { best = x; best_id = id; }
+					if (x < best) { best = x; best_id = rec[1]; }
 				}
 			}
 			acc = x;
 #undef LOL_KEEP_BRANCH
 		}
 		rg = r;
-		cool = cl;
 		best_out = best;
 		id_out = best_id;
 	}
@@ -721,10 +691,10 @@ void render_interp(const Launch L) {
 	extern __shared__ u32 lds[];
 	stage_common(L, lds);
 	__syncthreads();
-	Interp<SSIZE, KIND> sdf{ L.ops, L.n_ops, {}, 0u };
+	Interp<SSIZE, KIND> sdf{ L.ops, L.n_ops, {} };
 	Pixel P = shade_pixel(L, sdf, lds);
 	if (KIND != 0 && __ballot(sdf.rg.outside()) != 0) {
-		Interp<SSIZE, 0> exact{ L.ops, L.n_ops, {}, 0u };
+		Interp<SSIZE, 0> exact{ L.ops, L.n_ops, {} };
 		P = shade_pixel(L, exact, lds);
 	}
 	store_pixel(L, P, lds);
@@ -750,8 +720,8 @@ __device__ __forceinline__ void sdf_points(SdfFast& fast, SdfExact& exact, bool 
 template <int SSIZE, int KIND>
 __global__ __launch_bounds__(64)
 void sdf_points_interp(const u32* mops, u32 n_mops, const float* pts, float* dist, u32* id, u32 n) {
-	Interp<SSIZE, KIND> fast{ mops, n_mops, {}, 0u };
-	Interp<SSIZE, 0> exact{ mops, n_mops, {}, 0u };
+	Interp<SSIZE, KIND> fast{ mops, n_mops, {} };
+	Interp<SSIZE, 0> exact{ mops, n_mops, {} };
 	sdf_points(fast, exact, KIND != 0, pts, dist, id, n);
 }
 

@@ -1,0 +1,130 @@
+"""Exact culling of top-level objects (lol_gpu.hip "exact culling").
+
+CPU part — the proof obligation behind the skip: for every object with a bound (C, R'), the object's distance
+value(p) >= |p - C| - R' at every point.  Checked with the oracle's SDF on thousands of random points around random
+single-object scenes (spheres, rounded boxes, smooth unions nested up to 5 deep, k from 0.05 to 8), in double precision
+against the binary32 values the oracle (= the reference's arithmetic) produces.
+GPU part — culling on == culling off, bit for bit (pixels, hit ids, distances, step counts), and the reference's tie
+rule (the FIRST object of equal distance wins, naive_renderer.c:39) survives the re-ordering.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from loltracer_amd import gpu, scene as S
+
+
+def num(x):
+    return ("%.5f" % x).rstrip("0").rstrip(".") if "." in "%.5f" % x else "%.5f" % x
+
+
+def fmt(v):
+    return "(%s)" % ", ".join(num(x) for x in v)
+
+
+def rand_bounded(rng, depth):
+    if depth == 0 or rng.random() < 0.25:
+        if rng.random() < 0.5:
+            return "sphere { point = %s, radius = %s }" % (fmt(rng.normal(size=3) * 4), num(rng.uniform(0.1, 3)))
+        return "box { point = %s, point2 = %s, radius = %s }" % (
+            fmt(rng.normal(size=3) * 4), fmt(rng.uniform(0.05, 3, size=3)), num(rng.uniform(0, 1)))
+    return "smooth_union { smoothness = %s, a = %s, b = %s }" % (
+        num(rng.choice([0.05, 0.5, 1, 3, 8])), rand_bounded(rng, depth - 1), rand_bounded(rng, int(rng.integers(0, depth))))
+
+
+MAT = "materials { { shininess = 1, diffuse = (0,0,0), specular = (0,0,0), ambient = (0,0,0) } }\n"
+
+
+def bounds_of(prog, root):
+    c, r = (C.c_float * 3)(), C.c_float()
+    st = gpu.gpu_lib().lol_gpu_cull_bounds(C.byref(prog), root, c, C.byref(r))
+    return st, np.array(list(c), dtype=np.float64), float(r.value)
+
+
+def test_the_bound_holds_on_random_objects():
+    rng = np.random.default_rng(77)
+    l = O.lib()
+    checked = 0
+    for _ in range(120):
+        obj = rand_bounded(rng, int(rng.integers(0, 6)))
+        sc = S.Scene.parse_string(MAT + "scene { " + obj.replace("{", "{ material = #0,", 1) + " }")
+        prog = sc.flatten()
+        st, c, rp = bounds_of(prog, 0)
+        assert st == 1
+        # points: near the object, far away, and on a shell just outside the bound (where the inequality is tightest)
+        pts = np.concatenate([rng.normal(size=(60, 3)) * 6 + c, rng.normal(size=(30, 3)) * 300 + c,
+                              c + (lambda d: d / np.linalg.norm(d, axis=1, keepdims=True))(rng.normal(size=(60, 3))) * rp * rng.uniform(0.9, 1.3, size=(60, 1))])
+        for p in pts.astype(np.float32):
+            oid = C.c_uint32()
+            v = l.lol_oracle_sdf(sc.ptr, float(p[0]), float(p[1]), float(p[2]), C.byref(oid))
+            d = float(np.linalg.norm(p.astype(np.float64) - c))
+            assert v >= d - rp, (obj, p, v, d - rp)
+            checked += 1
+    assert checked > 15000
+
+
+def test_what_has_no_bound():
+    for obj in ("plane { y = -1, material = #0 }",
+                "smooth_union { material = #0, smoothness = 1, a = sphere { radius = 1 }, b = plane { y = 0 } }",
+                "smooth_union { material = #0, smoothness = 0, a = sphere { radius = 1 }, b = sphere { radius = 2 } }",
+                "smooth_union { material = #0, smoothness = -2, a = sphere { radius = 1 }, b = sphere { radius = 2 } }",
+                "box { material = #0, point2 = (-1, 1, 1), radius = 0.1 }",
+                "sphere { material = #0, point = (10000000000000000000, 0, 0), radius = 1 }"):
+        st, _, _ = bounds_of(S.Scene.parse_string(MAT + "scene { " + obj + " }").flatten(), 0)
+        assert st == 0, obj
+    st, c, r = bounds_of(S.Scene.parse_string(MAT + "scene { sphere { material = #0, point = (1,2,3), radius = -4 } }").flatten(), 0)
+    assert st == 1 and r < 1e-3 and c.tolist() == [1, 2, 3]       # |q| - r with r < 0 is >= |q|
+
+
+# ------------------------------------------------------------------ on the GPU
+
+def _render(torch, sc, w, h, cull):
+    from test_gpu_parity import gpu_render
+    r = gpu.Renderer(0)
+    r.set_cull(cull)
+    g = gpu_render(torch, r, sc, w, h)
+    assert r.kernel_name() == "lol_render_spec"
+    r.close()
+    return g
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,w,h", [("scene4", 640, 360), ("scene", 480, 270), ("scene2", 320, 200), ("scene3", 320, 200)])
+def test_culling_changes_nothing(scenes, name, w, h):
+    import torch
+    a, b = _render(torch, scenes[name], w, h, True), _render(torch, scenes[name], w, h, False)
+    for key in ("xrgb", "id", "steps"):
+        assert np.array_equal(a[key], b[key]), key
+    assert np.array_equal(a["dist"].view(np.uint32), b["dist"].view(np.uint32))
+    assert np.array_equal(a["rgb"].view(np.uint32), b["rgb"].view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_ties_go_to_the_first_object_after_reordering():
+    """sphere (id 1, bounded → evaluated last) and plane (id 2, no bound → evaluated first): at (0,-2,0) both are exactly
+    1 away, and the reference's strict '<' keeps the sphere.  Likewise two coincident spheres after a plane."""
+    import torch
+    text = MAT + ("scene { sphere { material = #0, radius = 1 }, plane { material = #0, y = -3 },"
+                  " sphere { material = #0, radius = 1 }, sphere { material = #0, point = (8, 0, 0), radius = 2 } }")
+    sc = S.Scene.parse_string(text)
+    pts = np.array([[0, -2, 0], [0, -2.5, 0], [0, 2, 0], [8, 0, 0], [5, -2, 0], [4, -1.5, 0], [0, -1, 0], [3, 0, 0]], dtype=np.float32)
+    l = O.lib()
+    want = []
+    for p in pts:
+        oid = C.c_uint32()
+        want.append((l.lol_oracle_sdf(sc.ptr, float(p[0]), float(p[1]), float(p[2]), C.byref(oid)), oid.value))
+    assert want[0] == (1.0, 1) and want[4][1] in (2, 4)
+    for cull in (True, False):
+        r = gpu.Renderer(0)
+        r.set_cull(cull)
+        r.prepare(sc)
+        d_pts = torch.from_numpy(pts.copy()).cuda()
+        d_dist = torch.zeros(len(pts), dtype=torch.float32, device="cuda")
+        d_id = torch.zeros(len(pts), dtype=torch.int32, device="cuda")
+        r.sdf_batch(d_pts.data_ptr(), d_dist.data_ptr(), d_id.data_ptr(), len(pts), stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = list(zip(d_dist.cpu().tolist(), d_id.cpu().tolist()))
+        assert got == want, (cull, got, want)
+        r.close()
