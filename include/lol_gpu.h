@@ -106,6 +106,18 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 int lol_gpu_render_host(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h, int max_steps,
                         void* host_pixels, size_t pitch_bytes);
 
+/*
+ * The same with two frames in flight, for hosts that can give the next frame's camera before they consume the
+ * previous frame (an orbit, a recorded path; an interactive host trades one frame of latency for it):
+ *     begin(cam[0]);  for i: { begin(cam[i+1]);  end(surface);  present frame i }
+ * begin() queues the frame's kernel and returns; end() copies the OLDEST queued frame into the host surface and
+ * waits for that copy — which runs while the next frame's kernel does (main.c:182-194 is the loop this overlaps).
+ * At most two frames may be begun and not yet ended; lol_gpu_render_host_pending() says how many are.
+ */
+int lol_gpu_render_host_begin(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h, int max_steps);
+int lol_gpu_render_host_end(lol_gpu* ctx, void* host_pixels, size_t pitch_bytes);
+int lol_gpu_render_host_pending(const lol_gpu* ctx);
+
 /* Wait for everything issued on the context's own stream. */
 int lol_gpu_sync(lol_gpu* ctx);
 

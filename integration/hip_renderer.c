@@ -9,6 +9,8 @@
  *                   semaphore (main.c:147-161): create the GPU context,
  *                   flatten the scene, upload it.  Renderer flags start at
  *                   argv[3] (main.c:223-242): --device N (one GPU),
+ *                   --pipeline (one GPU: the copy of frame i into the surface runs
+ *                   under frame i+1's kernel; the surface then shows frame i-1),
  *                   --devices A,B,... (the frame's rows are dealt in bands over
  *                   these GPUs and the parts gathered with RCCL on the first one,
  *                   include/lol_gpu.h lol_gpu_multi_*), --max-steps N, and
@@ -43,6 +45,7 @@ struct hip_renderer {
 	lol_gpu_multi* multi;      /* --devices A,B,...: used instead of `gpu` */
 	lol_program    program;
 	int         max_steps;      /* MAX_STEPS, naive_renderer.c:49 */
+	int         pipeline;       /* --pipeline: frame i's copy into the surface overlaps frame i+1's kernel (one frame of latency) */
 	int         ready;
 };
 
@@ -57,6 +60,7 @@ void render_prepare(struct render_data* data, int argc, const char* argv[]) {
 	for (int i = 3; i < argc; i++) {
 		const int is_device = !strcmp(argv[i], "--device"), is_devices = !strcmp(argv[i], "--devices");
 		const int is_steps = !strcmp(argv[i], "--max-steps"), is_dump = !strcmp(argv[i], "--dump-kernel");
+		if (!strcmp(argv[i], "--pipeline")) { r->pipeline = 1; continue; }
 		if (!(is_device || is_devices || is_steps || is_dump)) continue;      /* the host's own flags */
 		if (i + 1 >= argc) { fprintf(stderr, "hip_renderer: %s needs a value, ignored\n", argv[i]); break; }
 		const char* v = argv[++i];
@@ -127,9 +131,18 @@ int render_thread(void* ptr) {
 				lol_frame_camera fc;
 				HOST_SCENE_CAMERA(data->scene, &cam);   /* the host moves the camera between frames (main.c:180) */
 				lol_frame_camera_init(&fc, &cam, width, height);
-				int st = r->multi
-					? lol_gpu_multi_render_host(r->multi, &fc, width, height, r->max_steps, surf->pixels, (size_t)surf->pitch)
-					: lol_gpu_render_host(r->gpu, &fc, width, height, r->max_steps, surf->pixels, (size_t)surf->pitch);
+				int st;
+				if (r->multi) {
+					st = lol_gpu_multi_render_host(r->multi, &fc, width, height, r->max_steps, surf->pixels, (size_t)surf->pitch);
+				} else if (r->pipeline) {
+					/* queue this frame, then deliver the one queued on the previous call: the surface shows frame i-1
+					 * while frame i renders (the very first call delivers nothing and leaves the surface as it is) */
+					st = lol_gpu_render_host_begin(r->gpu, &fc, width, height, r->max_steps);
+					if (st == LOL_GPU_OK && lol_gpu_render_host_pending(r->gpu) == 2)
+						st = lol_gpu_render_host_end(r->gpu, surf->pixels, (size_t)surf->pitch);
+				} else {
+					st = lol_gpu_render_host(r->gpu, &fc, width, height, r->max_steps, surf->pixels, (size_t)surf->pitch);
+				}
 				if (st != LOL_GPU_OK)
 					fprintf(stderr, "hip_renderer: %s\n", r->multi ? lol_gpu_multi_error(r->multi) : lol_gpu_error(r->gpu));
 			}

@@ -4,7 +4,7 @@
  * the GPU box).
  *
  *   lol_headless <threads> <scene.lol> [--size WxH] [--frames N] [--out frame.ppm]
- *                [--orbit] [renderer flags: --device N --max-steps N]
+ *                [--orbit] [--pipeline] [renderer flags: --device N | --devices A,B,.. --max-steps N]
  *
  * Protocol reproduced from main.c (the caller side of SURVEY.md §8b):
  *   - argv[1] = worker threads, argv[2] = scene file, argv[3..] go to render_prepare  (main.c:223-242)
@@ -52,13 +52,14 @@ static void orbit_camera(lol_camera* cam, int i, int n) {
 int main(int argc, const char* argv[]) {
 	int threads = argc > 1 ? atoi(argv[1]) : 1;
 	const char* path = argc > 2 ? argv[2] : NULL;
-	int w = 320, h = 240, frames = 1, orbit = 0;         /* main.c:152-159 opens 320x240 */
+	int w = 320, h = 240, frames = 1, orbit = 0, pipeline = 0;         /* main.c:152-159 opens 320x240 */
 	const char* out = NULL;
 	for (int i = 3; i < argc; i++) {
 		if (!strcmp(argv[i], "--size") && i + 1 < argc) sscanf(argv[++i], "%dx%d", &w, &h);
 		else if (!strcmp(argv[i], "--frames") && i + 1 < argc) frames = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "--out") && i + 1 < argc) out = argv[++i];
 		else if (!strcmp(argv[i], "--orbit")) orbit = 1;
+		else if (!strcmp(argv[i], "--pipeline")) pipeline = 1;      /* also read by the plug-in: the surface lags one frame */
 	}
 	if (threads < 1) threads = 1;
 	if (!path || w < 1 || h < 1) {
@@ -93,8 +94,9 @@ int main(int argc, const char* argv[]) {
 	render_prepare(&data, argc, argv);
 
 	double tmin = 1e30, tmax = 0, tsum = 0;
-	for (int f = 0; f < frames; f++) {
-		if (orbit) orbit_camera(&scene->camera, f, frames);   /* update_camera(), main.c:180 */
+	/* with --pipeline the plug-in delivers frame i-1 on round i: one extra round (same camera) brings the last frame in */
+	for (int f = 0; f < frames + pipeline; f++) {
+		if (orbit) orbit_camera(&scene->camera, f < frames ? f : frames - 1, frames);   /* update_camera(), main.c:180 */
 		atomic_store(&current_line, 0);
 		double t0 = now_ms();
 		for (int i = 0; i < threads; i++) sem_post(&entry);

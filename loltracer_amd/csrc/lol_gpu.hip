@@ -51,6 +51,13 @@ struct lol_gpu {
 	bool         have_prog = false;
 	uint32_t*    d_frame = nullptr;      /* framebuffer for lol_gpu_render_host */
 	size_t       frame_bytes = 0;
+	/* lol_gpu_render_host_begin / _end: two frames in flight */
+	uint32_t*    d_pipe[2] = { nullptr, nullptr };
+	size_t       pipe_bytes = 0;
+	hipStream_t  copy_stream = nullptr;
+	hipEvent_t   pipe_rendered[2] = { nullptr, nullptr }, pipe_copied[2] = { nullptr, nullptr };
+	int          pipe_w[2] = { 0, 0 }, pipe_h[2] = { 0, 0 };
+	unsigned     pipe_begun = 0, pipe_ended = 0;
 	int          want_spec = 1;
 	hipModule_t  spec_module = nullptr;
 	hipFunction_t spec_fn = nullptr;
@@ -804,6 +811,12 @@ void lol_gpu_destroy(lol_gpu* ctx) {
 	if (ctx->d_prog) (void)hipFree(ctx->d_prog);
 	if (ctx->d_mops) (void)hipFree(ctx->d_mops);
 	if (ctx->d_frame) (void)hipFree(ctx->d_frame);
+	if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
+	for (int i = 0; i < 2; i++) {
+		if (ctx->d_pipe[i]) (void)hipFree(ctx->d_pipe[i]);
+		if (ctx->pipe_rendered[i]) (void)hipEventDestroy(ctx->pipe_rendered[i]);
+		if (ctx->pipe_copied[i]) (void)hipEventDestroy(ctx->pipe_copied[i]);
+	}
 	if (ctx->d_bad) (void)hipFree(ctx->d_bad);
 	delete ctx;
 }
@@ -1023,6 +1036,66 @@ int lol_gpu_render_host(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h,
 	LOL_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	return LOL_GPU_OK;
 }
+
+/*
+ * The host-surface path with two frames in flight: begin() queues frame i+1's kernel while end() copies frame i
+ * into the host's surface, so the 33 MB device-to-host copy of a 4K frame (0.6 ms at PCIe Gen5 rates) runs under
+ * the next frame's kernel instead of after its own.  Kernels go to the context's stream, copies to a second
+ * stream, two device framebuffers alternate.
+ */
+int lol_gpu_render_host_begin(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h, int max_steps) {
+	if (!ctx || !cam) return LOL_GPU_ERR_ARG;
+	if (w <= 0 || h <= 0) return fail(ctx, LOL_GPU_ERR_ARG, "bad frame geometry");
+	if (ctx->pipe_begun - ctx->pipe_ended >= 2) return fail(ctx, LOL_GPU_ERR_ARG, "two frames already in flight: call lol_gpu_render_host_end first");
+	LOL_HIP(ctx, hipSetDevice(ctx->device));
+	if (!ctx->copy_stream) {
+		LOL_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+		for (int i = 0; i < 2; i++) {
+			LOL_HIP(ctx, hipEventCreateWithFlags(&ctx->pipe_rendered[i], hipEventDisableTiming));
+			LOL_HIP(ctx, hipEventCreateWithFlags(&ctx->pipe_copied[i], hipEventDisableTiming));
+		}
+	}
+	const size_t need = (size_t)w * h * 4;
+	if (need > ctx->pipe_bytes) {               /* the surface grew (main.c:182-187): drain, then reallocate both */
+		LOL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		LOL_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+		if (ctx->pipe_begun != ctx->pipe_ended) return fail(ctx, LOL_GPU_ERR_ARG, "cannot resize with a frame in flight: call lol_gpu_render_host_end first");
+		for (int i = 0; i < 2; i++) {
+			if (ctx->d_pipe[i]) (void)hipFree(ctx->d_pipe[i]);
+			ctx->d_pipe[i] = nullptr;
+		}
+		ctx->pipe_bytes = 0;
+		for (int i = 0; i < 2; i++) LOL_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_pipe[i]), need));
+		ctx->pipe_bytes = need;
+	}
+	const int slot = (int)(ctx->pipe_begun & 1u);
+	/* the copy that last read this framebuffer (two frames ago) must be done before the kernel overwrites it */
+	LOL_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->pipe_copied[slot], 0));
+	int st = lol_gpu_render_device(ctx, cam, w, h, max_steps, nullptr, ctx->d_pipe[slot], (size_t)w * 4, nullptr, nullptr);
+	if (st != LOL_GPU_OK) return st;
+	LOL_HIP(ctx, hipEventRecord(ctx->pipe_rendered[slot], ctx->stream));
+	ctx->pipe_w[slot] = w; ctx->pipe_h[slot] = h;
+	ctx->pipe_begun++;
+	return LOL_GPU_OK;
+}
+
+int lol_gpu_render_host_end(lol_gpu* ctx, void* host_pixels, size_t pitch_bytes) {
+	if (!ctx || !host_pixels) return LOL_GPU_ERR_ARG;
+	if (ctx->pipe_begun == ctx->pipe_ended) return fail(ctx, LOL_GPU_ERR_ARG, "no frame in flight");
+	const int slot = (int)(ctx->pipe_ended & 1u);
+	const int w = ctx->pipe_w[slot], h = ctx->pipe_h[slot];
+	if (pitch_bytes < (size_t)w * 4) return fail(ctx, LOL_GPU_ERR_ARG, "bad frame geometry");
+	LOL_HIP(ctx, hipSetDevice(ctx->device));
+	LOL_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->pipe_rendered[slot], 0));
+	LOL_HIP(ctx, hipMemcpy2DAsync(host_pixels, pitch_bytes, ctx->d_pipe[slot], (size_t)w * 4, (size_t)w * 4, h,
+	                              hipMemcpyDeviceToHost, ctx->copy_stream));
+	LOL_HIP(ctx, hipEventRecord(ctx->pipe_copied[slot], ctx->copy_stream));
+	ctx->pipe_ended++;
+	LOL_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+	return LOL_GPU_OK;
+}
+
+int lol_gpu_render_host_pending(const lol_gpu* ctx) { return ctx ? (int)(ctx->pipe_begun - ctx->pipe_ended) : 0; }
 
 int lol_gpu_sync(lol_gpu* ctx) {
 	if (!ctx) return LOL_GPU_ERR_ARG;

@@ -76,6 +76,12 @@ def gpu_lib() -> C.CDLL:
         lib.lol_gpu_render_device.restype = C.c_int
         lib.lol_gpu_render_host.argtypes = [vp, P(S.FrameCamera), C.c_int, C.c_int, C.c_int, vp, C.c_size_t]
         lib.lol_gpu_render_host.restype = C.c_int
+        lib.lol_gpu_render_host_begin.argtypes = [vp, P(S.FrameCamera), C.c_int, C.c_int, C.c_int]
+        lib.lol_gpu_render_host_begin.restype = C.c_int
+        lib.lol_gpu_render_host_end.argtypes = [vp, vp, C.c_size_t]
+        lib.lol_gpu_render_host_end.restype = C.c_int
+        lib.lol_gpu_render_host_pending.argtypes = [vp]
+        lib.lol_gpu_render_host_pending.restype = C.c_int
         lib.lol_gpu_sync.argtypes = [vp]
         lib.lol_gpu_sync.restype = C.c_int
         lib.lol_gpu_malloc.argtypes = [vp, C.c_size_t, P(vp)]
@@ -151,6 +157,7 @@ EXPORTED_SYMBOLS = [
     "lol_gpu_free", "lol_gpu_memcpy_d2h", "lol_gpu_kernel_name", "lol_gpu_set_specialize",
     "lol_gpu_specialize_log", "lol_gpu_compile_offline", "lol_gpu_verify_fast_paths", "lol_gpu_set_miss_skip",
     "lol_gpu_miss_skip_active", "lol_gpu_powf_batch", "lol_gpu_device", "lol_gpu_sdf_batch", "lol_gpu_set_cull", "lol_gpu_cull_bounds",
+    "lol_gpu_render_host_begin", "lol_gpu_render_host_end", "lol_gpu_render_host_pending",
     "lol_gpu_multi_create", "lol_gpu_multi_destroy", "lol_gpu_multi_error", "lol_gpu_multi_device_count",
     "lol_gpu_multi_context", "lol_gpu_multi_upload_program", "lol_gpu_choose_band_rows", "lol_gpu_multi_set_band_rows",
     "lol_gpu_part_frame_row", "lol_gpu_multi_render_device", "lol_gpu_multi_render_host", "lol_gpu_multi_sync",
@@ -216,6 +223,17 @@ class Renderer:
         fc = self.scene.frame_camera(w, h, camera)
         self._check(self._lib.lol_gpu_render_host(self._ctx, C.byref(fc), w, h, max_steps, C.c_void_p(host_ptr),
                                                   pitch_bytes if pitch_bytes is not None else w * 4))
+
+    def render_host_begin(self, w: int, h: int, max_steps: int = 256, camera: S.Camera | None = None):
+        """Queue a frame for the host-surface path (two may be in flight); render_host_end() delivers the oldest."""
+        fc = self.scene.frame_camera(w, h, camera)
+        self._check(self._lib.lol_gpu_render_host_begin(self._ctx, C.byref(fc), w, h, max_steps))
+
+    def render_host_end(self, host_ptr: int, pitch_bytes: int):
+        self._check(self._lib.lol_gpu_render_host_end(self._ctx, C.c_void_p(host_ptr), pitch_bytes))
+
+    def render_host_pending(self) -> int:
+        return int(self._lib.lol_gpu_render_host_pending(self._ctx))
 
     def sync(self):
         self._check(self._lib.lol_gpu_sync(self._ctx))

@@ -117,15 +117,29 @@ class GatherPipeline:
         self.work = [None] * self.depth
         self.n = 0
         self.frames_done = 0
+        # On a GPU the root un-interleaves on a stream of its own, so that neither the wait for the parts nor the
+        # 4 B/pixel permuted copy sits in the render stream between two frame kernels; `assembled[slot]` orders the
+        # next gather into staging[slot] (and the caller's reads of `frame`) after it.
+        self.cuda = torch.device(device).type == "cuda"
+        self.asm_stream = torch.cuda.Stream(device=device) if self.cuda and self.is_dst and not self.single else None
+        self.assembled = [None] * self.depth
 
     def _finish(self, slot: int):
         w = self.work[slot]
         if w is None:
             return
-        w.wait()                                   # orders the current stream after the collective
         self.work[slot] = None
-        if self.is_dst:
-            self.frame.copy_(assemble(self.staging[slot], self.h, self.band))
+        if self.asm_stream is not None:
+            with torch.cuda.stream(self.asm_stream):
+                w.wait()                               # orders the assembly stream after the collective
+                self.frame.copy_(assemble(self.staging[slot], self.h, self.band))
+                ev = torch.cuda.Event()
+                ev.record()
+            self.assembled[slot] = ev
+        else:
+            w.wait()                                   # orders the current stream after the collective
+            if self.is_dst:
+                self.frame.copy_(assemble(self.staging[slot], self.h, self.band))
         self.frames_done += 1
 
     def submit(self, render):
@@ -139,6 +153,12 @@ class GatherPipeline:
             return
         self._finish(slot)
         render(self.local[slot])
+        self._gather(slot)
+
+    def _gather(self, slot: int):
+        if self.assembled[slot] is not None:           # staging[slot] is still being read by the assembly stream
+            self.assembled[slot].wait()
+            self.assembled[slot] = None
         if self.is_dst:
             self.work[slot] = dist.gather(self.local[slot], [self.staging[slot][i] for i in range(self.world)],
                                           dst=self.dst, group=self.group, async_op=True)
@@ -151,19 +171,23 @@ class GatherPipeline:
         if self.single:
             return
         self._finish(slot)
-        if self.is_dst:
-            self.work[slot] = dist.gather(self.local[slot], [self.staging[slot][i] for i in range(self.world)],
-                                          dst=self.dst, group=self.group, async_op=True)
-        else:
-            self.work[slot] = dist.gather(self.local[slot], None, dst=self.dst, group=self.group, async_op=True)
+        self._gather(slot)
         self._finish(slot)
+        self._join()
 
     def drain(self):
         """Finish every frame in flight, oldest first; returns the last assembled frame on dst (None elsewhere)."""
         if not self.single:
             for k in range(self.depth):
                 self._finish((self.n + k) % self.depth)
+            self._join()
         return self.frame if self.is_dst else None
+
+    def _join(self):
+        """Order the current stream after every assembly issued so far (before the caller reads `frame`)."""
+        for ev in self.assembled:
+            if ev is not None:
+                ev.wait()
 
 
 def render_frame_distributed(render_part: Callable[[int, int, int], torch.Tensor], w: int, h: int,

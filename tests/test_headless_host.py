@@ -88,3 +88,49 @@ def test_python_cli_renders_the_same_frame(tmp_path, scenes):
     ox, _, _ = O.render(scenes["scene4"], 120, 68, threads=4)
     want = np.stack([(ox >> 16) & 0xFF, (ox >> 8) & 0xFF, ox & 0xFF], axis=-1).astype(np.int32)
     assert np.abs(img - want).max() <= 1
+
+
+@pytest.mark.gpu
+def test_pipelined_host_path_delivers_the_same_frames(tmp_path, scenes):
+    """lol_gpu_render_host_begin / _end: frame i's copy overlaps frame i+1's kernel.  Frames come out in order and
+    equal the synchronous path's; through the C host (--pipeline) the final surface is the last orbit frame."""
+    import bench
+    from loltracer_amd import gpu
+    sc = scenes["scene4"]
+    r = gpu.Renderer(0)
+    r.prepare(sc)
+    w, h, pitch = 200, 120, (200 + 3) * 4
+    cams = [bench.orbit_camera(i, 256) for i in (0, 40, 80, 120, 160)]
+    want = []
+    for cam in cams:
+        surf = np.zeros((h, pitch // 4), dtype=np.uint32)
+        r.render_host(surf.ctypes.data, w, h, camera=cam, pitch_bytes=pitch)
+        want.append(surf)
+    got = []
+    r.render_host_begin(w, h, camera=cams[0])
+    for i in range(len(cams)):
+        if i + 1 < len(cams):
+            r.render_host_begin(w, h, camera=cams[i + 1])
+            assert r.render_host_pending() == 2
+        surf = np.zeros((h, pitch // 4), dtype=np.uint32)
+        r.render_host_end(surf.ctypes.data, pitch)
+        got.append(surf)
+    assert r.render_host_pending() == 0
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+    with pytest.raises(gpu.GpuError):
+        r.render_host_end(got[0].ctypes.data, pitch)           # nothing in flight
+    r.render_host_begin(w, h); r.render_host_begin(w, h)
+    with pytest.raises(gpu.GpuError):
+        r.render_host_begin(w, h)                              # a third frame is refused
+    r.render_host_end(got[0].ctypes.data, pitch); r.render_host_end(got[0].ctypes.data, pitch)
+    r.close()
+
+    outs = []
+    for flags in ([], ["--pipeline"]):
+        out = tmp_path / ("p%d.ppm" % len(flags))
+        p = subprocess.run([HOST, "2", SCENE4, "--size", "320x180", "--frames", "6", "--orbit", "--out", str(out)] + flags,
+                           capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0 and "hip_renderer" not in p.stderr, p.stderr
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1]
