@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""rocprofv3 --pmc CSVs → per-kernel, per-dispatch averages → profiles/pmc_traffic.json (what bench.py reads for
+`roofline.traffic`) or any other summary file.
+
+    python tools/pmc_summary.py --kernel lol_render_spec --workload c3 --pixels 8294400 \
+        --out profiles/pmc_traffic.json  profiles/r2_spec_pmc_*_counter_collection.csv
+
+Every CSV is one rocprofv3 pass (one counter group per pass, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and
+WRITE_SIZE do not fit one pass).  Rows of the named kernel are averaged per counter over its dispatches.
+Traffic per launch = WRITE_SIZE + 2 x FETCH_SIZE in bytes (both are reported in KiB; on gfx950 FETCH_SIZE counts
+128-byte requests as 64 bytes, hence the factor 2 — same guide, HBM section).  Also derives the issue view used in
+DESIGN.md §3.4: cycles per XCD (GRBM_GUI_ACTIVE / 8), clock, cycles per VALU wave-instruction per SIMD.
+"""
+import argparse
+import collections
+import csv
+import json
+import os
+import sys
+
+
+def summarise(paths, kernel):
+    acc = collections.defaultdict(list)
+    dur = collections.defaultdict(list)
+    for path in paths:
+        seen = set()
+        for row in csv.DictReader(open(path)):
+            if kernel not in row["Kernel_Name"]:
+                continue
+            acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+            key = (path, row["Dispatch_Id"])
+            if key not in seen:
+                seen.add(key)
+                dur[os.path.basename(path)].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6)
+    counters = {k: sum(v) / len(v) for k, v in sorted(acc.items())}
+    launches = {k: len(v) for k, v in acc.items()}
+    ms = {k: sum(v) / len(v) for k, v in dur.items()}
+    return counters, launches, ms
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("csv", nargs="+")
+    ap.add_argument("--kernel", required=True)
+    ap.add_argument("--workload", default="c3")
+    ap.add_argument("--pixels", type=int, default=3840 * 2160)
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--merge", action="store_true", help="keep the other kernels already in --out")
+    a = ap.parse_args()
+    c, n, ms = summarise(a.csv, a.kernel)
+    if not c:
+        sys.exit(f"no rows of kernel {a.kernel!r} in {a.csv}")
+    rec = {"workload": a.workload, "pixels_per_launch": a.pixels, "counters_avg_per_dispatch": c,
+           "dispatches_per_counter": n, "kernel_ms_under_pmc": ms, "sources": [os.path.basename(p) for p in a.csv]}
+    if "WRITE_SIZE" in c and "FETCH_SIZE" in c:
+        rec["write_bytes"] = c["WRITE_SIZE"] * 1024
+        rec["fetch_bytes_raw"] = c["FETCH_SIZE"] * 1024
+        rec["traffic_bytes"] = rec["write_bytes"] + 2 * rec["fetch_bytes_raw"]
+        rec["algorithmic_bytes"] = a.pixels * 4
+    if "GRBM_GUI_ACTIVE" in c:
+        cyc = c["GRBM_GUI_ACTIVE"] / 8                                   # the counter sums the 8 XCDs
+        rec["cycles_per_xcd"] = cyc
+        t = [v for k, v in ms.items()]
+        if t:
+            rec["clock_ghz_under_pmc"] = cyc / (sum(t) / len(t) * 1e-3) / 1e9
+        simds = 256 * 4
+        for name, key in (("valu", "SQ_INSTS_VALU"), ("salu", "SQ_INSTS_SALU"), ("branch", "SQ_INSTS_BRANCH"), ("smem", "SQ_INSTS_SMEM")):
+            if key in c:
+                rec[f"{name}_wave_instructions_per_simd"] = c[key] / simds
+                rec[f"cycles_per_{name}_instruction_per_simd"] = cyc / (c[key] / simds)
+        if "SQ_INSTS_VALU" in c:
+            rec["valu_instructions_per_pixel"] = c["SQ_INSTS_VALU"] * 64 / a.pixels
+    out = {"source": "rocprofv3 --pmc passes on MI355X (tools/final_profile.sh), summarised by tools/pmc_summary.py",
+           "units": "WRITE_SIZE / FETCH_SIZE are KiB per dispatch as reported; bytes = KiB*1024; FETCH doubled per the gfx950 "
+                    "correction (MI355X_MICROARCH.md, HBM); GRBM_GUI_ACTIVE sums the 8 XCDs", "kernels": {}}
+    if a.merge and os.path.exists(a.out):
+        out = json.load(open(a.out))
+    out["kernels"][a.kernel] = rec
+    json.dump(out, open(a.out, "w"), indent=1)
+    print(json.dumps(rec, indent=1))
+
+
+if __name__ == "__main__":
+    main()
