@@ -300,15 +300,12 @@ def main():
     steps = args.steps
     if orbit:
         steps = len(cams)                             # one pass over this rank's stripe of the orbit
-    # Set-up, not measurement: keep the device busy for a quarter of a second so that the clocks have ramped before
+    # Set-up, not measurement: keep the device busy for about a quarter of a second so that the clocks have ramped before
     # the W warm-up steps — the timed region of the default run is only ~40 ms, and a cold start moved it by several %.
-    t_pre = time.perf_counter()
-    prewarm = 0
-    while time.perf_counter() - t_pre < 0.25:
-        step(prewarm, False)
-        prewarm += 1
-        if prewarm % 8 == 0:
-            fence()
+    # A fixed frame count per workload (every rank issues the same number of gathers), none for the 256-frame orbit.
+    prewarm = 0 if orbit else {"c2": 400, "c3": 100, "c4": 32 * world}[name]
+    for i in range(prewarm):
+        step(i, False)
     fence()
     for i in range(args.warmup):
         step(i, False)
