@@ -140,6 +140,9 @@ __device__ __forceinline__ float sd_round_box(V3 p, float cx, float cy, float cz
  * (Szabolcs Nagy's design from ARM optimized-routines): log2(x) from a 16-entry table + degree-5 polynomial,
  * y*log2(x) in binary64, 2^z from a 32-entry table + cubic, every a*b+c fused as in glibc's FMA build
  * (the variant x86-64 glibc selects on any CPU with FMA/AVX2).  Table values are the published ones.
+ * Provenance: algorithm and tables of glibc 2.35 e_powf.c / e_powf_log2_data.c / e_exp2f_data.c (GNU C Library,
+ * LGPL-2.1-or-later; originally ARM optimized-routines, MIT) — third-party numerics restated for bit-parity with
+ * the host libm, not part of the loltracer reference.
  * tests/test_gpu_powf.py compares it with the CPU's powf bit for bit over every float in [0, 1] for the
  * exponents in use and over millions of random (x, y) pairs including NaN / inf / negative / subnormal. */
 __device__ const double POWF_LOG2_TAB[16][2] = {
