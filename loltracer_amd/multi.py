@@ -130,6 +130,8 @@ class GatherPipeline:
             return
         self.work[slot] = None
         if self.asm_stream is not None:
+            w.wait()                                   # the render stream may overwrite local[slot] only after the
+                                                       # collective that reads it (two frames of slack at depth 2)
             with torch.cuda.stream(self.asm_stream):
                 w.wait()                               # orders the assembly stream after the collective
                 self.frame.copy_(assemble(self.staging[slot], self.h, self.band))
