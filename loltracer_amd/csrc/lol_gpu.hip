@@ -225,64 +225,6 @@ struct FastPaths {
 	}
 };
 
-/*
- * Post-order program → macro-ops of the interpreter (lol_kernel.h, Interp).  The accumulator is the top of the
- * post-order operand stack:
- *   primitive followed by SMIN / SMIN_R  → one macro-op: x = primitive, combined with acc at once.  In post-order
- *                                           SMIN pops b (top) then a; the primitive is the top, so x = b and the
- *                                           combine is sminf(acc, x); SMIN_R (top is a) gives sminf(x, acc);
- *   primitive otherwise                   → SET when nothing is on the stack yet, else PUSH (acc goes under);
- *   SMIN / SMIN_R after a non-primitive   → x = the popped entry under acc: SMIN has a = x, b = acc → sminf(x, acc);
- *                                           SMIN_R has a = acc, b = x → sminf(acc, x);
- *   TOP                                   → a flag on the macro-op that produced the value.
- * `fast` lists the smoothness constants whose fast blend factor was proven on the device.
- */
-std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast) {
-	std::vector<uint32_t> out;
-	auto fbits32 = [](float v) { uint32_t u; memcpy(&u, &v, 4); return u; };
-	int depth = 0;                                   /* post-order stack depth before the current op */
-	size_t last = 0;                                 /* start of the macro-op that produced the current acc */
-	for (uint32_t i = 0; i < P.n_ops; i++) {
-		const lol_op& o = P.ops[i];
-		auto smin_fields = [&](uint32_t* m, const lol_op& sm) {
-			m[9] = fbits32(sm.f[0]);
-			if (fast && fast->has(sm.f[0])) {
-				m[0] |= lol::MOP_FASTDIV;
-				m[10] = fbits32(2.0f * sm.f[0]);
-				m[11] = fbits32(0.5f * (1.0f / sm.f[0]));
-			}
-		};
-		if (o.op <= LOL_OP_PLANE) {
-			uint32_t m[lol::MOP_DWORDS] = { 0 };
-			const uint32_t kind = o.op == LOL_OP_SPHERE ? lol::MOP_SPHERE : o.op == LOL_OP_RBOX ? lol::MOP_RBOX : lol::MOP_PLANE;
-			for (int j = 0; j < 7; j++) m[2 + j] = fbits32(o.f[j]);
-			const lol_op* nx = i + 1 < P.n_ops ? &P.ops[i + 1] : nullptr;
-			if (nx && (nx->op == LOL_OP_SMIN || nx->op == LOL_OP_SMIN_R) && depth >= 1) {
-				m[0] = lol::mop_header(kind, nx->op == LOL_OP_SMIN ? lol::MOP_SMIN : lol::MOP_SMIN_X);
-				smin_fields(m, *nx);
-				i++;                                    /* the smooth min is part of this macro-op; depth unchanged */
-			} else {
-				m[0] = lol::mop_header(kind, depth == 0 ? lol::MOP_SET : lol::MOP_PUSH);
-				depth++;
-			}
-			last = out.size();
-			out.insert(out.end(), m, m + lol::MOP_DWORDS);
-		} else if (o.op == LOL_OP_SMIN || o.op == LOL_OP_SMIN_R) {
-			uint32_t m[lol::MOP_DWORDS] = { 0 };
-			m[0] = lol::mop_header(lol::MOP_POP, o.op == LOL_OP_SMIN ? lol::MOP_SMIN_X : lol::MOP_SMIN);
-			smin_fields(m, o);
-			depth--;
-			last = out.size();
-			out.insert(out.end(), m, m + lol::MOP_DWORDS);
-		} else {                                         /* LOL_OP_TOP */
-			out[last] |= lol::MOP_TOP;
-			out[last + 1] = o.id;
-			depth = 0;
-		}
-	}
-	return out;
-}
-
 /* ------------------------------------------------ exact culling of top-level objects
  * sdf() (naive_renderer.c:31-44) is a strict-'<' minimum over the top-level objects.  An object whose distance is
  * PROVABLY greater than the running minimum cannot change it, so its evaluation may be skipped — exactly, not
@@ -431,6 +373,80 @@ CullPlan plan_culling(const std::vector<RootBound>& roots, bool enabled) {
 			plan.tests.push_back(make_test({ true, { r.c[0], r.c[1], r.c[2] }, r.r }));
 		}
 	return plan;
+}
+
+/*
+ * Post-order program → macro-ops of the interpreter (lol_kernel.h, Interp).  The accumulator is the top of the
+ * post-order operand stack:
+ *   primitive followed by SMIN / SMIN_R  → one macro-op: x = primitive, combined with acc at once.  In post-order
+ *                                           SMIN pops b (top) then a; the primitive is the top, so x = b and the
+ *                                           combine is sminf(acc, x); SMIN_R (top is a) gives sminf(x, acc);
+ *   primitive otherwise                   → SET when nothing is on the stack yet, else PUSH (acc goes under);
+ *   SMIN / SMIN_R after a non-primitive   → x = the popped entry under acc: SMIN has a = x, b = acc → sminf(x, acc);
+ *                                           SMIN_R has a = acc, b = x → sminf(acc, x);
+ *   TOP                                   → a flag on the macro-op that produced the value (+ MOP_TIE where the
+ *                                           object is evaluated after one that follows it in the file).
+ * The objects come in the order of `plan` (unbounded ones first).  The plan's GROUP test — the one in front of all
+ * bounded objects — becomes a constants record behind the last unbounded object's final macro-op, which gets
+ * MOPB_CULL_NEXT; tests of single objects are a specialised-kernel refinement and are not carried over.
+ * `fast` lists the smoothness constants whose fast blend factor was proven on the device.
+ */
+std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast, const std::vector<RootBound>& roots,
+                                 const CullPlan& plan) {
+	std::vector<uint32_t> out;
+	auto fbits32 = [](float v) { uint32_t u; memcpy(&u, &v, 4); return u; };
+	auto smin_fields = [&](uint32_t* m, const lol_op& sm) {
+		m[9] = fbits32(sm.f[0]);
+		if (fast && fast->has(sm.f[0])) {
+			m[0] |= lol::MOP_FASTDIV;
+			m[10] = fbits32(2.0f * sm.f[0]);
+			m[11] = fbits32(0.5f * (1.0f / sm.f[0]));
+		}
+		m[0] |= lol::mop_smin_bits(m[0]);
+	};
+	size_t group_at = (size_t)-1;                    /* the constants record of the group test */
+	uint32_t max_id_seen = 0;
+	for (size_t oi = 0; oi < plan.order.size(); oi++) {
+		const RootBound& R = roots[plan.order[oi]];
+		int depth = 0;                                   /* post-order stack depth before the current op */
+		size_t last = 0;                                 /* start of the macro-op that produced the current acc */
+		for (uint32_t i = R.first; i < R.top; i++) {
+			const lol_op& o = P.ops[i];
+			uint32_t m[lol::MOP_DWORDS] = { 0 };
+			if (o.op <= LOL_OP_PLANE) {
+				const uint32_t kind = o.op == LOL_OP_SPHERE ? lol::MOP_SPHERE : o.op == LOL_OP_RBOX ? lol::MOP_RBOX : lol::MOP_PLANE;
+				for (int j = 0; j < 7; j++) m[2 + j] = fbits32(o.f[j]);
+				const lol_op* nx = i + 1 < R.top ? &P.ops[i + 1] : nullptr;
+				if (nx && (nx->op == LOL_OP_SMIN || nx->op == LOL_OP_SMIN_R) && depth >= 1) {
+					m[0] = lol::mop_header(kind, nx->op == LOL_OP_SMIN ? lol::MOP_SMIN : lol::MOP_SMIN_X);
+					smin_fields(m, *nx);
+					i++;                                /* the smooth min is part of this macro-op; depth unchanged */
+				} else {
+					m[0] = lol::mop_header(kind, depth == 0 ? lol::MOP_SET : lol::MOP_PUSH);
+					depth++;
+				}
+			} else {                                     /* SMIN / SMIN_R on two computed operands */
+				m[0] = lol::mop_header(lol::MOP_POP, o.op == LOL_OP_SMIN ? lol::MOP_SMIN_X : lol::MOP_SMIN);
+				smin_fields(m, o);
+				depth--;
+			}
+			last = out.size();
+			out.insert(out.end(), m, m + lol::MOP_DWORDS);
+		}
+		out[last] |= lol::MOP_TOP | lol::MOPB_TAIL | (R.id < max_id_seen ? lol::MOP_TIE : 0u);
+		out[last + 1] = R.id;
+		if (R.id > max_id_seen) max_id_seen = R.id;
+		if (plan.group && oi + 1 == plan.n_unbounded) {
+			out[last] |= lol::MOPB_CULL_NEXT;
+			uint32_t c[lol::MOP_DWORDS] = { 0 };
+			for (int j = 0; j < 3; j++) c[2 + j] = fbits32(plan.group_test.c[j]);
+			c[5] = fbits32(plan.group_test.rm);
+			group_at = out.size();
+			out.insert(out.end(), c, c + lol::MOP_DWORDS);
+		}
+	}
+	if (group_at != (size_t)-1) out[group_at + 1] = (uint32_t)((out.size() - group_at) / lol::MOP_DWORDS - 1);
+	return out;
 }
 
 /* Emits one `struct <name>` with eval(): one SSA temporary per op, same operation order WITHIN every top-level object
@@ -793,7 +809,8 @@ int lol_gpu_create(int device, lol_gpu** out) {
 	hipError_t e = hipSetDevice(device);
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_prog), sizeof(lol_program));
-	if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_mops), (size_t)LOL_MAX_OPS * lol::MOP_DWORDS * 4);
+	/* at most one macro-op per op, plus the group test's constants record */
+	if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_mops), (size_t)(LOL_MAX_OPS + 1) * lol::MOP_DWORDS * 4);
 	if (e != hipSuccess) {
 		fprintf(stderr, "lol_gpu_create: %s\n", hipGetErrorString(e));
 		lol_gpu_destroy(ctx);
@@ -920,9 +937,10 @@ int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog) {
 	{
 		FastPaths fast = prove_fast_paths(ctx, *prog);
 		ctx->interp_sqrt_kind = fast.sqrt_kind == 3 ? 3 : 0;
-		std::vector<uint32_t> mops = build_mops(*prog, &fast);
+		const std::vector<RootBound> roots = analyse_roots(*prog);
+		std::vector<uint32_t> mops = build_mops(*prog, &fast, roots, plan_culling(roots, culling_enabled(ctx->want_cull)));
 		ctx->n_mops = (uint32_t)(mops.size() / lol::MOP_DWORDS);
-		if (ctx->n_mops > LOL_MAX_OPS) return fail(ctx, LOL_GPU_ERR_UNSUPPORTED, "program exceeds interpreter limits");
+		if (ctx->n_mops > LOL_MAX_OPS + 1) return fail(ctx, LOL_GPU_ERR_UNSUPPORTED, "program exceeds interpreter limits");
 		hipError_t e = hipMemcpy(ctx->d_prog, prog, sizeof *prog, hipMemcpyHostToDevice);
 		if (e == hipSuccess && !mops.empty())
 			e = hipMemcpy(ctx->d_mops, mops.data(), mops.size() * 4, hipMemcpyHostToDevice);

@@ -386,8 +386,28 @@ constexpr u32 MOPB_SPHERE = 1u, MOPB_RBOX = 2u, MOPB_PLANE = 4u, MOPB_POP = 8u;
 constexpr u32 MOP_FASTDIV = 16u;     /* the smooth min's blend factor was proven for this k: f[8] = 2k, f[9] = .5/k */
 constexpr u32 MOP_TOP = 32u;         /* acc is a finished top-level object: id in word 1                           */
 constexpr u32 MOPB_PUSH = 64u, MOPB_SMIN = 128u, MOPB_X_IS_A = 256u;   /* SET = none of PUSH / SMIN */
+/* summary bits, so that the common record (a sphere, no push, not the end of an object) pays ONE s_bitcmp for each
+ * group of rare cases instead of an s_and + s_cmp: */
+constexpr u32 MOPB_NOT_SPHERE = 512u;   /* = RBOX | PLANE | POP */
+constexpr u32 MOPB_TAIL = 1024u;        /* = PUSH | TOP (set by build_mops when it sets MOP_TOP) */
+/* which smooth min, one bit each (set by build_mops next to MOPB_SMIN / MOPB_X_IS_A / MOP_FASTDIV): */
+constexpr u32 MOPB_SMIN_AF = 2048u;     /* sminf_fastdiv(acc, x) */
+constexpr u32 MOPB_SMIN_XF = 4096u;     /* sminf_fastdiv(x, acc) */
+constexpr u32 MOPB_SMIN_EXACT = 8192u;  /* unproven k: sminf_ with the correctly rounded division, order by MOPB_X_IS_A */
+/* Exact object culling (lol_gpu.hip, "exact culling") in the interpreter: a record that finishes a top-level object
+ * (MOP_TOP) may carry MOPB_CULL_NEXT — the NEXT record is then not a macro-op but the test's constants
+ * {f[0..2] = C, f[3] = R', word 1 = how many records after it belong to the objects the test guards}; if every lane
+ * that cares may skip them, they are jumped over.  Lives in the rare TAIL branch, so ordinary records pay nothing. */
+constexpr u32 MOPB_CULL_NEXT = 16384u;
+constexpr u32 MOP_TIE = 32768u;         /* with MOP_TOP: evaluated after an object that follows it in the file → ties go to the lower id */
+constexpr float CULL_K = 1.0f + 0x1p-12f;
+constexpr u32 CULL_COOLDOWN = 3u;       /* after a test that did not allow the skip, this many evaluations do not test */
+__host__ __device__ constexpr u32 mop_smin_bits(u32 hdr) {
+	return !(hdr & MOPB_SMIN) ? 0u : !(hdr & MOP_FASTDIV) ? MOPB_SMIN_EXACT : (hdr & MOPB_X_IS_A) ? MOPB_SMIN_XF : MOPB_SMIN_AF;
+}
 __host__ __device__ constexpr u32 mop_header(u32 kind, u32 comb) {
-	return (1u << kind) | (comb == MOP_PUSH ? MOPB_PUSH : comb == MOP_SMIN ? MOPB_SMIN : comb == MOP_SMIN_X ? (MOPB_SMIN | MOPB_X_IS_A) : 0u);
+	return (1u << kind) | (kind != MOP_SPHERE ? MOPB_NOT_SPHERE : 0u) |
+	       (comb == MOP_PUSH ? (MOPB_PUSH | MOPB_TAIL) : comb == MOP_SMIN ? MOPB_SMIN : comb == MOP_SMIN_X ? (MOPB_SMIN | MOPB_X_IS_A) : 0u);
 }
 
 /* scalar (constant address space) view of the list; loaded dword by dword — the compiler merges the loads into
@@ -399,26 +419,25 @@ struct Interp {
 	const u32* mops;     /* global memory, MOP_DWORDS per macro-op, 16-byte aligned */
 	u32        n_mops;
 	Range      rg;       /* KIND != 0: range of the squared lengths given to the proven fast sqrt (see above) */
+	u32        cool;     /* evaluations left before a CULL_NEXT record tests again (wave-uniform) */
 
 	/* Inlined into the march / normal / shadow loops: as a real (noinline) function it was 8 % slower — arguments
 	 * travel in VGPRs and need v_readfirstlane, plus call / return and the callee's register shuffling. */
 	__device__ __forceinline__ void eval(V3 p, float& best_out, u32& id_out, bool care = true) {
-		(void)care;      /* which lanes still need the result: only the specialised SDF's object culling uses it.  Culling was
-		                  * tried here too (CULL records / block headers): the extra scalar work in this SALU-bound loop cost
-		                  * more (-11 %) than the skipped objects gave back (+9 %), so the interpreter evaluates every object. */
 		/* everything the loop carries is a local: the trip count and the list pointer must stay provably
 		 * wave-uniform (scalar loop, scalar loads, scalar branches), which they do not when they live behind
 		 * `this` next to per-lane results written through references */
 		const u32 n = n_mops;
 		mop_ptr rec = (mop_ptr)(unsigned long long)mops;
 		Range r = rg;
+		u32 cl = cool;
 		float s[SSIZE];
 #pragma unroll
 		for (int i = 0; i < SSIZE; i++) s[i] = 0.f;
 		float acc = 0.f;
 		float best = __builtin_inff();
 		u32 best_id = 0;
-		for (u32 i = 0; i < n; i++, rec += MOP_DWORDS) {
+		for (u32 left = n; left != 0u; left--, rec += MOP_DWORDS) {       /* (the TAIL branch may jump further) */
 			const u32 hdr = rec[0];
 			auto F = [&](int j) { return __builtin_bit_cast(float, rec[j]); };
 			/* one-hot header bits, tested one by one (s_bitcmp1 + s_cbranch each) with no else-chains: every `if`
@@ -429,7 +448,7 @@ struct Interp {
 			float x = 0.f;
 			if (hdr & MOPB_SPHERE)
 				x = KIND ? sd_sphere_fast<KIND ? KIND : 1>(p, F(2), F(3), F(4), F(5), r) : sd_sphere(p, F(2), F(3), F(4), F(5));
-			if (hdr & (MOPB_RBOX | MOPB_PLANE | MOPB_POP)) {         /* grouped: a sphere macro-op pays one test for these */
+			if (hdr & MOPB_NOT_SPHERE) {                             /* grouped: a sphere macro-op pays one test for these */
 				LOL_KEEP_BRANCH();
 				if (hdr & MOPB_RBOX)
 					x = KIND ? sd_round_box_fast<KIND ? KIND : 1>(p, F(2), F(3), F(4), F(5), F(6), F(7), F(8), r)
@@ -444,15 +463,18 @@ struct Interp {
 				}
 			}
 			if (hdr & MOPB_SMIN) {
-				if (hdr & MOPB_X_IS_A) {
+				/* four independent skip-aheads (operand order x fast / exact blend factor), the common fast ones first:
+				 * a nested if / ?: here made the compiler hoist the FASTDIV test through a VGPR and add flag registers */
+				LOL_KEEP_BRANCH();
+				if (hdr & MOPB_SMIN_AF) { LOL_KEEP_BRANCH(); x = sminf_fastdiv(acc, x, F(9), F(10), F(11)); }
+				if (hdr & MOPB_SMIN_XF) { LOL_KEEP_BRANCH(); x = sminf_fastdiv(x, acc, F(9), F(10), F(11)); }
+				if (hdr & MOPB_SMIN_EXACT) {
 					LOL_KEEP_BRANCH();
-					x = (hdr & MOP_FASTDIV) ? sminf_fastdiv(x, acc, F(9), F(10), F(11)) : sminf_(x, acc, F(9));
-				} else {
-					LOL_KEEP_BRANCH();
-					x = (hdr & MOP_FASTDIV) ? sminf_fastdiv(acc, x, F(9), F(10), F(11)) : sminf_(acc, x, F(9));
+					if (!(hdr & MOPB_X_IS_A)) { LOL_KEEP_BRANCH(); x = sminf_(acc, x, F(9)); }
+					if (hdr & MOPB_X_IS_A) { LOL_KEEP_BRANCH(); x = sminf_(x, acc, F(9)); }
 				}
 			}
-			if (hdr & (MOPB_PUSH | MOP_TOP)) {
+			if (hdr & MOPB_TAIL) {
 				LOL_KEEP_BRANCH();
 				if (hdr & MOPB_PUSH) {
 					LOL_KEEP_BRANCH();
@@ -462,13 +484,36 @@ struct Interp {
 				}
 				if (hdr & MOP_TOP) {
 					LOL_KEEP_BRANCH();
-					if (x < best) { best = x; best_id = rec[1]; }
+					const u32 id = rec[1];
+					if (!(hdr & MOP_TIE)) { LOL_KEEP_BRANCH(); if (x < best) { best = x; best_id = id; } }
+					if (hdr & MOP_TIE) { LOL_KEEP_BRANCH(); if (x < best || (x == best && best_id > id)) { best = x; best_id = id; } }
+				}
+				if (hdr & MOPB_CULL_NEXT) {
+					LOL_KEEP_BRANCH();
+					rec += MOP_DWORDS;                              /* the constants record is consumed either way */
+					left--;
+					if (cl == 0u) {
+						LOL_KEEP_BRANCH();
+						const float cx = p.x - F(2), cy = p.y - F(3), cz = p.z - F(4);
+						const float l2 = (cx * cx + cy * cy) + cz * cz;
+						const float u = (best + F(5)) * CULL_K;
+						const bool skip = l2 > u * u && u > 0.f;
+						if (__ballot(care && !skip) == 0) {
+							LOL_KEEP_BRANCH();
+							const u32 k = rec[1];
+							rec += k * MOP_DWORDS;
+							left -= k;
+						}
+						if (__ballot(care && !skip) != 0) { LOL_KEEP_BRANCH(); cl = CULL_COOLDOWN + 1u; }
+					}
+					cl = cl ? cl - 1u : 0u;
 				}
 			}
 			acc = x;
 #undef LOL_KEEP_BRANCH
 		}
 		rg = r;
+		cool = cl;
 		best_out = best;
 		id_out = best_id;
 	}
@@ -694,10 +739,10 @@ void render_interp(const Launch L) {
 	extern __shared__ u32 lds[];
 	stage_common(L, lds);
 	__syncthreads();
-	Interp<SSIZE, KIND> sdf{ L.ops, L.n_ops, {} };
+	Interp<SSIZE, KIND> sdf{ L.ops, L.n_ops, {}, 0u };
 	Pixel P = shade_pixel(L, sdf, lds);
 	if (KIND != 0 && __ballot(sdf.rg.outside()) != 0) {
-		Interp<SSIZE, 0> exact{ L.ops, L.n_ops, {} };
+		Interp<SSIZE, 0> exact{ L.ops, L.n_ops, {}, 0u };
 		P = shade_pixel(L, exact, lds);
 	}
 	store_pixel(L, P, lds);
@@ -723,8 +768,8 @@ __device__ __forceinline__ void sdf_points(SdfFast& fast, SdfExact& exact, bool 
 template <int SSIZE, int KIND>
 __global__ __launch_bounds__(64)
 void sdf_points_interp(const u32* mops, u32 n_mops, const float* pts, float* dist, u32* id, u32 n) {
-	Interp<SSIZE, KIND> fast{ mops, n_mops, {} };
-	Interp<SSIZE, 0> exact{ mops, n_mops, {} };
+	Interp<SSIZE, KIND> fast{ mops, n_mops, {}, 0u };
+	Interp<SSIZE, 0> exact{ mops, n_mops, {}, 0u };
 	sdf_points(fast, exact, KIND != 0, pts, dist, id, n);
 }
 
