@@ -80,21 +80,25 @@ def test_what_has_no_bound():
 
 # ------------------------------------------------------------------ on the GPU
 
-def _render(torch, sc, w, h, cull):
+KERNELS = {1: "lol_render_spec", 4: "render_interp"}
+
+
+def _render(torch, sc, w, h, cull, mode):
     from test_gpu_parity import gpu_render
-    r = gpu.Renderer(0)
+    r = gpu.Renderer(0, specialize=mode)
     r.set_cull(cull)
     g = gpu_render(torch, r, sc, w, h)
-    assert r.kernel_name() == "lol_render_spec"
+    assert r.kernel_name() == KERNELS[mode]
     r.close()
     return g
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1, 4], ids=["spec", "interp"])
 @pytest.mark.parametrize("name,w,h", [("scene4", 640, 360), ("scene", 480, 270), ("scene2", 320, 200), ("scene3", 320, 200)])
-def test_culling_changes_nothing(scenes, name, w, h):
+def test_culling_changes_nothing(scenes, name, w, h, mode):
     import torch
-    a, b = _render(torch, scenes[name], w, h, True), _render(torch, scenes[name], w, h, False)
+    a, b = _render(torch, scenes[name], w, h, True, mode), _render(torch, scenes[name], w, h, False, mode)
     for key in ("xrgb", "id", "steps"):
         assert np.array_equal(a[key], b[key]), key
     assert np.array_equal(a["dist"].view(np.uint32), b["dist"].view(np.uint32))
@@ -116,8 +120,8 @@ def test_ties_go_to_the_first_object_after_reordering():
         oid = C.c_uint32()
         want.append((l.lol_oracle_sdf(sc.ptr, float(p[0]), float(p[1]), float(p[2]), C.byref(oid)), oid.value))
     assert want[0] == (1.0, 1) and want[4][1] in (2, 4)
-    for cull in (True, False):
-        r = gpu.Renderer(0)
+    for cull, mode in ((True, 1), (False, 1), (True, 4), (False, 4)):
+        r = gpu.Renderer(0, specialize=mode)
         r.set_cull(cull)
         r.prepare(sc)
         d_pts = torch.from_numpy(pts.copy()).cuda()
@@ -126,5 +130,5 @@ def test_ties_go_to_the_first_object_after_reordering():
         r.sdf_batch(d_pts.data_ptr(), d_dist.data_ptr(), d_id.data_ptr(), len(pts), stream=torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         got = list(zip(d_dist.cpu().tolist(), d_id.cpu().tolist()))
-        assert got == want, (cull, got, want)
+        assert got == want, (cull, mode, got, want)
         r.close()
