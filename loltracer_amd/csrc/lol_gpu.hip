@@ -21,6 +21,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 #include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -640,17 +642,81 @@ struct Roctx {
 std::mutex g_cache_mutex;
 std::unordered_map<std::string, std::vector<char>> g_code_cache;
 
+/* ... and a cache on disk, so that the N ranks of a multi-GPU run (and the next run of the same host) do not each
+ * pay the 0.3 - 1 s hipRTC compile of the same scene.  One file per key under LOL_GPU_CACHE_DIR (default
+ * $XDG_CACHE_HOME/lol_gpu or $HOME/.cache/lol_gpu; set it to the empty string to switch the disk cache off): the
+ * file holds the full key in front of the code object and is only used when that key matches byte for byte, so a
+ * hash collision or a stale file can never hand out the wrong kernel; writes go through a temporary name + rename.
+ * Any I/O failure simply means "not cached". */
+std::string disk_cache_path(const std::string& key) {
+	const char* e = getenv("LOL_GPU_CACHE_DIR");
+	std::string dir;
+	if (e) { if (!e[0]) return ""; dir = e; }
+	else if (const char* x = getenv("XDG_CACHE_HOME")) { if (!x[0]) return ""; dir = std::string(x) + "/lol_gpu"; }
+	else if (const char* h = getenv("HOME")) { if (!h[0]) return ""; dir = std::string(h) + "/.cache/lol_gpu"; }
+	else return "";
+	for (size_t i = 1; i <= dir.size(); i++)              /* mkdir -p */
+		if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0700);
+	unsigned long long h = 0xcbf29ce484222325ull;         /* FNV-1a of the key names the file */
+	for (unsigned char c : key) { h ^= c; h *= 0x100000001b3ull; }
+	char name[40];
+	snprintf(name, sizeof name, "/%016llx.co", h);
+	return dir + name;
+}
+
+bool disk_cache_load(const std::string& key, std::vector<char>& code) {
+	const std::string path = disk_cache_path(key);
+	if (path.empty()) return false;
+	FILE* f = fopen(path.c_str(), "rb");
+	if (!f) return false;
+	bool ok = false;
+	unsigned long long klen = 0, clen = 0;
+	if (fread(&klen, 8, 1, f) == 1 && fread(&clen, 8, 1, f) == 1 && klen == key.size() && clen > 0 && clen < (1ull << 28)) {
+		std::string k(klen, 0);
+		code.resize(clen);
+		ok = fread(&k[0], 1, klen, f) == klen && k == key && fread(code.data(), 1, clen, f) == clen;
+	}
+	fclose(f);
+	return ok;
+}
+
+void disk_cache_store(const std::string& key, const std::vector<char>& code) {
+	const std::string path = disk_cache_path(key);
+	if (path.empty()) return;
+	char tmp[64];
+	snprintf(tmp, sizeof tmp, ".%ld.tmp", (long)getpid());
+	const std::string t = path + tmp;
+	FILE* f = fopen(t.c_str(), "wb");
+	if (!f) return;
+	const unsigned long long klen = key.size(), clen = code.size();
+	const bool ok = fwrite(&klen, 8, 1, f) == 1 && fwrite(&clen, 8, 1, f) == 1 && fwrite(key.data(), 1, klen, f) == klen &&
+	                fwrite(code.data(), 1, clen, f) == clen;
+	if (fclose(f) != 0 || !ok || rename(t.c_str(), path.c_str()) != 0) (void)remove(t.c_str());
+}
+
 bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string& arch, std::vector<char>& code,
                   std::string& log, std::string* src_out = nullptr, const int* shape = nullptr, bool cull = true) {
 	std::string src = generate_source(P, fast, cull);
 	if (src_out) *src_out = src;
-	std::string key = arch + "|" + (getenv("LOL_GPU_RTC_FLAGS") ? getenv("LOL_GPU_RTC_FLAGS") : "") + "|";
+	int rtc_major = 0, rtc_minor = 0;
+	(void)hiprtcVersion(&rtc_major, &rtc_minor);
+	std::string key = "lol_gpu/1|hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) + "|" + arch + "|" +
+	                  (getenv("LOL_GPU_RTC_FLAGS") ? getenv("LOL_GPU_RTC_FLAGS") : "") + "|";
 	if (shape) key += std::to_string(shape[0]) + "x" + std::to_string(shape[1]) + "x" + std::to_string(shape[2]);
 	key += "|" + src;
 	{
 		std::lock_guard<std::mutex> lock(g_cache_mutex);
 		auto it = g_code_cache.find(key);
 		if (it != g_code_cache.end()) { code = it->second; log.clear(); return true; }
+	}
+	/* on disk the pipeline source (lol_kernel.h, embedded in this library) is part of the key: another build of the
+	 * library must not pick up this one's kernels */
+	const std::string disk_key = key + "|" + LOL_KERNEL_H_TEXT;
+	if (disk_cache_load(disk_key, code)) {
+		std::lock_guard<std::mutex> lock(g_cache_mutex);
+		g_code_cache[key] = code;
+		log = "(code object from the disk cache)";
+		return true;
 	}
 	const char* hdr_src[] = { LOL_KERNEL_H_TEXT };
 	const char* hdr_name[] = { "lol_kernel.h" };
@@ -700,6 +766,7 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
 		std::lock_guard<std::mutex> lock(g_cache_mutex);
 		g_code_cache[key] = code;
 	}
+	disk_cache_store(disk_key, code);
 	return true;
 }
 

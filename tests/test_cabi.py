@@ -67,3 +67,35 @@ def test_scene_specialised_kernel_compiles_without_a_device(tmp_path, scenes):
     assert src4.count("sminf_(") == 4 and src4.count("sd_sphere(") == 5 and "best_id = 2u" in src4
     # constants are emitted as exact bit patterns: sphere radius 0.5 and smoothness 3
     assert "0x3f000000u" in src4 and "0x40400000u" in src4
+
+
+def test_code_objects_are_cached_on_disk(tmp_path, scenes):
+    """hipRTC output is kept under LOL_GPU_CACHE_DIR: a second process (another rank, the next run) loads it instead of
+    compiling; a damaged or foreign file is ignored, never trusted; an empty LOL_GPU_CACHE_DIR switches the cache off."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from loltracer_amd import gpu, scene as S\n"
+            "sc = S.Scene.parse_file(%r)\n"
+            "print(gpu.compile_offline(sc.flatten(), %r))\n") % (ROOT, os.path.join(ROOT, "tests", "golden", "scenes", "scene2.lol"),
+                                                                 str(tmp_path / "k"))
+
+    def run(cache):
+        env = dict(os.environ, LOL_GPU_CACHE_DIR=cache)
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr
+        return p.stdout
+
+    cache = str(tmp_path / "cache" / "nested")
+    assert "disk cache" not in run(cache)
+    files = os.listdir(cache)
+    assert len(files) == 1 and files[0].endswith(".co")
+    first = open(str(tmp_path / "k.co"), "rb").read()
+    assert "disk cache" in run(cache)
+    assert open(str(tmp_path / "k.co"), "rb").read() == first
+    with open(os.path.join(cache, files[0]), "r+b") as f:         # damage the key stored in front of the code object
+        f.seek(40)
+        f.write(b"XXXX")
+    assert "disk cache" not in run(cache)                         # recompiled, and the entry rewritten
+    assert "disk cache" in run(cache)
+    assert "disk cache" not in run("")                            # switched off
