@@ -372,7 +372,8 @@ __device__ __forceinline__ float sd_round_box_fast(V3 p, float cx, float cy, flo
  * so a chain of smooth unions whose one child is a primitive never touches the stack, and scene4's ten
  * post-order ops are seven macro-ops.
  *
- * The records (12 dwords) are wave-uniform data and are fetched with SCALAR loads straight into SGPRs
+ * Record = 12 dwords: header bits | object id (TOP) | 7 primitive parameters | k, 2k, .5/k of the smooth min.
+ * The records are wave-uniform data and are fetched with SCALAR loads straight into SGPRs
  * (constant address space, uniform index → s_load_dwordx4 through the scalar cache): measured on MI355X
  * (tools/salu_rate.hip) a scalar-cache dword costs ~2 cycles per SIMD against 8.6 for a ds_read_b32 in which all
  * 64 lanes read one LDS address, and it needs no LDS-address VGPR and no v_readfirstlane; the header word is
@@ -383,7 +384,7 @@ enum { MOP_SPHERE = 0, MOP_RBOX = 1, MOP_PLANE = 2, MOP_POP = 3 };          /* w
 enum { MOP_SET = 0, MOP_PUSH = 1, MOP_SMIN = 2, MOP_SMIN_X = 3 };           /* how it is combined */
 /* header word: one bit per decision */
 constexpr u32 MOPB_SPHERE = 1u, MOPB_RBOX = 2u, MOPB_PLANE = 4u, MOPB_POP = 8u;
-constexpr u32 MOP_FASTDIV = 16u;     /* the smooth min's blend factor was proven for this k: f[8] = 2k, f[9] = .5/k */
+constexpr u32 MOP_FASTDIV = 16u;     /* the smooth min's blend factor was proven for this k (word 9): words 10, 11 = 2k, .5/k */
 constexpr u32 MOP_TOP = 32u;         /* acc is a finished top-level object: id in word 1                           */
 constexpr u32 MOPB_PUSH = 64u, MOPB_SMIN = 128u, MOPB_X_IS_A = 256u;   /* SET = none of PUSH / SMIN */
 /* summary bits, so that the common record (a sphere, no push, not the end of an object) pays ONE s_bitcmp for each
