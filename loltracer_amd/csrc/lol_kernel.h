@@ -578,7 +578,7 @@ __device__ __forceinline__ V3 normal_at(Sdf& sdf, V3 p, float dist) {
 	const float h = dist / 100.f;
 	const float nh = -1.f * h;       /* v3scale(k, h) multiplies; -1*h == -h bit for bit */
 	V3 acc = { 0.f, 0.f, 0.f };
-#pragma unroll 1
+#pragma unroll 1      /* (unrolled — four independent evaluations in flight — it is 0.8 % slower within the 64-VGPR budget) */
 	for (int k = 3; k >= 0; k--) {
 		/* sign pattern of tap k, wave-uniform: x is + for k0,k3; y is + for k2,k3; z is + for k1,k3 */
 		const bool px = k == 0 || k == 3, py = k >= 2, pz = k == 1 || k == 3;
