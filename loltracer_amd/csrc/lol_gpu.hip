@@ -764,6 +764,23 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
 	}
 	for (auto& x : extra) opts.push_back(x.c_str());
 	hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
+	if (r != HIPRTC_SUCCESS) {
+		/* a hipRTC that does not know the scheduling option must not cost the specialisation: once more without it */
+		std::vector<const char*> plain;
+		for (size_t i = 0; i < opts.size(); i++) {
+			if (!strcmp(opts[i], "-mllvm") && i + 1 < opts.size() && !strcmp(opts[i + 1], "-amdgpu-sched-strategy=max-ilp")) { i++; continue; }
+			plain.push_back(opts[i]);
+		}
+		if (plain.size() != opts.size()) {
+			hiprtcDestroyProgram(&prog);
+			prog = nullptr;
+			if (hiprtcCreateProgram(&prog, src.c_str(), "lol_render_spec.hip", 1, hdr_src, hdr_name) != HIPRTC_SUCCESS) {
+				log = "hiprtcCreateProgram failed";
+				return false;
+			}
+			r = hiprtcCompileProgram(prog, (int)plain.size(), plain.data());
+		}
+	}
 	size_t log_size = 0;
 	hiprtcGetProgramLogSize(prog, &log_size);
 	log.clear();
