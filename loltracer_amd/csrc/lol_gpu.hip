@@ -713,7 +713,8 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
 	int rtc_major = 0, rtc_minor = 0;
 	(void)hiprtcVersion(&rtc_major, &rtc_minor);
 	std::string key = "lol_gpu/2|hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) + "|" + arch + "|" +
-	                  (getenv("LOL_GPU_RTC_FLAGS") ? getenv("LOL_GPU_RTC_FLAGS") : "") + "|";
+	                  (getenv("LOL_GPU_RTC_FLAGS") ? getenv("LOL_GPU_RTC_FLAGS") : "") + "|" +
+	                  (getenv("LOL_GPU_SCHED") ? getenv("LOL_GPU_SCHED") : "") + "|";
 	if (shape) key += std::to_string(shape[0]) + "x" + std::to_string(shape[1]) + "x" + std::to_string(shape[2]);
 	key += "|" + src;
 	{
@@ -752,9 +753,14 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
 	/* -amdgpu-sched-strategy=max-ilp: schedule for instruction-level parallelism within a wave rather than for
 	 * occupancy.  The default strategy serialises the independent primitives of a long smooth-union chain to save
 	 * registers; with max-ILP the same instructions run 1.4x faster on 142 - 1024-op scenes and 2 - 5 % faster on the
-	 * example scenes (generate_source sets the matching register budget).  Scheduling only: same instructions, same bits. */
+	 * example scenes (generate_source sets the matching register budget).  Scheduling only: same instructions, same bits.
+	 * An LLVM that does not know an -mllvm option ends the PROCESS from its option parser, so the option is only
+	 * passed to hipRTC versions it was verified on (hiprtcVersion >= 9.0 = ROCm 7.x); LOL_GPU_RTC_FLAGS can add it
+	 * elsewhere, LOL_GPU_SCHED=default leaves it out. */
 	std::vector<const char*> opts = { arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
-	                                  "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp" };
+	                                  "-fno-slp-vectorize" };
+	const char* sched = getenv("LOL_GPU_SCHED");
+	if (rtc_major >= 9 && !(sched && !strcmp(sched, "default"))) { opts.push_back("-mllvm"); opts.push_back("-amdgpu-sched-strategy=max-ilp"); }
 	char d0[32], d1[32], d2[32];
 	if (shape) {
 		snprintf(d0, sizeof d0, "-DLOL_WAVE_W=%d", shape[0]);
