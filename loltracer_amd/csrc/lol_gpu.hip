@@ -457,7 +457,7 @@ std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast, co
  * loops call, instead of being inlined into each of them — for large scenes, whose straight-line SDF would
  * otherwise be replicated six times (three loops x fast / exact) and outgrow the instruction cache. */
 void emit_sdf(std::string& s, const lol_program& P, const char* name, const FastPaths* fast, bool out_of_line,
-              const std::vector<RootBound>& roots, const CullPlan& plan) {
+              const std::vector<RootBound>& roots, const CullPlan& plan, const std::string& occupancy) {
 	char line[768];
 	const int fsqrt = fast ? fast->sqrt_kind : 0;
 	char fs[32] = "";
@@ -467,8 +467,11 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 	if (total_tests) snprintf(cool_decl, sizeof cool_decl, "\tu32 cool[%d] = {};\n", total_tests);
 	if (out_of_line) {
 		/* out of line the cool-down state is per call (always 0: every evaluation tests) */
+		/* (amdgpu_waves_per_eu applies to kernels only: the function is scheduled with the default register budget) */
+		(void)occupancy;
 		snprintf(line, sizeof line, "__device__ __noinline__ SdfOut %s_fn(float px, float py, float pz, u32 rg_lo, u32 rg_hi, bool care) {\n"
-		         "\t\tconst V3 p = { px, py, pz };\n\t\tRange rg; rg.lo = rg_lo; rg.hi = rg_hi;\n\t\tfloat best; u32 best_id;\n\t%s", name, cool_decl);
+		         "\t\tconst V3 p = { px, py, pz };\n\t\tRange rg; rg.lo = rg_lo; rg.hi = rg_hi;\n\t\tfloat best; u32 best_id;\n\t%s",
+		         name, cool_decl);
 		s += line;
 	} else {
 		snprintf(line, sizeof line, "struct %s {\n\tRange rg;\n%s", name, cool_decl);
@@ -584,11 +587,6 @@ std::string generate_source(const lol_program& P, const FastPaths* fast, bool cu
 	const CullPlan plan = plan_culling(roots, cull);
 	s += "#include \"lol_kernel.h\"\n";
 	s += "namespace lol {\n";
-	if (ool) s += "struct SdfOut { float best; u32 id; u32 lo, hi; };\n";
-	emit_sdf(s, P, "SpecSdfExact", nullptr, ool, roots, plan);
-	const bool any_fast = fast && (fast->sqrt_kind || !fast->div_ok.empty());
-	if (any_fast) emit_sdf(s, P, "SpecSdfFast", fast, ool, roots, plan);
-	s += "}  // namespace lol\n";
 	/* Register budget.  The SDF of one object is a long dependent chain (every smooth min waits for the one below
 	 * it) fed by independent primitives, and the kernel is compiled with the max-ILP scheduling strategy
 	 * (compile_spec): the more registers a wave may use, the more primitives it keeps in flight.  Measured on
@@ -601,6 +599,11 @@ std::string generate_source(const lol_program& P, const FastPaths* fast, bool cu
 		if (sscanf(e, "%d,%d", &lo, &hi) == 2 && lo >= 1 && hi >= lo && hi <= 8) { waves_lo = lo; waves_hi = hi; }
 	}
 	const std::string occupancy = " __attribute__((amdgpu_waves_per_eu(" + std::to_string(waves_lo) + ", " + std::to_string(waves_hi) + ")))";
+	if (ool) s += "struct SdfOut { float best; u32 id; u32 lo, hi; };\n";
+	emit_sdf(s, P, "SpecSdfExact", nullptr, ool, roots, plan, occupancy);
+	const bool any_fast = fast && (fast->sqrt_kind || !fast->div_ok.empty());
+	if (any_fast) emit_sdf(s, P, "SpecSdfFast", fast, ool, roots, plan, occupancy);
+	s += "}  // namespace lol\n";
 	s += "extern \"C\" __global__ __launch_bounds__(lol::BLOCK)" + occupancy + " void lol_render_spec(const lol::Launch L) {\n";
 	s += "\textern __shared__ lol::u32 lds[];\n";
 	s += "\tlol::stage_common(L, lds);\n";
@@ -760,7 +763,12 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
 	std::vector<const char*> opts = { arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
 	                                  "-fno-slp-vectorize" };
 	const char* sched = getenv("LOL_GPU_SCHED");
-	if (rtc_major >= 9 && !(sched && !strcmp(sched, "default"))) { opts.push_back("-mllvm"); opts.push_back("-amdgpu-sched-strategy=max-ilp"); }
+	if (rtc_major >= 9 && !(sched && !strcmp(sched, "default"))) {
+		opts.push_back("-mllvm"); opts.push_back("-amdgpu-sched-strategy=max-ilp");
+		/* ... and no post-RA scheduling pass: it re-orders the ILP-friendly schedule after register allocation and
+		 * costs 10 % on C3 (4650 -> 5150 Mpixels/s without it, same box and call; nothing on the large scenes) */
+		opts.push_back("-mllvm"); opts.push_back("-enable-post-misched=0");
+	}
 	char d0[32], d1[32], d2[32];
 	if (shape) {
 		snprintf(d0, sizeof d0, "-DLOL_WAVE_W=%d", shape[0]);
@@ -774,7 +782,8 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
 		/* a hipRTC that does not know the scheduling option must not cost the specialisation: once more without it */
 		std::vector<const char*> plain;
 		for (size_t i = 0; i < opts.size(); i++) {
-			if (!strcmp(opts[i], "-mllvm") && i + 1 < opts.size() && !strcmp(opts[i + 1], "-amdgpu-sched-strategy=max-ilp")) { i++; continue; }
+			if (!strcmp(opts[i], "-mllvm") && i + 1 < opts.size() &&
+			    (!strcmp(opts[i + 1], "-amdgpu-sched-strategy=max-ilp") || !strcmp(opts[i + 1], "-enable-post-misched=0"))) { i++; continue; }
 			plain.push_back(opts[i]);
 		}
 		if (plain.size() != opts.size()) {
