@@ -4,7 +4,11 @@
  * the GPU box).
  *
  *   lol_headless <threads> <scene.lol> [--size WxH] [--frames N] [--out frame.ppm]
- *                [--orbit] [--pipeline] [renderer flags: --device N | --devices A,B,.. --max-steps N]
+ *                [--orbit] [--keys SCRIPT] [--dump-camera FILE] [--pipeline]
+ *                [renderer flags: --device N | --devices A,B,.. --max-steps N]
+ *   --keys "W,W,WA,<,<^,."   held keys per frame (W A S D, _ = Space, c = LCtrl, ^ v < > = arrows): the camera is moved
+ *                            by main.c's update_camera before every frame, as the windowed host does with key events
+ *   --dump-camera FILE       one line per frame: the camera's point and direction as binary32 hex
  *
  * Protocol reproduced from main.c (the caller side of SURVEY.md §8b):
  *   - argv[1] = worker threads, argv[2] = scene file, argv[3..] go to render_prepare  (main.c:223-242)
@@ -23,6 +27,7 @@
 #include <time.h>
 
 #include "hip_renderer_host.h"
+#include "lol_host_input.h"
 
 atomic_int exiting;
 atomic_int current_line;
@@ -54,11 +59,15 @@ int main(int argc, const char* argv[]) {
 	const char* path = argc > 2 ? argv[2] : NULL;
 	int w = 320, h = 240, frames = 1, orbit = 0, pipeline = 0;         /* main.c:152-159 opens 320x240 */
 	const char* out = NULL;
+	const char* keys = NULL;
+	const char* dump_camera = NULL;
 	for (int i = 3; i < argc; i++) {
 		if (!strcmp(argv[i], "--size") && i + 1 < argc) sscanf(argv[++i], "%dx%d", &w, &h);
 		else if (!strcmp(argv[i], "--frames") && i + 1 < argc) frames = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "--out") && i + 1 < argc) out = argv[++i];
 		else if (!strcmp(argv[i], "--orbit")) orbit = 1;
+		else if (!strcmp(argv[i], "--keys") && i + 1 < argc) keys = argv[++i];
+		else if (!strcmp(argv[i], "--dump-camera") && i + 1 < argc) dump_camera = argv[++i];
 		else if (!strcmp(argv[i], "--pipeline")) pipeline = 1;      /* also read by the plug-in: the surface lags one frame */
 	}
 	if (threads < 1) threads = 1;
@@ -93,10 +102,23 @@ int main(int argc, const char* argv[]) {
 
 	render_prepare(&data, argc, argv);
 
+	FILE* cam_fp = dump_camera ? fopen(dump_camera, "w") : NULL;
+	const char* key_at = keys;
 	double tmin = 1e30, tmax = 0, tsum = 0;
 	/* with --pipeline the plug-in delivers frame i-1 on round i: one extra round (same camera) brings the last frame in */
 	for (int f = 0; f < frames + pipeline; f++) {
-		if (orbit) orbit_camera(&scene->camera, f < frames ? f : frames - 1, frames);   /* update_camera(), main.c:180 */
+		if (orbit) orbit_camera(&scene->camera, f < frames ? f : frames - 1, frames);
+		if (keys && f < frames) {                                /* update_camera(), main.c:180 */
+			const char* endp = key_at ? strchr(key_at, ',') : NULL;
+			lol_keys k = lol_keys_from_script(key_at ? key_at : "", key_at ? (endp ? (size_t)(endp - key_at) : strlen(key_at)) : 0);
+			key_at = endp ? endp + 1 : NULL;                     /* past the script: no keys held */
+			lol_host_update_camera(&scene->camera, &k);
+		}
+		if (cam_fp && f < frames) {
+			const float v[6] = { scene->camera.point.x, scene->camera.point.y, scene->camera.point.z,
+			                     scene->camera.direction.x, scene->camera.direction.y, scene->camera.direction.z };
+			for (int j = 0; j < 6; j++) { uint32_t u; memcpy(&u, &v[j], 4); fprintf(cam_fp, "%08x%c", u, j == 5 ? '\n' : ' '); }
+		}
 		atomic_store(&current_line, 0);
 		double t0 = now_ms();
 		for (int i = 0; i < threads; i++) sem_post(&entry);
@@ -123,6 +145,7 @@ int main(int argc, const char* argv[]) {
 		fclose(fp);
 	}
 
+	if (cam_fp) fclose(cam_fp);
 	LOG("Cerrando");
 	atomic_store(&exiting, 1);
 	for (int i = 0; i < threads; i++) sem_post(&entry);

@@ -20,6 +20,10 @@ Outputs (all DATA — inputs and expected outputs, no reference source text):
                         minimum, ids 1-based in file order) and every arithmetic step is a call into
                         liblol_ref.so (v3sub, sdSphere, sdRoundBox, sminf).  Extends the pin from the primitives
                         to rows a4/a5 of SURVEY.md §8 (tests/test_oracle.py checks lol_oracle_sdf against it).
+  ref_camera_path.json  the camera after every frame of a key script (W A S D Space LCtrl and the four arrows, singly and
+                        held together), stepped the way main.c's update_camera does (main.c:70-112) with every vector
+                        operation a call into the reference's compiled vec.h (v3cross, v3normalize, v3add, v3scale) —
+                        pins the host-side keyboard → camera step of integration/lol_host_input.h.
   oracle_frames.npz     XRGB8888 frames + float RGB of the CPU ORACLE (not of the reference:
                         naive_renderer.c cannot be built here) — regression fixtures that
                         pin the oracle's output across toolchains / on the GPU box.
@@ -60,7 +64,7 @@ def load_ref():
     sig = {
         "ref_minf": ([f, f], f), "ref_maxf": ([f, f], f), "ref_clamp": ([f, f, f], f),
         "ref_lerp": ([f, f, f], f), "ref_sminf": ([f, f, f], f),
-        "ref_v3sub": ([f3, f3, f3], None),
+        "ref_v3sub": ([f3, f3, f3], None), "ref_v3add": ([f3, f3, f3], None), "ref_v3scale": ([f3, f, f3], None),
         "ref_v3dot": ([f3, f3], f), "ref_v3len": ([f3], f), "ref_v3normalize": ([f3, f3], None),
         "ref_v3cross": ([f3, f3, f3], None), "ref_v3clamp": ([f3, f, f, f3], None),
         "ref_v3pow": ([f3, f, f3], None),
@@ -322,6 +326,51 @@ def gen_sdf_points(ref, sc, cam, seed):
     return out
 
 
+# ---------------------------------------------- keyboard → camera, stepped with the reference's vec.h
+
+CAMERA_SCRIPT = ("W,W,W,A,A,S,D,D,_,_,c,^,^,v,<,<,<,>,W^,WA<,SD>v,_c,WASD_c^v<>,.,.,w<,w<,w<,w<,w<,w<,w<,w<,^,^,^,^,^,^,^,^,^,^,^,^,"
+                 "D>,D>,D>,D>,Sv,Sv,Sv,A,W").split(",")
+
+
+def gen_camera_path(ref, cam7):
+    A3 = C.c_float * 3
+    f32 = lambda x: float(np.float32(x))
+
+    def call2(fn, a, b):
+        o = A3()
+        fn(A3(*a), A3(*b), o)
+        return list(o)
+
+    def scale(a, k):
+        o = A3()
+        ref.ref_v3scale(A3(*a), C.c_float(k), o)
+        return list(o)
+
+    def normalize(a):
+        o = A3()
+        ref.ref_v3normalize(A3(*a), o)
+        return list(o)
+
+    point, direction = [f32(v) for v in cam7[:3]], [f32(v) for v in cam7[3:6]]
+    out = []
+    for keys in CAMERA_SCRIPT:
+        right = normalize(call2(ref.ref_v3cross, direction, [0.0, 1.0, 0.0]))          # main.c:73-75
+        up = normalize(call2(ref.ref_v3cross, right, direction))
+        k = set(keys.upper()) | ({"v"} if "v" in keys or "V" in keys else set()) | ({"c"} if "c" in keys or "C" in keys else set())
+        if "W" in k: point = call2(ref.ref_v3add, point, scale(direction, f32(0.1)))
+        if "A" in k: point = call2(ref.ref_v3add, point, scale(right, f32(-0.1)))
+        if "S" in k: point = call2(ref.ref_v3add, point, scale(direction, f32(-0.1)))
+        if "D" in k: point = call2(ref.ref_v3add, point, scale(right, f32(0.1)))
+        if "_" in k: point[1] = f32(np.float32(point[1]) + np.float32(0.1))
+        if "c" in k: point[1] = f32(np.float32(point[1]) - np.float32(0.1))
+        if "^" in k: direction = normalize(call2(ref.ref_v3add, direction, scale(up, f32(0.1))))
+        if "v" in k: direction = normalize(call2(ref.ref_v3add, direction, scale(up, f32(-0.1))))
+        if "<" in k: direction = normalize(call2(ref.ref_v3add, direction, scale(right, f32(-0.1))))
+        if ">" in k: direction = normalize(call2(ref.ref_v3add, direction, scale(right, f32(0.1))))
+        out.append([f2h(v) for v in point + direction])
+    return out
+
+
 def main():
     if not os.path.exists(REF_SO):
         raise SystemExit("oracle/_ref/liblol_ref.so missing: run `make -C oracle ref` where /root/reference exists")
@@ -338,6 +387,12 @@ def main():
         scenes[name] = dump_scene(ref, sc)
         sdf_points[name] = gen_sdf_points(ref, sc, [h2f(v) for v in scenes[name]["camera"]], 20261004 + k)
         ref.ref_scene_free(sc)
+    with open(os.path.join(HERE, "ref_camera_path.json"), "w") as f:
+        json.dump({"source": "main.c:70-112 stepped with the reference's vec.h functions via oracle/_ref/liblol_ref.so "
+                             "(make_golden.py gen_camera_path); start = scene4.lol's camera",
+                   "keys": "W A S D, _ = Space, c = LCtrl, ^ v < > = arrows; one entry per frame",
+                   "script": CAMERA_SCRIPT, "format": "[px,py,pz,dx,dy,dz] after each frame, binary32 hex",
+                   "path": gen_camera_path(ref, [h2f(v) for v in scenes["scene4"]["camera"]])}, f, indent=0)
     with open(os.path.join(HERE, "ref_sdf_points.json"), "w") as f:
         json.dump({"source": "scene SDF composed from the reference's scene.c object tree + float.h/vec.h/sdf.h functions "
                              "via oracle/_ref/liblol_ref.so (walk: make_golden.py ref_scene_sdf, after naive_renderer.c:11-44)",
@@ -359,7 +414,7 @@ def main():
         if w == 64:
             frames[f"{name}_{w}x{h}_rgb"] = rgb
     np.savez_compressed(os.path.join(HERE, "oracle_frames.npz"), **frames)
-    print("wrote ref_primitives.json, ref_scenes.json, ref_sdf_points.json, oracle_frames.npz")
+    print("wrote ref_primitives.json, ref_scenes.json, ref_sdf_points.json, ref_camera_path.json, oracle_frames.npz")
 
 
 if __name__ == "__main__":

@@ -134,3 +134,20 @@ def test_pipelined_host_path_delivers_the_same_frames(tmp_path, scenes):
         assert p.returncode == 0 and "hip_renderer" not in p.stderr, p.stderr
         outs.append(open(out, "rb").read())
     assert outs[0] == outs[1]
+
+
+def test_keyboard_to_camera_step_matches_the_reference_arithmetic(tmp_path):
+    """The caller side of the boundary: main.c moves the camera from the held keys once per frame
+    (update_camera, main.c:70-112).  integration/lol_host_input.h restates that step; the fixture was stepped with the
+    reference's own compiled vec.h functions (tests/golden/make_golden.py).  No GPU needed: frames are skipped loudly,
+    the protocol and the camera still run."""
+    import json
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_camera_path.json")))
+    dump = tmp_path / "cam.txt"
+    p = subprocess.run([HOST, "2", SCENE4, "--size", "8x8", "--frames", str(len(gold["script"])),
+                        "--keys", ",".join(gold["script"]), "--dump-camera", str(dump)],
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    got = [line.split() for line in open(dump).read().splitlines()]
+    assert got == gold["path"]
+    assert len({tuple(g) for g in got}) > 40                  # the script really moves and turns the camera
