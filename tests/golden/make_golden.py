@@ -20,6 +20,18 @@ Outputs (all DATA — inputs and expected outputs, no reference source text):
                         minimum, ids 1-based in file order) and every arithmetic step is a call into
                         liblol_ref.so (v3sub, sdSphere, sdRoundBox, sminf).  Extends the pin from the primitives
                         to rows a4/a5 of SURVEY.md §8 (tests/test_oracle.py checks lol_oracle_sdf against it).
+  ref_pixels.json       whole pixels of the four example scenes (a 13 x 9 grid of a 64x36 frame each, + 256x256 probes
+                        of scene / scene4), COMPOSED from the reference's compiled pieces exactly like the scene SDF
+                        above: this script follows naive_renderer.c:48-236 statement by statement (camera ray, march
+                        loop, tetrahedron normal, soft shadow loop, Phong sum, clamp, gamma, 8-bit pack) and every
+                        vector / min / max / clamp / smooth-min / distance operation is a call into liblol_ref.so
+                        (scalar +, *, / are IEEE binary32 via numpy; atanf and powf are the C library's, the latter
+                        through the reference's v3pow).  Recorded per pixel: ray direction, hit distance, hit id,
+                        march steps, normal, per-light shadow factor and steps, linear and gamma colour, packed pixel.
+                        Pins rows a2, a3, a9 - a13 of SURVEY.md §8 for the oracle (tests/test_oracle.py).
+  ref_frames.npz        the same composition for EVERY pixel of the 64x36 frame of each example scene (9216 pixels):
+                        arrays <scene>_xrgb, _rgb, _rgb_linear, _hit_dist, _hit_id, _march_steps, _normal, _rd, _shadow,
+                        _shadow_steps — whole reference-composed frames for the oracle to equal.
   ref_camera_path.json  the camera after every frame of a key script (W A S D Space LCtrl and the four arrows, singly and
                         held together), stepped the way main.c's update_camera does (main.c:70-112) with every vector
                         operation a call into the reference's compiled vec.h (v3cross, v3normalize, v3add, v3scale) —
@@ -65,6 +77,7 @@ def load_ref():
         "ref_minf": ([f, f], f), "ref_maxf": ([f, f], f), "ref_clamp": ([f, f, f], f),
         "ref_lerp": ([f, f, f], f), "ref_sminf": ([f, f, f], f),
         "ref_v3sub": ([f3, f3, f3], None), "ref_v3add": ([f3, f3, f3], None), "ref_v3scale": ([f3, f, f3], None),
+        "ref_v3mul": ([f3, f3, f3], None),
         "ref_v3dot": ([f3, f3], f), "ref_v3len": ([f3], f), "ref_v3normalize": ([f3, f3], None),
         "ref_v3cross": ([f3, f3, f3], None), "ref_v3clamp": ([f3, f, f, f3], None),
         "ref_v3pow": ([f3, f, f3], None),
@@ -306,6 +319,145 @@ def ref_scene_sdf(ref, sc, p):
     return best, best_id
 
 
+class RefPipeline:
+    """naive_renderer.c:48-236 for one pixel, every vector / float.h / sdf.h operation done by liblol_ref.so."""
+
+    def __init__(self, ref, sc, dump):
+        self.ref, self.sc, self.dump = ref, sc, dump
+        self.A3 = C.c_float * 3
+        self.libm = C.CDLL("libm.so.6")
+        self.libm.atanf.restype, self.libm.atanf.argtypes = C.c_float, [C.c_float]
+        self.cam = [h2f(v) for v in dump["camera"]]
+        self.lights = [[h2f(v) for v in l] for l in dump["lights"]]
+        self.materials = [[h2f(v) for v in m] for m in dump["materials"]]
+        self.obj_material = [o["material"] for o in dump["objects"]]
+        self.ambient = [h2f(v) for v in dump["ambient"]]
+
+    # --- vec.h through the harness
+    def v2(self, fn, a, b):
+        o = self.A3()
+        fn(self.A3(*a), self.A3(*b), o)
+        return list(o)
+
+    def add(self, a, b): return self.v2(self.ref.ref_v3add, a, b)
+    def sub(self, a, b): return self.v2(self.ref.ref_v3sub, a, b)
+    def mul(self, a, b): return self.v2(self.ref.ref_v3mul, a, b)
+    def cross(self, a, b): return self.v2(self.ref.ref_v3cross, a, b)
+    def dot(self, a, b): return self.ref.ref_v3dot(self.A3(*a), self.A3(*b))
+    def length(self, a): return self.ref.ref_v3len(self.A3(*a))
+
+    def scale(self, a, k):
+        o = self.A3()
+        self.ref.ref_v3scale(self.A3(*a), C.c_float(k), o)
+        return list(o)
+
+    def normalize(self, a):
+        o = self.A3()
+        self.ref.ref_v3normalize(self.A3(*a), o)
+        return list(o)
+
+    def powf(self, x, y):                               # v3pow = 3 x powf (vec.h:66-67)
+        o = self.A3()
+        self.ref.ref_v3pow(self.A3(x, x, x), C.c_float(y), o)
+        return o[0]
+
+    def sdf(self, p):
+        return ref_scene_sdf(self.ref, self.sc, p)
+
+    # --- naive_renderer.c
+    def camera_ray(self, vx, vy, aspect):              # :179-193
+        f32 = np.float32
+        d = self.cam[3:6]
+        half_fov = f32(self.cam[6]) / f32(2.0)
+        height = f32(self.libm.atanf(C.c_float(float(half_fov))))
+        width = f32(aspect) * height
+        right = self.normalize(self.cross(d, [0.0, 1.0, 0.0]))
+        up = self.cross(right, d)
+        r = self.add(self.scale(right, float(f32(vx) * width)), self.scale(up, float(f32(vy) * height)))
+        return self.normalize(self.add(r, d))
+
+    def intersection(self, ro, rd):                    # :48-69
+        f32 = np.float32
+        dist, oid, steps = f32(0.0), 0, 0
+        for _ in range(256):
+            p = self.add(ro, self.scale(rd, float(dist)))
+            sd, sid = self.sdf(p)
+            dist = dist + f32(sd)
+            oid = sid
+            steps += 1
+            if f32(sd) < f32(0.001) or dist > f32(100.0):
+                break
+        if dist >= f32(100.0):
+            oid = 0
+        return float(dist), oid, steps
+
+    def normal(self, p, dist):                         # :114-125
+        h = float(np.float32(dist) / np.float32(100.0))
+        ks = ([1.0, -1.0, -1.0], [-1.0, -1.0, 1.0], [-1.0, 1.0, -1.0], [1.0, 1.0, 1.0])
+        ps = [self.scale(k, self.sdf(self.add(p, self.scale(k, h)))[0]) for k in ks]
+        return self.normalize(self.add(ps[0], self.add(ps[1], self.add(ps[2], ps[3]))))
+
+    def in_shadow(self, light_point, p):               # :73-100
+        f32 = np.float32
+        light_dist = self.length(self.sub(light_point, p))
+        rd = self.normalize(self.sub(light_point, p))
+        ro = self.add(p, rd)
+        res, dist, steps = f32(1.0), f32(0.0), 0
+        with np.errstate(all="ignore"):
+            for _ in range(128):
+                sd = f32(self.sdf(self.add(ro, self.scale(rd, float(dist))))[0])
+                res = f32(self.ref.ref_minf(C.c_float(float(res)), C.c_float(float(f32(50.0) * sd / dist))))
+                dist = dist + sd
+                steps += 1
+                if res < f32(-1.0) or dist > f32(light_dist):
+                    break
+        return self.ref.ref_maxf(C.c_float(float(res)), C.c_float(0.0)), steps
+
+    def light(self, p, n, oid, rec):                   # :129-175
+        f32 = np.float32
+        mat = self.materials[self.obj_material[oid - 1] if oid else 0]
+        shininess, m_diff, m_spec, m_amb = mat[0], mat[1:4], mat[4:7], mat[7:10]
+        total = [0.0, 0.0, 0.0]
+        cam_pos = self.cam[:3]
+        for l in self.lights:
+            shadow, sh_steps = self.in_shadow(l[:3], p)
+            rec["shadow"].append(f2h(shadow)); rec["shadow_steps"].append(sh_steps)
+            light_dir = self.normalize(self.sub(l[:3], p))
+            refl = self.sub(self.scale(n, float(f32(2.0) * f32(self.dot(light_dir, n)))), light_dir)
+            camera_dir = self.normalize(self.sub(cam_pos, p))
+            di = self.ref.ref_clamp(C.c_float(self.dot(n, light_dir)), C.c_float(0.0), C.c_float(1.0))
+            ld = self.mul(self.scale(l[3:6], float(f32(shadow) * f32(di))), m_diff)
+            total = self.add(total, ld)
+            si = float(f32(di) * f32(self.powf(self.ref.ref_clamp(C.c_float(self.dot(refl, camera_dir)), C.c_float(0.0), C.c_float(1.0)), shininess)))
+            ls = self.mul(self.scale(l[6:9], float(f32(shadow) * f32(si))), m_spec)
+            total = self.add(total, ls)
+        total = self.add(total, self.mul(self.ambient, m_amb))
+        o = self.A3()
+        self.ref.ref_v3clamp(self.A3(*total), C.c_float(0.0), C.c_float(1.0), o)
+        return list(o)
+
+    def pixel(self, x, y, w, h):                       # :207-236, renderer.h:17-22
+        f32 = np.float32
+        fw, fh = f32(w), f32(h)
+        aspect = fw / fh
+        vx = (f32(x) + f32(0.5)) / fw * f32(2.0) - f32(1.0)
+        vy = f32(1.0) - (f32(y) + f32(0.5)) / fh * f32(2.0)
+        ro = self.cam[:3]
+        rd = self.camera_ray(vx, vy, aspect)
+        dist, oid, steps = self.intersection(ro, rd)
+        p = self.add(ro, self.scale(rd, dist))
+        n = self.normal(p, dist)
+        rec = {"x": x, "y": y, "rd": [f2h(v) for v in rd], "hit_dist": f2h(dist), "hit_id": oid, "march_steps": steps,
+               "normal": [f2h(v) for v in n], "shadow": [], "shadow_steps": []}
+        lin = self.light(p, n, oid, rec)
+        o = self.A3()
+        self.ref.ref_v3pow(self.A3(*lin), C.c_float(float(f32(1.0) / f32(2.2))), o)
+        rgb = list(o)
+        ch = [int(f32(c) * f32(255.0)) & 0xFF for c in rgb]          # Uint8 r = colorf.x * 255
+        rec.update(rgb_linear=[f2h(v) for v in lin], rgb=[f2h(v) for v in rgb], xrgb=ch[0] << 16 | ch[1] << 8 | ch[2])
+        return rec
+
+
 def gen_sdf_points(ref, sc, cam, seed):
     rng = np.random.default_rng(seed)
     pts = []
@@ -380,13 +532,36 @@ def main():
         json.dump({"source": "reference float.h/vec.h/sdf.h via oracle/_ref/liblol_ref.so", "vectors": gen_primitives(ref)},
                   f, separators=(",", ":"))
 
-    scenes, sdf_points = {}, {}
+    scenes, sdf_points, pixels, frames = {}, {}, {}, {}
     for k, name in enumerate(("scene", "scene2", "scene3", "scene4")):
         text = open(os.path.join(HERE, "scenes", name + ".lol")).read()
         sc = Walker(ref, text).run()
         scenes[name] = dump_scene(ref, sc)
         sdf_points[name] = gen_sdf_points(ref, sc, [h2f(v) for v in scenes[name]["camera"]], 20261004 + k)
+        pipe = RefPipeline(ref, sc, scenes[name])
+        grid = [(x, y) for y in range(2, 36, 4) for x in range(2, 64, 5)]
+        pixels[name] = {"64x36": [pipe.pixel(x, y, 64, 36) for x, y in grid]}
+        W, H = 64, 36
+        full = [pipe.pixel(x, y, W, H) for y in range(H) for x in range(W)]
+        u = lambda hs: np.array([int(v, 16) for v in hs], dtype=np.uint32)
+        nl = len(scenes[name]["lights"])
+        frames[f"{name}_xrgb"] = np.array([q["xrgb"] for q in full], dtype=np.uint32).reshape(H, W)
+        frames[f"{name}_hit_id"] = np.array([q["hit_id"] for q in full], dtype=np.uint32).reshape(H, W)
+        frames[f"{name}_march_steps"] = np.array([q["march_steps"] for q in full], dtype=np.uint32).reshape(H, W)
+        frames[f"{name}_hit_dist"] = u([q["hit_dist"] for q in full]).view(np.float32).reshape(H, W)
+        for key in ("rgb", "rgb_linear", "normal", "rd"):
+            frames[f"{name}_{key}"] = u([v for q in full for v in q[key]]).view(np.float32).reshape(H, W, 3)
+        frames[f"{name}_shadow"] = u([v for q in full for v in q["shadow"]]).view(np.float32).reshape(H, W, nl)
+        frames[f"{name}_shadow_steps"] = np.array([v for q in full for v in q["shadow_steps"]], dtype=np.uint32).reshape(H, W, nl)
+        if name in ("scene", "scene4"):
+            pixels[name]["256x256"] = [pipe.pixel(x, y, 256, 256) for x, y in ((128, 128), (0, 0), (255, 255), (40, 200), (200, 60), (77, 131))]
         ref.ref_scene_free(sc)
+    np.savez_compressed(os.path.join(HERE, "ref_frames.npz"), **frames)
+    with open(os.path.join(HERE, "ref_pixels.json"), "w") as f:
+        json.dump({"source": "naive_renderer.c:48-236 followed statement by statement in make_golden.py (RefPipeline), every vector / "
+                             "float.h / sdf.h operation executed by the reference's compiled code via oracle/_ref/liblol_ref.so",
+                   "format": "floats as binary32 hex; xrgb = r<<16|g<<8|b with Uint8 channel = c*255 truncated (renderer.h:17-22)",
+                   "pixels": pixels}, f, separators=(",", ":"))
     with open(os.path.join(HERE, "ref_camera_path.json"), "w") as f:
         json.dump({"source": "main.c:70-112 stepped with the reference's vec.h functions via oracle/_ref/liblol_ref.so "
                              "(make_golden.py gen_camera_path); start = scene4.lol's camera",
@@ -414,7 +589,7 @@ def main():
         if w == 64:
             frames[f"{name}_{w}x{h}_rgb"] = rgb
     np.savez_compressed(os.path.join(HERE, "oracle_frames.npz"), **frames)
-    print("wrote ref_primitives.json, ref_scenes.json, ref_sdf_points.json, ref_camera_path.json, oracle_frames.npz")
+    print("wrote ref_primitives.json, ref_scenes.json, ref_sdf_points.json, ref_pixels.json, ref_frames.npz, ref_camera_path.json, oracle_frames.npz")
 
 
 if __name__ == "__main__":

@@ -47,3 +47,28 @@ def test_device_sdf_equals_the_reference_composition(scenes, name, mode):
     assert bad.size == 0, (name, mode, [(xyz[i].tolist(), hex(got_d[i]), hex(want_d[i])) for i in bad[:5]])
     assert np.array_equal(got_id, want_id), (name, mode, np.flatnonzero(got_id != want_id)[:5])
     r.close()
+
+
+@pytest.mark.parametrize("mode", [1, 3, 0, 4], ids=["spec", "spec-plain", "interp-plain", "interp"])
+@pytest.mark.parametrize("name", ["scene", "scene2", "scene3", "scene4"])
+def test_device_frames_equal_the_reference_composition(scenes, name, mode):
+    """tests/golden/ref_frames.npz — 64x36 frames composed pixel by pixel from the reference's compiled vec.h / float.h /
+    sdf.h following naive_renderer.c:48-236 — against the DEVICE, with no oracle in between: packed pixel, post-gamma
+    float colour, hit distance, hit id, march steps and (where no exact skip removes them) shadow steps, bit for bit."""
+    import torch
+    from test_gpu_parity import gpu_render, HOST_LIBM_IS_FMA_VARIANT
+    g = np.load(os.path.join(HERE, "golden", "ref_frames.npz"))
+    r = gpu.Renderer(0, specialize=mode)
+    r.set_miss_skip(False)                     # march every shadow ray, so that the shadow step counts are comparable
+    w, h = 64, 36
+    d = gpu_render(torch, r, scenes[name], w, h)
+    assert np.array_equal(d["id"], g[f"{name}_hit_id"])
+    assert np.array_equal(d["dist"].view(np.uint32), g[f"{name}_hit_dist"].view(np.uint32))
+    assert np.array_equal(d["steps"] & 0xFFFF, g[f"{name}_march_steps"])
+    assert np.array_equal(d["steps"] >> 16, g[f"{name}_shadow_steps"].sum(axis=-1))
+    if HOST_LIBM_IS_FMA_VARIANT:               # the fixture's powf is the build container's libm (FMA variant), like the kernel's
+        assert np.array_equal(d["rgb"].view(np.uint32), g[f"{name}_rgb"].view(np.uint32))
+        assert np.array_equal(d["xrgb"][:, :w], g[f"{name}_xrgb"])
+    else:
+        assert np.abs(d["rgb"] - g[f"{name}_rgb"]).max() <= 1e-4
+    r.close()

@@ -7,6 +7,8 @@
    centre / corner pixels and the per-pixel work counters (sdf evaluations, march steps, shadow steps).
    (The survey's five whole-frame hashes are not used: they do not describe the shipped scene files.)
 3. tests/golden/ref_sdf_points.json — the scene SDF composed from the reference's own object tree and primitives.
+   tests/golden/ref_frames.npz, ref_pixels.json — whole pixels composed the same way: naive_renderer.c:48-236 followed
+   statement by statement with the reference's compiled vec.h / float.h / sdf.h doing every operation.
 4. tests/golden/oracle_frames.npz — regression frames of the oracle itself (pins it across toolchains).
 """
 import ctypes as C
@@ -148,6 +150,53 @@ def test_scene_sdf_matches_the_reference_composition(scenes, name):
         assert oid.value == want_id, (name, p, oid.value, want_id)
         ids_seen.add(want_id)
     assert len(ids_seen) >= 2                       # more than one object wins somewhere
+
+
+# ---- whole pixels and frames composed from the reference's compiled pieces ---------------------------
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("name", ["scene", "scene2", "scene3", "scene4"])
+def test_whole_frames_equal_the_reference_composition(scenes, name):
+    """tests/golden/ref_frames.npz: every pixel of the 64x36 frame, produced by following naive_renderer.c:48-236
+    statement by statement with every vector / min / max / clamp / smooth-min / distance operation executed by the
+    reference's own compiled code (make_golden.py: RefPipeline).  The oracle must reproduce ALL of it bit for bit:
+    packed pixel, gamma and linear colour, hit distance and id, march steps (rows a2, a3, a9 - a13 of SURVEY.md §8)."""
+    g = np.load(os.path.join(HERE, "golden", "ref_frames.npz"))
+    w, h = 64, 36
+    x, rgb, steps = O.render_rows(scenes[name], w, h, 0, h, want_steps=True)
+    assert np.array_equal(x, g[f"{name}_xrgb"])
+    assert np.array_equal(_bits(rgb), _bits(g[f"{name}_rgb"]))
+    assert np.array_equal(steps[..., 0], g[f"{name}_march_steps"])
+    assert np.array_equal(steps[..., 2], g[f"{name}_hit_id"])
+    assert np.array_equal(steps[..., 1], g[f"{name}_shadow_steps"].sum(axis=-1))
+    assert len(np.unique(x)) > 50                       # a real picture, not a constant
+
+
+@pytest.mark.parametrize("name", ["scene", "scene2", "scene3", "scene4"])
+def test_pixel_intermediates_equal_the_reference_composition(scenes, name):
+    """The same composition, per pixel and per stage (tests/golden/ref_pixels.json, a 13 x 9 grid of the 64x36 frame and
+    a few 256x256 pixels): camera ray, hit distance, normal, every light's shadow factor and step count, linear colour."""
+    px = json.load(open(os.path.join(HERE, "golden", "ref_pixels.json")))["pixels"][name]
+    n = 0
+    for size, plist in px.items():
+        w, h = (int(v) for v in size.split("x"))
+        for q in plist:
+            p = O.probe(scenes[name], w, h, q["x"], q["y"])
+            where = (name, size, q["x"], q["y"])
+            assert [f2h(v) for v in p.rd] == q["rd"], where
+            assert f2h(p.hit_dist) == q["hit_dist"] and p.hit_id == q["hit_id"] and p.march_steps == q["march_steps"], where
+            nl = len(q["shadow"])
+            assert all(same(p.shadow[i], q["shadow"][i]) for i in range(nl)), where
+            assert [p.shadow_steps[i] for i in range(nl)] == q["shadow_steps"], where
+            assert all(same(a, b) for a, b in zip(p.normal, q["normal"])), where
+            assert all(same(a, b) for a, b in zip(p.rgb_linear, q["rgb_linear"])), where
+            assert all(same(a, b) for a, b in zip(p.rgb, q["rgb"])), where
+            assert p.xrgb == q["xrgb"], where
+            n += 1
+    assert n >= 117
 
 
 # ---- regression frames of the oracle ---------------------------------------------------------------
