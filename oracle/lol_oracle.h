@@ -13,9 +13,15 @@
  *  (1) oracle/_ref — the reference's own SDL-free headers (float.h, vec.h, sdf.h) and scene.c
  *      compiled where they lie; their outputs on committed input vectors
  *      (tests/golden/ref_primitives.json, ref_scenes.json) must match bit for bit;
- *  (2) the known pixels and per-pixel work counters the survey recorded from the unmodified
- *      naive_renderer.c — reproduced; its whole-frame hashes are NOT reproduced,
- *      so the pipeline level is only partially pinned.
+ *  (2) compositions of those compiled pieces: the scene SDF walked over the reference's own struct object
+ *      tree (tests/golden/ref_sdf_points.json) and WHOLE PIXELS — naive_renderer.c:48-236 followed statement by
+ *      statement by tests/golden/make_golden.py with every vector / min / max / clamp / smooth-min / distance
+ *      operation executed by the reference's compiled code (ref_frames.npz: four 64x36 frames; ref_pixels.json:
+ *      per-stage values) — all reproduced bit for bit;
+ *  (3) the known pixels and per-pixel work counters the survey recorded from the unmodified
+ *      naive_renderer.c — reproduced by this oracle AND by the composition of (2).
+ * What no fixture can come from is naive_renderer.c's own object code: its loop and branch structure is
+ * restated (here and in make_golden.py), its arithmetic is the reference's.
  */
 #ifndef LOL_ORACLE_H
 #define LOL_ORACLE_H
