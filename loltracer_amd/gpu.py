@@ -52,7 +52,7 @@ _lib = None
 def gpu_lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        path = os.path.join(S.LIB_DIR, "liblol_gpu.so")
+        path = os.environ.get("LOL_GPU_LIB") or os.path.join(S.LIB_DIR, "liblol_gpu.so")     # LOL_GPU_LIB: A/B another build
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: the HIP extension was not built "
                                "(run __graft_entry__.build()); there is no CPU fallback")
