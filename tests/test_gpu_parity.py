@@ -294,3 +294,23 @@ def test_errors_are_loud(torch_cuda, scenes):
     with pytest.raises(gpu.GpuError):
         gpu.Renderer(99)
     r.close()
+
+
+def test_scheduling_options_do_not_change_a_bit(torch_cuda, scenes, monkeypatch):
+    """The specialised kernel is compiled with -amdgpu-sched-strategy=max-ilp and without the post-RA scheduler
+    (lol_gpu.hip: compile_spec) — instruction ORDER only.  LOL_GPU_SCHED=default compiles it the stock way: every pixel,
+    colour bit, distance and step count must be the same."""
+    sc = scenes["scene4"]
+    w, h = 320, 180
+    monkeypatch.setenv("LOL_GPU_CACHE_DIR", "")
+    r = gpu.Renderer(0)
+    a = gpu_render(torch_cuda, r, sc, w, h)
+    r.close()
+    monkeypatch.setenv("LOL_GPU_SCHED", "default")
+    r = gpu.Renderer(0)
+    b = gpu_render(torch_cuda, r, sc, w, h)
+    r.close()
+    for key in ("xrgb", "id", "steps"):
+        assert np.array_equal(a[key], b[key]), key
+    assert np.array_equal(a["rgb"].view(np.uint32), b["rgb"].view(np.uint32))
+    assert np.array_equal(a["dist"].view(np.uint32), b["dist"].view(np.uint32))
