@@ -207,9 +207,10 @@ int         lol_gpu_compile_offline(const lol_program* prog, const char* arch, c
  * exchange stream every device ncclSend()s its part to device 0 (devices[0], the root), which
  * ncclRecv()s them (one grouped call, parts may differ in size) and un-interleaves the bands into the
  * destination — the frame barrier of main.c:189-194 becomes the completion of that exchange.  Parts are
- * double-buffered, so frame i's exchange overlaps frame i+1's kernels.  RCCL is loaded (dlopen) by
- * lol_gpu_multi_create only, single-device users never touch it.  No CPU fallback and no other
- * transport: without RCCL, or with a device listed twice, creation fails.
+ * double-buffered, so frame i's exchange overlaps frame i+1's kernels.  RCCL is loaded (dlopen) and the
+ * communicators are created by the first lol_gpu_multi_render_device: single-device users, and hosts that only ever
+ * render into HOST surfaces (which need no exchange, see lol_gpu_multi_render_host), never touch it.  No CPU
+ * fallback: a device listed twice fails at creation, a missing RCCL at the first frame that needs the exchange.
  */
 typedef struct lol_gpu_multi lol_gpu_multi;
 
@@ -236,9 +237,16 @@ int  lol_gpu_part_frame_row(int h, const lol_gpu_rows* rows, int local_row);
  */
 int  lol_gpu_multi_render_device(lol_gpu_multi* m, const lol_frame_camera* cam, int w, int h, int max_steps,
                                  void* dst, size_t pitch_bytes);
-/* What render_thread does with surf->pixels: one frame over all devices into a HOST surface; waits. */
+/* What render_thread does with surf->pixels: one frame over all devices into a HOST surface; waits.  No exchange is
+ * needed for this: every device copies its own bands straight into the surface (one strided copy per part), so N
+ * devices use N PCIe links in parallel.  set_host_via_root(m, 1) (or LOL_GPU_MULTI_HOST_VIA_ROOT=1) instead assembles
+ * on the root with the RCCL exchange and copies from there. */
 int  lol_gpu_multi_render_host(lol_gpu_multi* m, const lol_frame_camera* cam, int w, int h, int max_steps,
                                void* host_pixels, size_t pitch_bytes);
+int  lol_gpu_multi_set_host_via_root(lol_gpu_multi* m, int enable);
+/* Parts per device (default 1): device d owns parts d, d + n, d + 2n, … of n * parts.  Finer interleaving of the rows,
+ * and the way a single-GPU machine exercises the multi-part code paths.  n * parts <= 64. */
+int  lol_gpu_multi_set_parts_per_device(lol_gpu_multi* m, int parts);
 int  lol_gpu_multi_sync(lol_gpu_multi* m);
 /* Memory on the root device (for destinations of lol_gpu_multi_render_device). */
 int  lol_gpu_multi_malloc(lol_gpu_multi* m, size_t bytes, void** out);

@@ -14,8 +14,16 @@
  *   render[d]: wait sent[slot] (frame i-2 has left the buffer) → kernel → record rendered[slot]
  *   xchg[d]:   wait rendered[slot] → ncclSend(part[slot] → root) → record sent[slot]
  *   xchg[0]:   … → ncclRecv(staging[slot] ← every d) → assemble_kernel(staging[slot] → dst) → record done[slot]
- * RCCL itself is resolved with dlopen in lol_gpu_multi_create: librccl is a 570 MB library that a
- * single-device host should not have to map.
+ * RCCL itself is resolved with dlopen, and the communicators are created, on the first frame that needs the
+ * exchange: librccl is a 570 MB library that a host which never assembles on a device should not have to map.
+ *
+ * A HOST surface (what render_thread fills, naive_renderer.c:233-235) needs no exchange at all: every device copies
+ * its own bands straight into the surface — one strided hipMemcpy3DAsync per part, so N devices drive N PCIe links
+ * in parallel instead of funnelling 4 B per pixel through the root's single link (132 MB = 2.4 ms for a C4 frame).
+ *
+ * parts_per_device (default 1) lets one device own several parts (parts p, p + n, p + 2n, … of n * parts_per_device):
+ * finer interleaving for load balance, and the means by which a single-GPU box exercises every multi-part code path
+ * (strided copies, part table, assembly) — tests/test_multi_device.py.
  */
 #include "lol_gpu.h"
 
@@ -72,8 +80,10 @@ struct Device {
 	hipEvent_t   rendered[SLOTS] = { nullptr, nullptr }, sent[SLOTS] = { nullptr, nullptr };
 };
 
+constexpr int MAX_PARTS = 64;      /* devices x parts_per_device */
+
 /* Offsets (in rows) of the parts inside the staging buffer, by value in the kernel arguments. */
-struct PartTable { uint32_t row0[LOL_GPU_MULTI_MAX_DEVICES]; };
+struct PartTable { uint32_t row0[MAX_PARTS]; };
 
 /* dst row y ← the row of the part that rendered it.  One thread per 4 pixels (uint4) when VEC, else per pixel. */
 template <bool VEC>
@@ -106,6 +116,7 @@ hipError_t launch_assemble(const void* parts, const PartTable& tab, int n_parts,
 	return hipGetLastError();
 }
 
+/* parts stored back to back in part order (lol_gpu_assemble_parts) */
 bool fill_table(PartTable& tab, int n_parts, int band_rows, int h) {
 	uint32_t row = 0;
 	for (int r = 0; r < n_parts; r++) {
@@ -118,6 +129,27 @@ bool fill_table(PartTable& tab, int n_parts, int band_rows, int h) {
 	return row == (uint32_t)h;
 }
 
+/* parts stored device by device (device d owns parts d, d + n_dev, d + 2 n_dev, …, back to back): the layout of the
+ * per-device buffers and, concatenated in device order, of the root's staging buffer.  dev_row0[d] = first staging
+ * row of device d, dev_rows[d] = rows device d owns, tab.row0[part] = staging row where that part starts. */
+bool fill_device_major(PartTable& tab, uint32_t* dev_row0, uint32_t* dev_rows, int n_dev, int per_dev, int band_rows, int h) {
+	const int n_parts = n_dev * per_dev;
+	uint32_t row = 0;
+	for (int d = 0; d < n_dev; d++) {
+		dev_row0[d] = row;
+		for (int j = 0; j < per_dev; j++) {
+			const int part = d + j * n_dev;
+			lol_gpu_rows R = { band_rows, n_parts, part };
+			int n = lol_gpu_part_rows(h, &R);
+			if (n < 0) return false;
+			tab.row0[part] = row;
+			row += (uint32_t)n;
+		}
+		dev_rows[d] = row - dev_row0[d];
+	}
+	return row == (uint32_t)h;
+}
+
 }  // namespace
 
 struct lol_gpu_multi {
@@ -126,10 +158,12 @@ struct lol_gpu_multi {
 	Rccl      rccl;
 	bool      comms_up = false;
 	int       band_override = 0;
+	int       per_dev = 1;                             /* parts per device */
+	int       host_via_root = 0;                       /* render_host: assemble on the root first (RCCL) instead of direct copies */
 	uint32_t* staging[SLOTS] = { nullptr, nullptr };   /* root: every part of a frame, back to back */
 	size_t    staging_bytes = 0;
 	hipEvent_t done[SLOTS] = { nullptr, nullptr };     /* root: frame of this slot assembled (staging free again) */
-	uint32_t* d_frame = nullptr;                       /* root: framebuffer of the host-surface path */
+	uint32_t* d_frame = nullptr;                       /* root: framebuffer of the host-surface path when host_via_root */
 	size_t    frame_bytes = 0;
 	unsigned long frames = 0;
 	char      err[512] = { 0 };
@@ -157,12 +191,11 @@ int mfail(lol_gpu_multi* m, int status, const char* what, const char* detail = n
 	} while (0)
 
 /* (re)size the per-device part buffers and the root's staging for frames of w x h */
-int ensure_buffers(lol_gpu_multi* m, int w, int h, int band_rows) {
-	size_t need_staging = (size_t)w * h * 4;
+int ensure_buffers(lol_gpu_multi* m, int w, int h, const uint32_t* dev_rows, bool want_staging) {
+	size_t need_staging = want_staging ? (size_t)w * h * 4 : 0;
 	for (int d = 0; d < m->n; d++) {
 		Device& D = m->dev[d];
-		lol_gpu_rows R = { band_rows, m->n, d };
-		size_t need = (size_t)lol_gpu_part_rows(h, &R) * w * 4;
+		size_t need = (size_t)dev_rows[d] * w * 4;
 		if (need > D.part_bytes) {
 			M_HIP(m, hipSetDevice(D.id));
 			M_HIP(m, hipDeviceSynchronize());
@@ -213,7 +246,7 @@ int lol_gpu_part_frame_row(int h, const lol_gpu_rows* rows, int local_row) {
 int lol_gpu_assemble_parts(lol_gpu* ctx, const void* parts, int n_parts, int band_rows, int w, int h,
                            void* dst, size_t pitch_bytes, void* stream) {
 	if (!ctx || !parts || !dst) return LOL_GPU_ERR_ARG;
-	if (n_parts < 1 || n_parts > LOL_GPU_MULTI_MAX_DEVICES || band_rows < 1 || w < 1 || h < 1 ||
+	if (n_parts < 1 || n_parts > MAX_PARTS || band_rows < 1 || w < 1 || h < 1 ||
 	    pitch_bytes % 4 || pitch_bytes < (size_t)w * 4)
 		return LOL_GPU_ERR_ARG;
 	PartTable tab;
@@ -248,7 +281,6 @@ int lol_gpu_multi_create(const int* devices, int n, lol_gpu_multi** out) {
 		lol_gpu_multi_destroy(m);
 		return LOL_GPU_ERR_HIP;
 	};
-	if (!m->rccl.load(m->err, sizeof m->err)) return bail(m->err, nullptr);
 	for (int i = 0; i < n; i++) {
 		Device& D = m->dev[i];
 		D.id = devices[i];
@@ -267,11 +299,7 @@ int lol_gpu_multi_create(const int* devices, int n, lol_gpu_multi** out) {
 		for (int s = 0; s < SLOTS && e == hipSuccess; s++) e = hipEventCreateWithFlags(&m->done[s], hipEventDisableTiming);
 		if (e != hipSuccess) return bail("event setup", hipGetErrorString(e));
 	}
-	ncclComm_t comms[LOL_GPU_MULTI_MAX_DEVICES];
-	ncclResult_t r = m->rccl.CommInitAll(comms, n, devices);
-	if (r != ncclSuccess) return bail("ncclCommInitAll", m->rccl.GetErrorString(r));
-	for (int i = 0; i < n; i++) m->dev[i].comm = comms[i];
-	m->comms_up = true;
+	if (const char* e = getenv("LOL_GPU_MULTI_HOST_VIA_ROOT")) m->host_via_root = e[0] == '1';
 	*out = m;
 	return LOL_GPU_OK;
 }
@@ -333,45 +361,92 @@ int lol_gpu_multi_upload_program(lol_gpu_multi* m, const lol_program* prog) {
 	return LOL_GPU_OK;
 }
 
-int lol_gpu_multi_render_device(lol_gpu_multi* m, const lol_frame_camera* cam, int w, int h, int max_steps,
-                                void* dst, size_t pitch_bytes) {
-	if (!m || !cam || !dst) return LOL_GPU_ERR_ARG;
-	if (w <= 0 || h <= 0 || pitch_bytes % 4 || pitch_bytes < (size_t)w * 4) return mfail(m, LOL_GPU_ERR_ARG, "bad frame geometry");
-	const int n = m->n;
-	const int band = m->band_override > 0 ? m->band_override : lol_gpu_choose_band_rows(h, n);
-	int st = ensure_buffers(m, w, h, band);
+int lol_gpu_multi_set_parts_per_device(lol_gpu_multi* m, int parts) {
+	if (!m || parts < 1 || parts * m->n > MAX_PARTS) return LOL_GPU_ERR_ARG;
+	int st = lol_gpu_multi_sync(m);
 	if (st != LOL_GPU_OK) return st;
-	PartTable tab;
-	if (!fill_table(tab, n, band, h)) return mfail(m, LOL_GPU_ERR_ARG, "bad row partition");
-	const int slot = (int)(m->frames % SLOTS);
-	m->frames++;
-	Device& root = m->dev[0];
+	m->per_dev = parts;
+	return LOL_GPU_OK;
+}
 
-	/* every device renders its part; the root's own part takes the same road as the others (a send to itself),
-	 * so that one code path serves any number of devices, one included */
-	size_t count[LOL_GPU_MULTI_MAX_DEVICES];
-	for (int d = 0; d < n; d++) {
+int lol_gpu_multi_set_host_via_root(lol_gpu_multi* m, int enable) {
+	if (!m) return LOL_GPU_ERR_ARG;
+	m->host_via_root = enable ? 1 : 0;
+	return LOL_GPU_OK;
+}
+
+/* RCCL on first use: load the library, one communicator per device */
+static int ensure_comms(lol_gpu_multi* m) {
+	if (m->comms_up) return LOL_GPU_OK;
+	if (!m->rccl.handle && !m->rccl.load(m->err, sizeof m->err)) return LOL_GPU_ERR_HIP;
+	ncclComm_t comms[LOL_GPU_MULTI_MAX_DEVICES];
+	int ids[LOL_GPU_MULTI_MAX_DEVICES];
+	for (int i = 0; i < m->n; i++) ids[i] = m->dev[i].id;
+	M_NCCL(m, m->rccl.CommInitAll(comms, m->n, ids));
+	for (int i = 0; i < m->n; i++) m->dev[i].comm = comms[i];
+	m->comms_up = true;
+	return LOL_GPU_OK;
+}
+
+/* the partition of a frame of height h: band height, part table (device-major), rows per device */
+struct Split { int band; PartTable tab; uint32_t dev_row0[LOL_GPU_MULTI_MAX_DEVICES], dev_rows[LOL_GPU_MULTI_MAX_DEVICES]; };
+
+static int split_frame(lol_gpu_multi* m, int h, Split& S) {
+	const int n_parts = m->n * m->per_dev;
+	S.band = m->band_override > 0 ? m->band_override : lol_gpu_choose_band_rows(h, n_parts);
+	if (!fill_device_major(S.tab, S.dev_row0, S.dev_rows, m->n, m->per_dev, S.band, h)) return mfail(m, LOL_GPU_ERR_ARG, "bad row partition");
+	return LOL_GPU_OK;
+}
+
+/* queue the kernels of one frame: device d renders its parts back to back into part[slot] on its render stream */
+static int render_parts(lol_gpu_multi* m, const lol_frame_camera* cam, int w, int h, int max_steps, const Split& S, int slot) {
+	const int n_parts = m->n * m->per_dev;
+	for (int d = 0; d < m->n; d++) {
 		Device& D = m->dev[d];
-		lol_gpu_rows R = { band, n, d };
-		const int rows = lol_gpu_part_rows(h, &R);
-		count[d] = (size_t)rows * w;
 		M_HIP(m, hipSetDevice(D.id));
 		M_HIP(m, hipStreamWaitEvent(D.render, D.sent[slot], 0));      /* the frame two back has left part[slot] */
-		if (rows > 0) {
-			st = lol_gpu_render_device(D.ctx, cam, w, h, max_steps, &R, D.part[slot], (size_t)w * 4, nullptr, D.render);
+		for (int j = 0; j < m->per_dev; j++) {
+			lol_gpu_rows R = { S.band, n_parts, d + j * m->n };
+			if (lol_gpu_part_rows(h, &R) <= 0) continue;
+			uint32_t* dst = D.part[slot] + (size_t)(S.tab.row0[R.part] - S.dev_row0[d]) * w;
+			int st = lol_gpu_render_device(D.ctx, cam, w, h, max_steps, &R, dst, (size_t)w * 4, nullptr, D.render);
 			if (st != LOL_GPU_OK) return mfail(m, st, "lol_gpu_render_device", lol_gpu_error(D.ctx));
 		}
 		M_HIP(m, hipEventRecord(D.rendered[slot], D.render));
 		M_HIP(m, hipStreamWaitEvent(D.xchg, D.rendered[slot], 0));
 	}
-	/* the exchange: one group, every device sends, the root receives every part (its own included) */
+	return LOL_GPU_OK;
+}
+
+int lol_gpu_multi_render_device(lol_gpu_multi* m, const lol_frame_camera* cam, int w, int h, int max_steps,
+                                void* dst, size_t pitch_bytes) {
+	if (!m || !cam || !dst) return LOL_GPU_ERR_ARG;
+	if (w <= 0 || h <= 0 || pitch_bytes % 4 || pitch_bytes < (size_t)w * 4) return mfail(m, LOL_GPU_ERR_ARG, "bad frame geometry");
+	const int n = m->n;
+	Split S;
+	int st = split_frame(m, h, S);
+	if (st != LOL_GPU_OK) return st;
+	st = ensure_comms(m);
+	if (st != LOL_GPU_OK) return st;
+	st = ensure_buffers(m, w, h, S.dev_rows, true);
+	if (st != LOL_GPU_OK) return st;
+	const int slot = (int)(m->frames % SLOTS);
+	m->frames++;
+	Device& root = m->dev[0];
+
+	/* every device renders its parts; the root's own take the same road as the others (a send to itself),
+	 * so that one code path serves any number of devices, one included */
+	st = render_parts(m, cam, w, h, max_steps, S, slot);
+	if (st != LOL_GPU_OK) return st;
+	/* the exchange: one group, every device sends its parts (one message), the root receives them device by device */
 	M_HIP(m, hipSetDevice(root.id));
 	M_HIP(m, hipStreamWaitEvent(root.xchg, m->done[slot], 0));        /* staging[slot] was assembled two frames ago */
 	M_NCCL(m, m->rccl.GroupStart());
 	for (int d = 0; d < n; d++) {
-		if (count[d] == 0) continue;
-		M_NCCL(m, m->rccl.Send(m->dev[d].part[slot], count[d], ncclUint32, 0, m->dev[d].comm, m->dev[d].xchg));
-		M_NCCL(m, m->rccl.Recv(m->staging[slot] + (size_t)tab.row0[d] * w, count[d], ncclUint32, d, root.comm, root.xchg));
+		const size_t count = (size_t)S.dev_rows[d] * w;
+		if (count == 0) continue;
+		M_NCCL(m, m->rccl.Send(m->dev[d].part[slot], count, ncclUint32, 0, m->dev[d].comm, m->dev[d].xchg));
+		M_NCCL(m, m->rccl.Recv(m->staging[slot] + (size_t)S.dev_row0[d] * w, count, ncclUint32, d, root.comm, root.xchg));
 	}
 	M_NCCL(m, m->rccl.GroupEnd());
 	for (int d = 0; d < n; d++) {
@@ -379,7 +454,7 @@ int lol_gpu_multi_render_device(lol_gpu_multi* m, const lol_frame_camera* cam, i
 		M_HIP(m, hipEventRecord(m->dev[d].sent[slot], m->dev[d].xchg));
 	}
 	M_HIP(m, hipSetDevice(root.id));
-	M_HIP(m, launch_assemble(m->staging[slot], tab, n, band, w, h, dst, pitch_bytes, root.xchg));
+	M_HIP(m, launch_assemble(m->staging[slot], S.tab, n * m->per_dev, S.band, w, h, dst, pitch_bytes, root.xchg));
 	M_HIP(m, hipEventRecord(m->done[slot], root.xchg));
 	return LOL_GPU_OK;
 }
@@ -395,27 +470,84 @@ int lol_gpu_multi_sync(lol_gpu_multi* m) {
 	return LOL_GPU_OK;
 }
 
+/* One part of the frame from its compact device copy into the host surface: the part's bands are band_rows rows each,
+ * n_parts * band_rows rows apart in the frame — one strided 3-D copy (+ one 2-D copy if the part owns the frame's
+ * partial last band). */
+static int copy_part_to_host(lol_gpu_multi* m, const uint32_t* part_dev, const lol_gpu_rows& R, int w, int h,
+                             char* host, size_t pitch, hipStream_t s) {
+	const int rows = lol_gpu_part_rows(h, &R);
+	const int full = rows / R.band_rows, tail = rows - full * R.band_rows;
+	if (full > 0) {
+		hipMemcpy3DParms p;
+		memset(&p, 0, sizeof p);
+		p.srcPtr = make_hipPitchedPtr(const_cast<uint32_t*>(part_dev), (size_t)w * 4, (size_t)w * 4, (size_t)R.band_rows);
+		p.dstPtr = make_hipPitchedPtr(host + (size_t)R.part * R.band_rows * pitch, pitch, (size_t)w * 4,
+		                              (size_t)R.n_parts * R.band_rows);
+		p.extent = make_hipExtent((size_t)w * 4, (size_t)R.band_rows, (size_t)full);
+		p.kind = hipMemcpyDeviceToHost;
+		M_HIP(m, hipMemcpy3DAsync(&p, s));
+	}
+	if (tail > 0) {
+		const size_t y0 = ((size_t)full * R.n_parts + R.part) * R.band_rows;
+		M_HIP(m, hipMemcpy2DAsync(host + y0 * pitch, pitch, part_dev + (size_t)full * R.band_rows * w, (size_t)w * 4,
+		                          (size_t)w * 4, (size_t)tail, hipMemcpyDeviceToHost, s));
+	}
+	return LOL_GPU_OK;
+}
+
 int lol_gpu_multi_render_host(lol_gpu_multi* m, const lol_frame_camera* cam, int w, int h, int max_steps,
                               void* host_pixels, size_t pitch_bytes) {
-	if (!m || !host_pixels) return LOL_GPU_ERR_ARG;
+	if (!m || !host_pixels || !cam) return LOL_GPU_ERR_ARG;
 	if (w <= 0 || h <= 0 || pitch_bytes < (size_t)w * 4) return mfail(m, LOL_GPU_ERR_ARG, "bad frame geometry");
-	const size_t need = (size_t)w * h * 4;
 	Device& root = m->dev[0];
-	M_HIP(m, hipSetDevice(root.id));
-	if (need > m->frame_bytes) {                 /* the surface may be resized between frames (main.c:182-187) */
-		int st = lol_gpu_multi_sync(m);
+	if (m->host_via_root) {
+		/* assemble on the root (RCCL exchange), then ONE copy over the root's link */
+		const size_t need = (size_t)w * h * 4;
+		M_HIP(m, hipSetDevice(root.id));
+		if (need > m->frame_bytes) {                 /* the surface may be resized between frames (main.c:182-187) */
+			int st = lol_gpu_multi_sync(m);
+			if (st != LOL_GPU_OK) return st;
+			if (m->d_frame) (void)hipFree(m->d_frame);
+			m->d_frame = nullptr; m->frame_bytes = 0;
+			M_HIP(m, hipMalloc(reinterpret_cast<void**>(&m->d_frame), need));
+			m->frame_bytes = need;
+		}
+		int st = lol_gpu_multi_render_device(m, cam, w, h, max_steps, m->d_frame, (size_t)w * 4);
 		if (st != LOL_GPU_OK) return st;
-		if (m->d_frame) (void)hipFree(m->d_frame);
-		m->d_frame = nullptr; m->frame_bytes = 0;
-		M_HIP(m, hipMalloc(reinterpret_cast<void**>(&m->d_frame), need));
-		m->frame_bytes = need;
+		M_HIP(m, hipSetDevice(root.id));
+		M_HIP(m, hipMemcpy2DAsync(host_pixels, pitch_bytes, m->d_frame, (size_t)w * 4, (size_t)w * 4, h,
+		                          hipMemcpyDeviceToHost, root.xchg));
+		M_HIP(m, hipStreamSynchronize(root.xchg));
+		return LOL_GPU_OK;
 	}
-	int st = lol_gpu_multi_render_device(m, cam, w, h, max_steps, m->d_frame, (size_t)w * 4);
+	/* every device copies its own bands into the surface: N links in parallel, no exchange, no RCCL */
+	Split S;
+	int st = split_frame(m, h, S);
 	if (st != LOL_GPU_OK) return st;
+	st = ensure_buffers(m, w, h, S.dev_rows, false);
+	if (st != LOL_GPU_OK) return st;
+	const int slot = (int)(m->frames % SLOTS);
+	m->frames++;
+	st = render_parts(m, cam, w, h, max_steps, S, slot);
+	if (st != LOL_GPU_OK) return st;
+	const int n_parts = m->n * m->per_dev;
+	for (int d = 0; d < m->n; d++) {
+		Device& D = m->dev[d];
+		M_HIP(m, hipSetDevice(D.id));
+		for (int j = 0; j < m->per_dev; j++) {
+			lol_gpu_rows R = { S.band, n_parts, d + j * m->n };
+			if (lol_gpu_part_rows(h, &R) <= 0) continue;
+			st = copy_part_to_host(m, D.part[slot] + (size_t)(S.tab.row0[R.part] - S.dev_row0[d]) * w, R, w, h,
+			                       static_cast<char*>(host_pixels), pitch_bytes, D.xchg);
+			if (st != LOL_GPU_OK) return st;
+		}
+		M_HIP(m, hipEventRecord(D.sent[slot], D.xchg));
+	}
+	for (int d = 0; d < m->n; d++) {
+		M_HIP(m, hipSetDevice(m->dev[d].id));
+		M_HIP(m, hipStreamSynchronize(m->dev[d].xchg));
+	}
 	M_HIP(m, hipSetDevice(root.id));
-	M_HIP(m, hipMemcpy2DAsync(host_pixels, pitch_bytes, m->d_frame, (size_t)w * 4, (size_t)w * 4, h,
-	                          hipMemcpyDeviceToHost, root.xchg));
-	M_HIP(m, hipStreamSynchronize(root.xchg));
 	return LOL_GPU_OK;
 }
 

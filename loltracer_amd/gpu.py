@@ -137,6 +137,10 @@ def gpu_lib() -> C.CDLL:
         lib.lol_gpu_multi_render_device.restype = C.c_int
         lib.lol_gpu_multi_render_host.argtypes = [vp, P(S.FrameCamera), C.c_int, C.c_int, C.c_int, vp, C.c_size_t]
         lib.lol_gpu_multi_render_host.restype = C.c_int
+        lib.lol_gpu_multi_set_parts_per_device.argtypes = [vp, C.c_int]
+        lib.lol_gpu_multi_set_parts_per_device.restype = C.c_int
+        lib.lol_gpu_multi_set_host_via_root.argtypes = [vp, C.c_int]
+        lib.lol_gpu_multi_set_host_via_root.restype = C.c_int
         lib.lol_gpu_multi_sync.argtypes = [vp]
         lib.lol_gpu_multi_sync.restype = C.c_int
         lib.lol_gpu_multi_malloc.argtypes = [vp, C.c_size_t, P(vp)]
@@ -162,6 +166,7 @@ EXPORTED_SYMBOLS = [
     "lol_gpu_multi_context", "lol_gpu_multi_upload_program", "lol_gpu_choose_band_rows", "lol_gpu_multi_set_band_rows",
     "lol_gpu_part_frame_row", "lol_gpu_multi_render_device", "lol_gpu_multi_render_host", "lol_gpu_multi_sync",
     "lol_gpu_multi_malloc", "lol_gpu_multi_free", "lol_gpu_multi_memcpy_d2h", "lol_gpu_assemble_parts",
+    "lol_gpu_multi_set_parts_per_device", "lol_gpu_multi_set_host_via_root",
 ]
 
 
@@ -312,6 +317,12 @@ class MultiRenderer:
 
     def set_band_rows(self, band_rows: int):
         self._check(self._lib.lol_gpu_multi_set_band_rows(self._m, band_rows))
+
+    def set_parts_per_device(self, parts: int):
+        self._check(self._lib.lol_gpu_multi_set_parts_per_device(self._m, parts))
+
+    def set_host_via_root(self, enable: bool):
+        self._check(self._lib.lol_gpu_multi_set_host_via_root(self._m, 1 if enable else 0))
 
     def render_into(self, dst_ptr: int, w: int, h: int, max_steps: int = 256, camera: S.Camera | None = None,
                     pitch_bytes: int | None = None, frame_camera: S.FrameCamera | None = None):

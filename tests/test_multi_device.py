@@ -147,6 +147,38 @@ def test_multi_path_on_one_device_equals_the_single_device_frame(scenes):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("via_root", [False, True], ids=["direct-copies", "via-root"])
+@pytest.mark.parametrize("parts,band,w,h", [(1, 0, 640, 360), (2, 0, 640, 360), (3, 4, 333, 181), (8, 12, 512, 300), (5, 16, 200, 97)])
+def test_host_surface_with_several_parts_per_device(scenes, parts, band, w, h, via_root):
+    """The multi-part machinery on ONE device: `parts` parts owned by device 0 (bands dealt over them), each part
+    rendered by its own launch, then either copied band by band straight into the host surface (strided 3-D copies —
+    what N devices do in parallel over N PCIe links) or sent through the RCCL exchange and assembled on the root.
+    Both must give the single-launch frame, for heights that are not a multiple of the band and a padded pitch."""
+    import torch
+    single = gpu.Renderer(0)
+    single.prepare(scenes["scene4"])
+    want = _frame(single, torch, w, h).cpu().numpy().view(np.uint32)
+    m = gpu.MultiRenderer([0])
+    m.prepare(scenes["scene4"])
+    m.set_parts_per_device(parts)
+    m.set_band_rows(band)
+    m.set_host_via_root(via_root)
+    pitch = (w + 9) * 4
+    for _ in range(2):                                          # twice: both buffer slots
+        host = np.full((h, pitch // 4), 0xDEADBEEF, dtype=np.uint32)
+        m.render_host(host.ctypes.data, w, h, pitch_bytes=pitch)
+        assert np.array_equal(host[:, :w], want)
+        assert (host[:, w:] == 0xDEADBEEF).all()                # nothing written past the row
+    # and the device-resident form with the same split
+    got = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    m.render_into(got.data_ptr(), w, h)
+    m.sync()
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), want)
+    m.close()
+    single.close()
+
+
+@pytest.mark.gpu
 def test_duplicate_devices_are_refused():
     with pytest.raises(gpu.GpuError) as e:
         gpu.MultiRenderer([0, 0])
