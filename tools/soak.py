@@ -1,4 +1,4 @@
-"""One-off soak: many random scenes, GPU (spec + interp) vs the CPU oracle.  python tools/soak.py [n] [seed]"""
+"""Soak: many random scenes, GPU (spec + interp) vs the CPU oracle.  python tools/soak.py [n] [seed] [stress]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -9,11 +9,44 @@ from loltracer_amd import gpu, scene as S
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+stress = len(sys.argv) > 3 and sys.argv[3] == "stress"
 rng = np.random.default_rng(seed)
+
+
+def stress_scene(rng):
+    """Scenes that lean on the culling bounds: many top-level objects of very different sizes and distances, smoothness
+    from 0.01 to 60 (and 0 / negative: no bound), coordinates up to 10^4, negative radii, cameras inside objects."""
+    scale = float(rng.choice([1, 1, 1, 30, 1000]))
+
+    def leaf():
+        c = rng.normal(size=3) * [6, 3, 6] * scale + [0, 1, -8 * scale]
+        if rng.random() < 0.6:
+            return "sphere { point = %s, radius = %s }" % (F.fmt(c), F.num(rng.choice([-1, 0, 0.01, 0.5, 2, 9]) * scale))
+        return "box { point = %s, point2 = %s, radius = %s }" % (F.fmt(c), F.fmt(rng.uniform(0, 4, 3) * scale), F.num(rng.choice([0, 0.3, 2]) * scale))
+
+    def tree(d):
+        if d == 0 or rng.random() < 0.35:
+            return leaf() if rng.random() < 0.93 else "plane { y = %s }" % F.num(rng.uniform(-5, 0) * scale)
+        k = rng.choice([0, -1, 0.01, 0.3, 1, 4, 15, 60]) * scale
+        return "smooth_union { smoothness = %s, a = %s, b = %s }" % (F.num(k), tree(d - 1), tree(int(rng.integers(0, d))))
+
+    mats = "materials { { shininess = 2, diffuse = (0,0,0), specular = (0,0,0), ambient = (.1,.1,.1) }, { shininess = 9, diffuse = (.5,.4,.3), specular = (.3,.3,.3), ambient = (.1,.1,.1) } }"
+    comps = ["camera { point = %s, direction = %s, fov = %s }" % (F.fmt(rng.normal(size=3) * [3, 2, 3] * scale), F.fmt(rng.normal(size=3) * 0.3 + [0, -0.2, -1]), F.num(rng.uniform(50, 150)))]
+    for _ in range(int(rng.integers(0, 3))):
+        comps.append("point_light { point = %s, diffuse_intensity = (2,2,2), specular_intensity = (1,1,1) }" % F.fmt(rng.normal(size=3) * 8 * scale + [0, 9 * scale, 0]))
+    order = [0, 1] if rng.random() < 0.5 else [1, 0]
+    objs = []
+    for _ in range(int(rng.integers(1, 9))):
+        o = tree(int(rng.integers(0, 4)))
+        head, rest = o.split("{", 1)
+        objs.append("%s{ material = #1,%s" % (head, rest))
+    if rng.random() < 0.7:
+        objs.insert(int(rng.integers(0, len(objs) + 1)), "plane { material = #1, y = %s }" % F.num(rng.uniform(-6, -1) * scale))
+    return mats + "\nscene { " + ",\n".join(comps + objs) + " }\n"
 rs = {m: gpu.Renderer(0, specialize=m) for m in (1, 4)}
 bad = 0
 for i in range(n):
-    text = F.rand_scene(rng)
+    text = stress_scene(rng) if stress else F.rand_scene(rng)
     sc = S.Scene.parse_string(text)
     w, h = int(rng.integers(17, 90)), int(rng.integers(9, 60))
     for m, r in rs.items():
