@@ -23,6 +23,7 @@
 #include <dlfcn.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <algorithm>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -331,13 +332,16 @@ CullTest make_test(const Sphere& b) {
 	return t;
 }
 
+/* A test guards a run of consecutive objects of the evaluation order: [begin, end) positions in `order`.  Runs nest
+ * (the run of all bounded objects, inside it spatial clusters, inside those single heavy objects). */
+struct CullInterval { size_t begin, end; CullTest test; };
+
 struct CullPlan {
 	std::vector<uint32_t> order;          /* evaluation order: indices into the root list */
 	size_t   n_unbounded = 0;             /* the first n_unbounded entries of `order` have no bound */
-	bool     group = false;               /* one test in front of the whole bounded block */
+	std::vector<CullInterval> intervals;  /* outer before inner, by position */
+	bool     group = false;               /* intervals[0] is the run of ALL bounded objects (what the interpreter carries) */
 	CullTest group_test{};
-	std::vector<int> own_test;            /* per root (by index into roots): index into `tests` or -1 */
-	std::vector<CullTest> tests;
 };
 
 bool culling_enabled(int want) {
@@ -345,9 +349,50 @@ bool culling_enabled(int want) {
 	return want && !(e && e[0] == '0');
 }
 
+/* Objects that lie together are evaluated together, behind a test of their common bounding sphere: a k-d split of
+ * the bounded objects (median cut along the widest axis of their centres, down to runs of at most three) gives the
+ * evaluation order, and every node of that tree gets a test — single objects too: 11 instructions against a sphere's
+ * ~20 with its square root, measured faster on every scene tried (tools/flat_scene_ab.py: leaf sizes 2…8, tests from
+ * 1…4 primitives up; profiles/r2_flat_scene_ab.jsonl).  A ray that is far from a whole cluster pays one test for it
+ * instead of one evaluation per object — what makes a scene of hundreds of separate objects affordable. */
+static void kd_build(const std::vector<RootBound>& roots, std::vector<uint32_t>& ids, size_t lo, size_t hi,
+                     size_t base, bool has_predecessor, size_t leaf_max, uint32_t min_prims, CullPlan& plan) {
+	const size_t count = hi - lo;
+	Sphere g = { true, { roots[ids[lo]].c[0], roots[ids[lo]].c[1], roots[ids[lo]].c[2] }, roots[ids[lo]].r };
+	uint32_t prims = roots[ids[lo]].prims;
+	for (size_t k = lo + 1; k < hi; k++) {
+		const RootBound& r = roots[ids[k]];
+		g = enclose(g, { true, { r.c[0], r.c[1], r.c[2] }, r.r });
+		prims += r.prims;
+	}
+	/* a test needs a running minimum to compare with (something evaluated before the run); a node that covers
+	 * exactly what its parent covers adds nothing */
+	const bool same_as_parent = !plan.intervals.empty() && plan.intervals.back().begin == base + lo && plan.intervals.back().end == base + hi;
+	if ((has_predecessor || lo > 0) && prims >= min_prims && !same_as_parent)
+		plan.intervals.push_back({ base + lo, base + hi, make_test(g) });
+	if (count <= leaf_max) {
+		if (count > 1)                       /* inside a small run: the objects' own tests */
+			for (size_t k = lo; k < hi; k++) {
+				const RootBound& r = roots[ids[k]];
+				if (r.prims >= min_prims && (has_predecessor || k > 0))
+					plan.intervals.push_back({ base + k, base + k + 1, make_test({ true, { r.c[0], r.c[1], r.c[2] }, r.r }) });
+			}
+		return;
+	}
+	double mn[3] = { 1e300, 1e300, 1e300 }, mx[3] = { -1e300, -1e300, -1e300 };
+	for (size_t k = lo; k < hi; k++)
+		for (int a = 0; a < 3; a++) { mn[a] = fmin(mn[a], roots[ids[k]].c[a]); mx[a] = fmax(mx[a], roots[ids[k]].c[a]); }
+	int axis = 0;
+	for (int a = 1; a < 3; a++) if (mx[a] - mn[a] > mx[axis] - mn[axis]) axis = a;
+	const size_t mid = lo + count / 2;
+	std::nth_element(ids.begin() + lo, ids.begin() + mid, ids.begin() + hi,
+	                 [&](uint32_t x, uint32_t y) { return roots[x].c[axis] < roots[y].c[axis] || (roots[x].c[axis] == roots[y].c[axis] && x < y); });
+	kd_build(roots, ids, lo, mid, base, has_predecessor, leaf_max, min_prims, plan);
+	kd_build(roots, ids, mid, hi, base, has_predecessor, leaf_max, min_prims, plan);
+}
+
 CullPlan plan_culling(const std::vector<RootBound>& roots, bool enabled) {
 	CullPlan plan;
-	plan.own_test.assign(roots.size(), -1);
 	std::vector<uint32_t> bounded;
 	if (enabled)
 		for (uint32_t i = 0; i < roots.size(); i++) (roots[i].bounded ? bounded : plan.order).push_back(i);
@@ -355,25 +400,22 @@ CullPlan plan_culling(const std::vector<RootBound>& roots, bool enabled) {
 		for (uint32_t i = 0; i < roots.size(); i++) plan.order.push_back(i);
 	plan.n_unbounded = plan.order.size();
 	if (!enabled || bounded.empty()) return plan;
+	/* LOL_GPU_CULL_CLUSTERS=0: one run of all bounded objects in scene order, no spatial clusters (for A/B runs) */
+	const char* e = getenv("LOL_GPU_CULL_CLUSTERS");
+	const size_t leaf_max = (e && atoi(e) == 0) ? (size_t)-1 : (e && atoi(e) > 1 ? (size_t)atoi(e) : 3);
+	uint32_t min_prims = 1;
+	if (const char* m = getenv("LOL_GPU_CULL_MIN_PRIMS")) min_prims = (uint32_t)std::max(1, atoi(m));
+	kd_build(roots, bounded, 0, bounded.size(), plan.n_unbounded, plan.n_unbounded > 0, leaf_max, min_prims, plan);
 	plan.order.insert(plan.order.end(), bounded.begin(), bounded.end());
-	/* a running minimum exists once something has been evaluated: the group test needs an unbounded object in
-	 * front; an object's own test needs anything in front, and pays only for objects of several primitives */
-	if (plan.n_unbounded > 0) {
-		Sphere g = { true, { roots[bounded[0]].c[0], roots[bounded[0]].c[1], roots[bounded[0]].c[2] }, roots[bounded[0]].r };
-		for (size_t k = 1; k < bounded.size(); k++) {
-			const RootBound& r = roots[bounded[k]];
-			g = enclose(g, { true, { r.c[0], r.c[1], r.c[2] }, r.r });
-		}
+	/* outer runs before inner ones at the same position (kd_build emits parents first; keep that order stable) */
+	std::stable_sort(plan.intervals.begin(), plan.intervals.end(), [](const CullInterval& a, const CullInterval& b) {
+		return a.begin < b.begin || (a.begin == b.begin && a.end > b.end);
+	});
+	if (!plan.intervals.empty() && plan.intervals[0].begin == plan.n_unbounded && plan.intervals[0].end == plan.order.size() &&
+	    plan.n_unbounded > 0) {
 		plan.group = true;
-		plan.group_test = make_test(g);
+		plan.group_test = plan.intervals[0].test;
 	}
-	if (bounded.size() >= 2)
-		for (size_t k = 0; k < bounded.size(); k++) {
-			const RootBound& r = roots[bounded[k]];
-			if (r.prims < 3 || (k == 0 && plan.n_unbounded == 0)) continue;
-			plan.own_test[bounded[k]] = (int)plan.tests.size();
-			plan.tests.push_back(make_test({ true, { r.c[0], r.c[1], r.c[2] }, r.r }));
-		}
 	return plan;
 }
 
@@ -388,9 +430,10 @@ CullPlan plan_culling(const std::vector<RootBound>& roots, bool enabled) {
  *                                           SMIN_R has a = acc, b = x → sminf(acc, x);
  *   TOP                                   → a flag on the macro-op that produced the value (+ MOP_TIE where the
  *                                           object is evaluated after one that follows it in the file).
- * The objects come in the order of `plan` (unbounded ones first).  The plan's GROUP test — the one in front of all
- * bounded objects — becomes a constants record behind the last unbounded object's final macro-op, which gets
- * MOPB_CULL_NEXT; tests of single objects are a specialised-kernel refinement and are not carried over.
+ * The objects come in the order of `plan` (unbounded ones first).  Every test of the plan becomes a constants
+ * record in front of the first object of its run (outer runs first); the macro-op that finishes the object before
+ * it gets MOPB_CULL_NEXT (the run of all bounded objects) and / or MOPB_CULL_CHAIN (inner runs), and the
+ * CULLC_NEXT / CULLC_AFTER flags chain test records that follow one another directly.
  * `fast` lists the smoothness constants whose fast blend factor was proven on the device.
  */
 std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast, const std::vector<RootBound>& roots,
@@ -406,10 +449,33 @@ std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast, co
 		}
 		m[0] |= lol::mop_smin_bits(m[0]);
 	};
-	size_t group_at = (size_t)-1;                    /* the constants record of the group test */
+	/* LOL_GPU_INTERP_CULL_MIN_PRIMS: leave out the tests of runs with fewer primitives (measured: 1, i.e. keeping
+	 * every test, is fastest here too — a test is one turn of a scalar loop inside the rare TAIL branch). */
+	uint32_t min_prims = 1;
+	if (const char* e = getenv("LOL_GPU_INTERP_CULL_MIN_PRIMS")) min_prims = (uint32_t)std::max(1, atoi(e));
+	std::vector<CullInterval> ivs;
+	for (const CullInterval& iv : plan.intervals) {
+		uint32_t prims = 0;
+		for (size_t k = iv.begin; k < iv.end; k++) prims += roots[plan.order[k]].prims;
+		if (prims >= min_prims) ivs.push_back(iv);
+	}
+	const bool group_first = plan.group && !ivs.empty() && ivs[0].begin == plan.n_unbounded && ivs[0].end == plan.order.size();
+	std::vector<size_t> at(ivs.size());              /* where each test's constants record went */
+	std::vector<uint32_t> begins(plan.order.size() + 1, 0);
+	for (const CullInterval& iv : ivs) begins[iv.begin]++;
 	uint32_t max_id_seen = 0;
+	size_t next_iv = 0;
 	for (size_t oi = 0; oi < plan.order.size(); oi++) {
 		const RootBound& R = roots[plan.order[oi]];
+		for (uint32_t n = 0; n < begins[oi]; n++, next_iv++) {             /* (never at oi == 0: plan_culling) */
+			const CullInterval& iv = ivs[next_iv];
+			uint32_t c[lol::MOP_DWORDS] = { 0 };
+			c[0] = (n + 1 < begins[oi] ? lol::CULLC_NEXT : 0u) | (begins[iv.end] ? lol::CULLC_AFTER : 0u);
+			for (int j = 0; j < 3; j++) c[2 + j] = fbits32(iv.test.c[j]);
+			c[5] = fbits32(iv.test.rm);
+			at[next_iv] = out.size();
+			out.insert(out.end(), c, c + lol::MOP_DWORDS);
+		}
 		int depth = 0;                                   /* post-order stack depth before the current op */
 		size_t last = 0;                                 /* start of the macro-op that produced the current acc */
 		for (uint32_t i = R.first; i < R.top; i++) {
@@ -438,16 +504,14 @@ std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast, co
 		out[last] |= lol::MOP_TOP | lol::MOPB_TAIL | (R.id < max_id_seen ? lol::MOP_TIE : 0u);
 		out[last + 1] = R.id;
 		if (R.id > max_id_seen) max_id_seen = R.id;
-		if (plan.group && oi + 1 == plan.n_unbounded) {
-			out[last] |= lol::MOPB_CULL_NEXT;
-			uint32_t c[lol::MOP_DWORDS] = { 0 };
-			for (int j = 0; j < 3; j++) c[2 + j] = fbits32(plan.group_test.c[j]);
-			c[5] = fbits32(plan.group_test.rm);
-			group_at = out.size();
-			out.insert(out.end(), c, c + lol::MOP_DWORDS);
+		if (begins[oi + 1]) {
+			const bool group_here = group_first && oi + 1 == plan.n_unbounded;
+			if (group_here) out[last] |= lol::MOPB_CULL_NEXT;
+			if (begins[oi + 1] > (group_here ? 1u : 0u)) out[last] |= lol::MOPB_CULL_CHAIN;
 		}
+		for (size_t k = 0; k < ivs.size(); k++)                            /* every run that ends here: how far its test jumps */
+			if (ivs[k].end == oi + 1) out[at[k] + 1] = (uint32_t)((out.size() - at[k]) / lol::MOP_DWORDS - 1);
 	}
-	if (group_at != (size_t)-1) out[group_at + 1] = (uint32_t)((out.size() - group_at) / lol::MOP_DWORDS - 1);
 	return out;
 }
 
@@ -462,9 +526,9 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 	const int fsqrt = fast ? fast->sqrt_kind : 0;
 	char fs[32] = "";
 	if (fsqrt) snprintf(fs, sizeof fs, "_fast<%d>", fsqrt);
-	const int total_tests = (plan.group ? 1 : 0) + (int)plan.tests.size();
+	/* only the outermost test keeps a cool-down counter (wave-uniform state in the Sdf struct) */
 	char cool_decl[64] = "";
-	if (total_tests) snprintf(cool_decl, sizeof cool_decl, "\tu32 cool[%d] = {};\n", total_tests);
+	if (!plan.intervals.empty()) snprintf(cool_decl, sizeof cool_decl, "\tu32 cool[1] = {};\n");
 	if (out_of_line) {
 		/* out of line the cool-down state is per call (always 0: every evaluation tests) */
 		/* (amdgpu_waves_per_eu applies to kernels only: the function is scheduled with the default register budget) */
@@ -486,30 +550,42 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 	 * test only ever permits a skip — so this changes no result.  `cool` lives in the Sdf struct, wave-uniform. */
 	int cooldown = 3;
 	if (const char* e = getenv("LOL_GPU_CULL_COOLDOWN")) cooldown = atoi(e);
-	auto open_test = [&](const CullTest& ct) {
+	auto open_test = [&](const CullTest& ct, bool with_cooldown) {
 		const int k = n_tests++;
-		snprintf(line, sizeof line,
-		         "\t\t{ bool need%d = true;\n"
-		         "\t\t  if (cool[%d] == 0u) {\n"
-		         "\t\t  const float cx%d = p.x - %s, cy%d = p.y - %s, cz%d = p.z - %s;\n"
-		         "\t\t  const float cl%d = (cx%d * cx%d + cy%d * cy%d) + cz%d * cz%d;\n"
-		         "\t\t  const float cu%d = (best + %s) * %s;\n"
-		         "\t\t  const bool skip%d = cl%d > cu%d * cu%d && cu%d > 0.f;\n"
-		         "\t\t  need%d = __ballot(care && !skip%d) != 0;\n"
-		         "\t\t  if (need%d) cool[%d] = %du;\n"
-		         "\t\t  } else cool[%d]--;\n"
-		         "\t\t  if (need%d) {\n",
-		         k, k, k, fbits(ct.c[0]).c_str(), k, fbits(ct.c[1]).c_str(), k, fbits(ct.c[2]).c_str(),
-		         k, k, k, k, k, k, k, k, fbits(ct.rm).c_str(), fbits(1.0f + 0x1p-12f).c_str(), k, k, k, k, k,
-		         k, k, k, k, cooldown, k, k);
+		if (with_cooldown)
+			snprintf(line, sizeof line,
+			         "\t\t{ bool need%d = true;\n"
+			         "\t\t  if (cool[0] == 0u) {\n"
+			         "\t\t  const float cx%d = p.x - %s, cy%d = p.y - %s, cz%d = p.z - %s;\n"
+			         "\t\t  const float cl%d = (cx%d * cx%d + cy%d * cy%d) + cz%d * cz%d;\n"
+			         "\t\t  const float cu%d = (best + %s) * %s;\n"
+			         "\t\t  const bool skip%d = cl%d > cu%d * cu%d && cu%d > 0.f;\n"
+			         "\t\t  need%d = __ballot(care && !skip%d) != 0;\n"
+			         "\t\t  if (need%d) cool[0] = %du;\n"
+			         "\t\t  } else cool[0]--;\n"
+			         "\t\t  if (need%d) {\n",
+			         k, k, fbits(ct.c[0]).c_str(), k, fbits(ct.c[1]).c_str(), k, fbits(ct.c[2]).c_str(),
+			         k, k, k, k, k, k, k, k, fbits(ct.rm).c_str(), fbits(1.0f + 0x1p-12f).c_str(), k, k, k, k, k,
+			         k, k, k, cooldown, k);
+		else
+			snprintf(line, sizeof line,
+			         "\t\t{ const float cx%d = p.x - %s, cy%d = p.y - %s, cz%d = p.z - %s;\n"
+			         "\t\t  const float cl%d = (cx%d * cx%d + cy%d * cy%d) + cz%d * cz%d;\n"
+			         "\t\t  const float cu%d = (best + %s) * %s;\n"
+			         "\t\t  const bool skip%d = cl%d > cu%d * cu%d && cu%d > 0.f;\n"
+			         "\t\t  if (__ballot(care && !skip%d) != 0) {\n",
+			         k, fbits(ct.c[0]).c_str(), k, fbits(ct.c[1]).c_str(), k, fbits(ct.c[2]).c_str(),
+			         k, k, k, k, k, k, k, k, fbits(ct.rm).c_str(), fbits(1.0f + 0x1p-12f).c_str(), k, k, k, k, k, k);
 		s += line;
 	};
 	uint32_t max_id_seen = 0;
+	size_t next_iv = 0;
 	for (size_t oi = 0; oi < plan.order.size(); oi++) {
 		const RootBound& R = roots[plan.order[oi]];
-		if (plan.group && oi == plan.n_unbounded) open_test(plan.group_test);
-		const int own = plan.own_test[plan.order[oi]];
-		if (own >= 0) open_test(plan.tests[own]);
+		while (next_iv < plan.intervals.size() && plan.intervals[next_iv].begin == oi) {      /* outer runs first */
+			open_test(plan.intervals[next_iv].test, next_iv == 0);
+			next_iv++;
+		}
 		std::vector<int> stack;
 		for (uint32_t i = R.first; i < R.top; i++) {
 			const lol_op& o = P.ops[i];
@@ -549,9 +625,9 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 			snprintf(line, sizeof line, "\t\tif (t%d < best) { best = t%d; best_id = %uu; }\n", d, d, R.id);
 		s += line;
 		if (R.id > max_id_seen) max_id_seen = R.id;
-		if (own >= 0) s += "\t\t} }\n";
+		for (const CullInterval& iv : plan.intervals)                                        /* every run that ends here */
+			if (iv.end == oi + 1) s += "\t\t} }\n";
 	}
-	if (plan.group) s += "\t\t} }\n";
 	if (out_of_line) {
 		s += "\t\treturn { best, best_id, rg.lo, rg.hi };\n}\n";
 		snprintf(line, sizeof line, "struct %s {\n\tRange rg;\n\t__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id, bool care = true) {\n"
@@ -925,7 +1001,7 @@ int lol_gpu_create(int device, lol_gpu** out) {
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_prog), sizeof(lol_program));
 	/* at most one macro-op per op, plus the group test's constants record */
-	if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_mops), (size_t)(LOL_MAX_OPS + 1) * lol::MOP_DWORDS * 4);
+	if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_mops), (size_t)(2 * LOL_MAX_OPS) * lol::MOP_DWORDS * 4);   /* macro-ops + test records <= 1.5 x ops */
 	if (e != hipSuccess) {
 		fprintf(stderr, "lol_gpu_create: %s\n", hipGetErrorString(e));
 		lol_gpu_destroy(ctx);
@@ -1055,7 +1131,7 @@ int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog) {
 		const std::vector<RootBound> roots = analyse_roots(*prog);
 		std::vector<uint32_t> mops = build_mops(*prog, &fast, roots, plan_culling(roots, culling_enabled(ctx->want_cull)));
 		ctx->n_mops = (uint32_t)(mops.size() / lol::MOP_DWORDS);
-		if (ctx->n_mops > LOL_MAX_OPS + 1) return fail(ctx, LOL_GPU_ERR_UNSUPPORTED, "program exceeds interpreter limits");
+		if (ctx->n_mops > 2 * LOL_MAX_OPS) return fail(ctx, LOL_GPU_ERR_UNSUPPORTED, "program exceeds interpreter limits");
 		hipError_t e = hipMemcpy(ctx->d_prog, prog, sizeof *prog, hipMemcpyHostToDevice);
 		if (e == hipSuccess && !mops.empty())
 			e = hipMemcpy(ctx->d_mops, mops.data(), mops.size() * 4, hipMemcpyHostToDevice);

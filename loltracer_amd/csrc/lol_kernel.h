@@ -396,10 +396,15 @@ constexpr u32 MOPB_SMIN_AF = 2048u;     /* sminf_fastdiv(acc, x) */
 constexpr u32 MOPB_SMIN_XF = 4096u;     /* sminf_fastdiv(x, acc) */
 constexpr u32 MOPB_SMIN_EXACT = 8192u;  /* unproven k: sminf_ with the correctly rounded division, order by MOPB_X_IS_A */
 /* Exact object culling (lol_gpu.hip, "exact culling") in the interpreter: a record that finishes a top-level object
- * (MOP_TOP) may carry MOPB_CULL_NEXT — the NEXT record is then not a macro-op but the test's constants
- * {f[0..2] = C, f[3] = R', word 1 = how many records after it belong to the objects the test guards}; if every lane
- * that cares may skip them, they are jumped over.  Lives in the rare TAIL branch, so ordinary records pay nothing. */
-constexpr u32 MOPB_CULL_NEXT = 16384u;
+ * (MOP_TOP) may carry MOPB_CULL_NEXT / MOPB_CULL_CHAIN — the NEXT record is then not a macro-op but a test's constants
+ * {word 0 = CULLC_* flags, word 1 = how many records after it belong to the objects the test guards, f[2..4] = C,
+ * f[5] = R'}; if every lane that cares may skip them, they are jumped over.  Runs nest (lol_gpu.hip, plan_culling):
+ * CULLC_NEXT says the record after this one is the test of a run nested in this one, CULLC_AFTER that the record
+ * after the guarded ones is the test of the run that follows.  Lives in the rare TAIL branch, so ordinary records
+ * pay nothing. */
+constexpr u32 MOPB_CULL_NEXT = 16384u;    /* the test of the run of ALL bounded objects: the one with a cool-down */
+constexpr u32 MOPB_CULL_CHAIN = 65536u;   /* one or more tests of inner runs follow (after the NEXT one, if both) */
+constexpr u32 CULLC_NEXT = 1u, CULLC_AFTER = 2u;
 constexpr u32 MOP_TIE = 32768u;         /* with MOP_TOP: evaluated after an object that follows it in the file → ties go to the lower id */
 constexpr float CULL_K = 1.0f + 0x1p-12f;
 constexpr u32 CULL_COOLDOWN = 3u;       /* after a test that did not allow the skip, this many evaluations do not test */
@@ -483,31 +488,53 @@ struct Interp {
 					for (int j = SSIZE - 1; j > 0; j--) s[j] = s[j - 1];
 					s[0] = acc;
 				}
-				if (hdr & MOP_TOP) {
+				if (hdr & MOP_TOP) {                                    /* (tests only follow finished objects) */
 					LOL_KEEP_BRANCH();
 					const u32 id = rec[1];
 					if (!(hdr & MOP_TIE)) { LOL_KEEP_BRANCH(); if (x < best) { best = x; best_id = id; } }
 					if (hdr & MOP_TIE) { LOL_KEEP_BRANCH(); if (x < best || (x == best && best_id > id)) { best = x; best_id = id; } }
-				}
-				if (hdr & MOPB_CULL_NEXT) {
-					LOL_KEEP_BRANCH();
-					rec += MOP_DWORDS;                              /* the constants record is consumed either way */
-					left--;
-					if (cl == 0u) {
+					if (hdr & MOPB_CULL_NEXT) {                             /* the run of all bounded objects: the test that cools down */
 						LOL_KEEP_BRANCH();
-						const float cx = p.x - F(2), cy = p.y - F(3), cz = p.z - F(4);
-						const float l2 = (cx * cx + cy * cy) + cz * cz;
-						const float u = (best + F(5)) * CULL_K;
-						const bool skip = l2 > u * u && u > 0.f;
-						if (__ballot(care && !skip) == 0) {
+						rec += MOP_DWORDS;                                  /* the constants record is consumed either way */
+						left--;
+						if (cl == 0u) {
 							LOL_KEEP_BRANCH();
-							const u32 k = rec[1];
-							rec += k * MOP_DWORDS;
-							left -= k;
+							const float cx = p.x - F(2), cy = p.y - F(3), cz = p.z - F(4);
+							const float l2 = (cx * cx + cy * cy) + cz * cz;
+							const float u = (best + F(5)) * CULL_K;
+							const bool skip = l2 > u * u && u > 0.f;
+							if (__ballot(care && !skip) == 0) {
+								LOL_KEEP_BRANCH();
+								const u32 k = rec[1];                       /* to the last record: nothing follows that run */
+								rec += k * MOP_DWORDS;
+								left -= k;
+							}
+							if (__ballot(care && !skip) != 0) { LOL_KEEP_BRANCH(); cl = CULL_COOLDOWN + 1u; }
 						}
-						if (__ballot(care && !skip) != 0) { LOL_KEEP_BRANCH(); cl = CULL_COOLDOWN + 1u; }
+						cl = cl ? cl - 1u : 0u;
 					}
-					cl = cl ? cl - 1u : 0u;
+					if (hdr & MOPB_CULL_CHAIN) {
+						LOL_KEEP_BRANCH();
+						u32 more = left > 1u;                               /* 1: the test above has just jumped to the last record */
+						while (more) {                                      /* wave-uniform: one turn per test record met */
+							LOL_KEEP_BRANCH();
+							rec += MOP_DWORDS;
+							left--;
+							const u32 ch = rec[0];
+							more = ch & CULLC_NEXT;
+							const float cx = p.x - F(2), cy = p.y - F(3), cz = p.z - F(4);
+							const float l2 = (cx * cx + cy * cy) + cz * cz;
+							const float u = (best + F(5)) * CULL_K;
+							const bool skip = l2 > u * u && u > 0.f;
+							if (__ballot(care && !skip) == 0) {
+								LOL_KEEP_BRANCH();
+								const u32 k = rec[1];
+								rec += k * MOP_DWORDS;
+								left -= k;
+								more = ch & CULLC_AFTER;
+							}
+						}
+					}
 				}
 			}
 			acc = x;

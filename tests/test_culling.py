@@ -132,3 +132,74 @@ def test_ties_go_to_the_first_object_after_reordering():
         got = list(zip(d_dist.cpu().tolist(), d_id.cpu().tolist()))
         assert got == want, (cull, mode, got, want)
         r.close()
+
+
+def _field_scene(n, seed):
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import flat_scene_ab
+    return flat_scene_ab.field_scene(n, seed)
+
+
+def test_many_objects_are_grouped_into_nested_clusters(tmp_path, monkeypatch):
+    """A field of 64 objects: the generated SDF holds one test per k-d node (nested braces), and with
+    LOL_GPU_CULL_CLUSTERS=0 only the one run of all bounded objects plus the heavy objects' own tests."""
+    sc = _field_scene(64, 5)
+    gpu.compile_offline(sc.flatten(), str(tmp_path / "kd"))
+    kd = open(str(tmp_path / "kd.hip")).read()
+    monkeypatch.setenv("LOL_GPU_CULL_CLUSTERS", "0")
+    gpu.compile_offline(sc.flatten(), str(tmp_path / "flat"))
+    flat = open(str(tmp_path / "flat.hip")).read()
+    assert kd.count("__ballot(") > flat.count("__ballot(") > 1
+    assert kd.count("cool[0] = ") == flat.count("cool[0] = ") == 1      # only the outermost run cools down
+    # every object is still evaluated exactly once
+    import re
+    for src in (kd, flat):
+        assert len(re.findall(r"best_id = \d+u; }", src)) == 65 * src.count("void eval(")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("clusters", ["0", "3", "5"], ids=["one-run", "leaf3", "leaf5"])
+def test_fields_of_many_objects_match_the_oracle(monkeypatch, clusters):
+    """10 … 120 separate objects (spheres, rounded boxes, small smooth unions) over a plane: every pixel against the
+    oracle, for each shape of the culling plan, specialised kernel and interpreter (which carries the same tests)."""
+    import torch
+    from test_gpu_parity import check_against_oracle, gpu_render
+    monkeypatch.setenv("LOL_GPU_CULL_CLUSTERS", clusters)
+    for n, seed, w, h in ((10, 1, 64, 40), (40, 2, 56, 32), (120, 3, 48, 28)):
+        sc = _field_scene(n, seed)
+        for mode in (1, 4):
+            r = gpu.Renderer(0, specialize=mode)
+            g = gpu_render(torch, r, sc, w, h)
+            assert r.kernel_name() == KERNELS[mode]
+            check_against_oracle(g, sc, w, h)
+            r.close()
+
+
+@pytest.mark.gpu
+def test_clustered_sdf_matches_the_oracle_at_points():
+    """lol_gpu_sdf_batch over points scattered through a 150-object field, culling on (clusters) vs the oracle's SDF:
+    distance bits and object id at every point — ids are where a wrong tie or a wrong skip would show."""
+    import torch
+    sc = _field_scene(150, 9)
+    rng = np.random.default_rng(4)
+    pts = (rng.uniform(-1, 1, size=(4096, 3)) * [14, 3, 14] + [0, 1, -14]).astype(np.float32)
+    l = O.lib()
+    want_d = np.zeros(len(pts), dtype=np.float32)
+    want_id = np.zeros(len(pts), dtype=np.int32)
+    for i, p in enumerate(pts):
+        oid = C.c_uint32()
+        want_d[i] = l.lol_oracle_sdf(sc.ptr, float(p[0]), float(p[1]), float(p[2]), C.byref(oid))
+        want_id[i] = oid.value
+    for mode in (1, 4):
+        r = gpu.Renderer(0, specialize=mode)
+        r.prepare(sc)
+        d_pts = torch.from_numpy(pts.copy()).cuda()
+        d_dist = torch.zeros(len(pts), dtype=torch.float32, device="cuda")
+        d_id = torch.zeros(len(pts), dtype=torch.int32, device="cuda")
+        r.sdf_batch(d_pts.data_ptr(), d_dist.data_ptr(), d_id.data_ptr(), len(pts), stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_dist.cpu().numpy().view(np.uint32), want_d.view(np.uint32)), mode
+        assert np.array_equal(d_id.cpu().numpy(), want_id), mode
+        r.close()

@@ -36,8 +36,9 @@ def stress_scene(rng):
         comps.append("point_light { point = %s, diffuse_intensity = (2,2,2), specular_intensity = (1,1,1) }" % F.fmt(rng.normal(size=3) * 8 * scale + [0, 9 * scale, 0]))
     order = [0, 1] if rng.random() < 0.5 else [1, 0]
     objs = []
-    for _ in range(int(rng.integers(1, 9))):
-        o = tree(int(rng.integers(0, 4)))
+    crowd = rng.random() < 0.25                      # many shallow objects: the k-d clusters of the culling plan
+    for _ in range(int(rng.integers(10, 60)) if crowd else int(rng.integers(1, 9))):
+        o = tree(int(rng.integers(0, 2 if crowd else 4)))
         head, rest = o.split("{", 1)
         objs.append("%s{ material = #1,%s" % (head, rest))
     if rng.random() < 0.7:
