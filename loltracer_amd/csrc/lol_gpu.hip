@@ -177,12 +177,26 @@ __global__ __launch_bounds__(VERIFY_THREADS) void verify_sqrt_kernel(unsigned lo
 	if (n) atomicAdd(bad, (unsigned long long)n);
 }
 
-__global__ __launch_bounds__(VERIFY_THREADS) void verify_div_kernel(float k, float k2, float hrk, unsigned long long* bad) {
+/* smooth_sat_threshold: the |dlt| from which sminf_fastdiv_sat treats the blend factor as saturated: k(1 + 2^-20),
+ * rounded up (so >= k(1 + 2^-21) whatever the rounding); 0 for k <= 0 or non-finite (no shortcut). */
+float smooth_sat_threshold(float k) {
+	if (!(k > 0.f) || !std::isfinite(k)) return 0.f;
+	const double want = (double)k * (1.0 + 0x1p-20);
+	float ks = (float)want;
+	if ((double)ks < want) ks = nextafterf(ks, INFINITY);
+	return std::isfinite(ks) ? ks : 0.f;
+}
+
+__global__ __launch_bounds__(VERIFY_THREADS) void verify_div_kernel(float k, float k2, float hrk, float ks, unsigned long long* bad) {
 	uint32_t base = blockIdx.x * VERIFY_THREADS + threadIdx.x;
 	unsigned n = 0;
 	for (uint32_t it = 0; it < VERIFY_ITERS; it++) {
 		float x = __builtin_bit_cast(float, base + it * (VERIFY_BLOCKS * VERIFY_THREADS));
-		if (!same_float(lol::smin_h_fast(x, k2, hrk), lol::smin_h_exact(x, k))) n++;
+		const float h = lol::smin_h_exact(x, k);
+		if (!same_float(lol::smin_h_fast(x, k2, hrk), h)) n++;
+		/* what sminf_fastdiv_sat relies on (ks > 0 only): saturated inputs have h == 1 / h == +0 exactly */
+		if (ks > 0.f && x >= ks && __builtin_bit_cast(uint32_t, h) != 0x3f800000u) n++;
+		if (ks > 0.f && x <= -ks && __builtin_bit_cast(uint32_t, h) != 0u) n++;
 	}
 	if (n) atomicAdd(bad, (unsigned long long)n);
 }
@@ -202,7 +216,8 @@ unsigned long long run_verify(lol_gpu* ctx, int sqrt_kind, float k) {
 	if (sqrt_kind == 3) hipLaunchKernelGGL(verify_sqrt_kernel<3>, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, ctx->d_bad);
 	else if (sqrt_kind == 2) hipLaunchKernelGGL(verify_sqrt_kernel<2>, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, ctx->d_bad);
 	else if (sqrt_kind == 1) hipLaunchKernelGGL(verify_sqrt_kernel<1>, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, ctx->d_bad);
-	else hipLaunchKernelGGL(verify_div_kernel, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, k, 2.0f * k, 0.5f * (1.0f / k), ctx->d_bad);
+	else hipLaunchKernelGGL(verify_div_kernel, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, k, 2.0f * k, 0.5f * (1.0f / k),
+	                        smooth_sat_threshold(k), ctx->d_bad);
 	if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return ~0ull;
 	if (hipMemcpy(&bad, ctx->d_bad, sizeof bad, hipMemcpyDeviceToHost) != hipSuccess) return ~0ull;
 	return bad;
@@ -550,6 +565,8 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 	 * test only ever permits a skip — so this changes no result.  `cool` lives in the Sdf struct, wave-uniform. */
 	int cooldown = 3;
 	if (const char* e = getenv("LOL_GPU_CULL_COOLDOWN")) cooldown = atoi(e);
+	/* LOL_GPU_SMIN_SAT=0: smooth minima without the per-wave saturation shortcut (sminf_fastdiv_sat), for A/B runs */
+	const bool smin_sat = !(getenv("LOL_GPU_SMIN_SAT") && atoi(getenv("LOL_GPU_SMIN_SAT")) == 0);
 	auto open_test = [&](const CullTest& ct, bool with_cooldown) {
 		const int k = n_tests++;
 		if (with_cooldown)
@@ -608,7 +625,11 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 				int top = stack.back(); stack.pop_back();
 				int under = stack.back(); stack.pop_back();
 				int a = o.op == LOL_OP_SMIN ? under : top, b = o.op == LOL_OP_SMIN ? top : under;
-				if (fast && fast->has(o.f[0]))
+				const float ks = smin_sat ? smooth_sat_threshold(o.f[0]) : 0.f;
+				if (fast && fast->has(o.f[0]) && ks > 0.f)
+					snprintf(line, sizeof line, "\t\tconst float t%d = sminf_fastdiv_sat(t%d, t%d, %s, %s, %s, %s, care);\n", t, a, b,
+					         fbits(o.f[0]).c_str(), fbits(2.0f * o.f[0]).c_str(), fbits(0.5f * (1.0f / o.f[0])).c_str(), fbits(ks).c_str());
+				else if (fast && fast->has(o.f[0]))
 					snprintf(line, sizeof line, "\t\tconst float t%d = sminf_fastdiv(t%d, t%d, %s, %s, %s);\n", t, a, b,
 					         fbits(o.f[0]).c_str(), fbits(2.0f * o.f[0]).c_str(), fbits(0.5f * (1.0f / o.f[0])).c_str());
 				else
