@@ -25,6 +25,7 @@
 #include <unistd.h>
 #include <algorithm>
 #include <cmath>
+#include <functional>
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
@@ -567,6 +568,13 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 	if (const char* e = getenv("LOL_GPU_CULL_COOLDOWN")) cooldown = atoi(e);
 	/* LOL_GPU_SMIN_SAT=0: smooth minima without the per-wave saturation shortcut (sminf_fastdiv_sat), for A/B runs */
 	const bool smin_sat = !(getenv("LOL_GPU_SMIN_SAT") && atoi(getenv("LOL_GPU_SMIN_SAT")) == 0);
+	/* LOL_GPU_SAT_CULL_MIN_PRIMS: `a` operands of a smooth union with at least this many primitives get a saturation-
+	 * culling test (see emit_node below); 0 = none.  Measured (tools/tree_scene_ab.py, balanced trees of spheres at
+	 * 1080p, profiles/r2_tree_scene_ab.jsonl): the 17-instruction test pays from a few dozen primitives — 128 spheres
+	 * 232 -> 405 Mpixels/s, 256 spheres 127 -> 166 at 32 (375 / 157 at 16); with a test on every operand scene4
+	 * loses 14 %, a 32-sphere tree 30 %. */
+	int sat_cull_min_prims = 32;
+	if (const char* e = getenv("LOL_GPU_SAT_CULL_MIN_PRIMS")) sat_cull_min_prims = atoi(e);
 	auto open_test = [&](const CullTest& ct, bool with_cooldown) {
 		const int k = n_tests++;
 		if (with_cooldown)
@@ -603,43 +611,114 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 			open_test(plan.intervals[next_iv].test, next_iv == 0);
 			next_iv++;
 		}
-		std::vector<int> stack;
-		for (uint32_t i = R.first; i < R.top; i++) {
-			const lol_op& o = P.ops[i];
+		/* the object's expression tree from its post-order ops (child `a` / `b` = the operands of sminf(a, b, k)) */
+		struct Node { uint32_t op; int a, b; Sphere bound; uint32_t prims; };
+		std::vector<Node> nodes;
+		{
+			std::vector<int> st;
+			auto sane = [](double v) { return v - v == 0.0 && fabs(v) < 1e15; };
+			for (uint32_t i = R.first; i < R.top; i++) {
+				const lol_op& o = P.ops[i];
+				Node n{ i, -1, -1, { false, { 0, 0, 0 }, 0 }, 1 };
+				if (o.op == LOL_OP_SPHERE) {
+					n.bound = { sane(o.f[0]) && sane(o.f[1]) && sane(o.f[2]) && sane(o.f[3]), { o.f[0], o.f[1], o.f[2] }, o.f[3] > 0 ? (double)o.f[3] : 0.0 };
+				} else if (o.op == LOL_OP_RBOX) {
+					bool ok = true;
+					for (int j = 0; j < 7; j++) ok = ok && sane(o.f[j]);
+					ok = ok && o.f[3] >= 0 && o.f[4] >= 0 && o.f[5] >= 0 && o.f[6] >= 0;
+					const double hb = sqrt((double)o.f[3] * o.f[3] + (double)o.f[4] * o.f[4] + (double)o.f[5] * o.f[5]);
+					n.bound = { ok, { o.f[0], o.f[1], o.f[2] }, hb * (1.0 + 1e-12) + o.f[6] };
+				} else if (o.op == LOL_OP_SMIN || o.op == LOL_OP_SMIN_R) {
+					const int top = st.back(); st.pop_back();
+					const int under = st.back(); st.pop_back();
+					n.a = o.op == LOL_OP_SMIN ? under : top;
+					n.b = o.op == LOL_OP_SMIN ? top : under;
+					n.bound = enclose(nodes[n.a].bound, nodes[n.b].bound);
+					if (!(sane(o.f[0]) && o.f[0] > 0)) n.bound.ok = false;
+					n.bound.r += 0.25 * (double)o.f[0];
+					if (!sane(n.bound.r)) n.bound.ok = false;
+					n.prims = nodes[n.a].prims + nodes[n.b].prims;
+				}
+				st.push_back((int)nodes.size());
+				nodes.push_back(n);
+			}
+		}
+		/* Saturation culling inside a smooth union (fast struct only, proven k > 0): sminf(a, b, k) is EXACTLY
+		 * b - dlt*0.f = b + 0.f when dlt = b - a <= -ks (sminf_fastdiv_sat), so operand `a` need not be evaluated
+		 * where it is provably that much greater than b.  b is evaluated first; with sb = fl(b + ks) the bounding-
+		 * sphere test of the top-level culling (best := sb) gives a > sb for the binary32 value of `a`, hence
+		 * dlt = fl(b - a) <= fl(b - sb) =: sw by the monotonicity of rounding, and sw <= -ks is checked directly;
+		 * |p - C|^2 < 2^120 keeps every primitive of `a` (all within R < 10^15 of C) finite, so dlt is finite and
+		 * dlt*0.f = -0.  A NaN or infinite b fails the comparisons.  Per wave, like every other skip. */
+		std::function<int(int)> emit_node = [&](int ni) -> int {
+			const Node& n = nodes[ni];
+			const lol_op& o = P.ops[n.op];
 			switch (o.op) {
 			case LOL_OP_SPHERE:
 				snprintf(line, sizeof line, "\t\tconst float t%d = sd_sphere%s(p, %s, %s, %s, %s%s);\n", t, fs,
 				         fbits(o.f[0]).c_str(), fbits(o.f[1]).c_str(), fbits(o.f[2]).c_str(), fbits(o.f[3]).c_str(),
 				         fsqrt ? ", rg" : "");
-				s += line; stack.push_back(t++); break;
+				s += line; return t++;
 			case LOL_OP_RBOX:
 				snprintf(line, sizeof line, "\t\tconst float t%d = sd_round_box%s(p, %s, %s, %s, %s, %s, %s, %s%s);\n", t,
 				         fs,
 				         fbits(o.f[0]).c_str(), fbits(o.f[1]).c_str(), fbits(o.f[2]).c_str(), fbits(o.f[3]).c_str(),
 				         fbits(o.f[4]).c_str(), fbits(o.f[5]).c_str(), fbits(o.f[6]).c_str(), fsqrt ? ", rg" : "");
-				s += line; stack.push_back(t++); break;
+				s += line; return t++;
 			case LOL_OP_PLANE:
 				snprintf(line, sizeof line, "\t\tconst float t%d = p.y - %s;\n", t, fbits(o.f[0]).c_str());
-				s += line; stack.push_back(t++); break;
-			case LOL_OP_SMIN: case LOL_OP_SMIN_R: {
-				int top = stack.back(); stack.pop_back();
-				int under = stack.back(); stack.pop_back();
-				int a = o.op == LOL_OP_SMIN ? under : top, b = o.op == LOL_OP_SMIN ? top : under;
-				const float ks = smin_sat ? smooth_sat_threshold(o.f[0]) : 0.f;
-				if (fast && fast->has(o.f[0]) && ks > 0.f)
-					snprintf(line, sizeof line, "\t\tconst float t%d = sminf_fastdiv_sat(t%d, t%d, %s, %s, %s, %s, care);\n", t, a, b,
-					         fbits(o.f[0]).c_str(), fbits(2.0f * o.f[0]).c_str(), fbits(0.5f * (1.0f / o.f[0])).c_str(), fbits(ks).c_str());
-				else if (fast && fast->has(o.f[0]))
-					snprintf(line, sizeof line, "\t\tconst float t%d = sminf_fastdiv(t%d, t%d, %s, %s, %s);\n", t, a, b,
-					         fbits(o.f[0]).c_str(), fbits(2.0f * o.f[0]).c_str(), fbits(0.5f * (1.0f / o.f[0])).c_str());
-				else
-					snprintf(line, sizeof line, "\t\tconst float t%d = sminf_(t%d, t%d, %s);\n", t, a, b, fbits(o.f[0]).c_str());
-				s += line; stack.push_back(t++); break;
-			}
+				s += line; return t++;
 			default: break;
 			}
-		}
-		const int d = stack.back();
+			/* LOL_OP_SMIN / LOL_OP_SMIN_R */
+			const float ks = smooth_sat_threshold(o.f[0]);
+			const bool proven = fast && fast->has(o.f[0]);
+			/* the arithmetic shortcut only where the SDF is inlined: in the out-of-line function its four-way branching
+			 * costs more than it saves (504-op chain: 100 -> 42 Mpixels/s) */
+			const bool sat_arith = smin_sat && !out_of_line && ks > 0.f;
+			const std::string kk = fbits(o.f[0]), k2 = fbits(2.0f * o.f[0]), hrk = fbits(0.5f * (1.0f / o.f[0])), kss = fbits(ks);
+			if (proven && ks > 0.f && sat_cull_min_prims > 0 && nodes[n.a].bound.ok && nodes[n.a].prims >= (uint32_t)sat_cull_min_prims) {
+				const int b = emit_node(n.b);
+				const CullTest ct = make_test(nodes[n.a].bound);
+				const int r = t++, q = n_tests++;
+				snprintf(line, sizeof line,
+				         "\t\tfloat t%d;\n"
+				         "\t\t{ const float sb%d = t%d + %s, sw%d = t%d - sb%d;\n"
+				         "\t\t  const float sx%d = p.x - %s, sy%d = p.y - %s, sz%d = p.z - %s;\n"
+				         "\t\t  const float sl%d = (sx%d * sx%d + sy%d * sy%d) + sz%d * sz%d;\n"
+				         "\t\t  const float su%d = (sb%d + %s) * %s;\n"
+				         "\t\t  const bool ss%d = sl%d > su%d * su%d && su%d > 0.f && sw%d <= -%s && sl%d < 0x1p120f;\n"
+				         "\t\t  if (__ballot(care && !ss%d) != 0) {\n",
+				         r, q, b, kss.c_str(), q, b, q,
+				         q, fbits(ct.c[0]).c_str(), q, fbits(ct.c[1]).c_str(), q, fbits(ct.c[2]).c_str(),
+				         q, q, q, q, q, q, q,
+				         q, q, fbits(ct.rm).c_str(), fbits(1.0f + 0x1p-12f).c_str(),
+				         q, q, q, q, q, q, kss.c_str(), q, q);
+				s += line;
+				const int a = emit_node(n.a);
+				if (sat_arith)
+					snprintf(line, sizeof line, "\t\t  t%d = sminf_fastdiv_sat(t%d, t%d, %s, %s, %s, %s, care);\n\t\t  } else t%d = t%d + 0.f;\n\t\t}\n",
+					         r, a, b, kk.c_str(), k2.c_str(), hrk.c_str(), kss.c_str(), r, b);
+				else
+					snprintf(line, sizeof line, "\t\t  t%d = sminf_fastdiv(t%d, t%d, %s, %s, %s);\n\t\t  } else t%d = t%d + 0.f;\n\t\t}\n",
+					         r, a, b, kk.c_str(), k2.c_str(), hrk.c_str(), r, b);
+				s += line;
+				return r;
+			}
+			/* operands in program order (a flattened chain keeps its deep operand first and its operand stack shallow) */
+			const bool a_first = o.op == LOL_OP_SMIN;
+			const int first = emit_node(a_first ? n.a : n.b), second = emit_node(a_first ? n.b : n.a);
+			const int a = a_first ? first : second, b = a_first ? second : first;
+			if (proven && sat_arith)
+				snprintf(line, sizeof line, "\t\tconst float t%d = sminf_fastdiv_sat(t%d, t%d, %s, %s, %s, %s, care);\n", t, a, b,
+				         kk.c_str(), k2.c_str(), hrk.c_str(), kss.c_str());
+			else if (proven)
+				snprintf(line, sizeof line, "\t\tconst float t%d = sminf_fastdiv(t%d, t%d, %s, %s, %s);\n", t, a, b, kk.c_str(), k2.c_str(), hrk.c_str());
+			else
+				snprintf(line, sizeof line, "\t\tconst float t%d = sminf_(t%d, t%d, %s);\n", t, a, b, kk.c_str());
+			s += line; return t++;
+		};
+		const int d = emit_node((int)nodes.size() - 1);
 		if (R.id < max_id_seen)      /* evaluated after an object that follows it in the file: ties go to the lower id */
 			snprintf(line, sizeof line, "\t\tif (t%d < best || (t%d == best && best_id > %uu)) { best = t%d; best_id = %uu; }\n", d, d, R.id, d, R.id);
 		else

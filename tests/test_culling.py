@@ -203,3 +203,81 @@ def test_clustered_sdf_matches_the_oracle_at_points():
         assert np.array_equal(d_dist.cpu().numpy().view(np.uint32), want_d.view(np.uint32)), mode
         assert np.array_equal(d_id.cpu().numpy(), want_id), mode
         r.close()
+
+
+def _tree_scene(depth, smooth=0.5):
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import tree_scene_ab
+    return tree_scene_ab.tree_scene(depth, smooth)
+
+
+def test_big_operands_of_a_smooth_union_get_a_saturation_test(tmp_path, monkeypatch):
+    """A balanced union tree of 64 spheres: operands `a` of >= 32 primitives (LOL_GPU_SAT_CULL_MIN_PRIMS moves the
+    threshold, 0 removes the tests) are evaluated behind a test of their own bounding sphere against b + ks — in the
+    fast struct only."""
+    sc = _tree_scene(6)
+
+    def tests_in(src):
+        fast = src[src.index("struct SpecSdfFast"):]
+        return fast.count("+ 0.f;")
+    gpu.compile_offline(sc.flatten(), str(tmp_path / "d"), assume_fast=True)
+    src = open(str(tmp_path / "d.hip")).read()
+    assert tests_in(src) == 1                       # the root's `a` (32 spheres)
+    exact = src[src.index("struct SpecSdfExact"):src.index("struct SpecSdfFast")]
+    assert "+ 0.f;" not in exact and "sminf_fastdiv" not in exact
+    monkeypatch.setenv("LOL_GPU_SAT_CULL_MIN_PRIMS", "16")
+    gpu.compile_offline(sc.flatten(), str(tmp_path / "s"), assume_fast=True)
+    assert tests_in(open(str(tmp_path / "s.hip")).read()) == 3      # + the `a` of both 32-sphere halves
+    monkeypatch.setenv("LOL_GPU_SAT_CULL_MIN_PRIMS", "1")
+    gpu.compile_offline(sc.flatten(), str(tmp_path / "a"), assume_fast=True)
+    assert tests_in(open(str(tmp_path / "a.hip")).read()) == 63
+    monkeypatch.setenv("LOL_GPU_SAT_CULL_MIN_PRIMS", "0")
+    gpu.compile_offline(sc.flatten(), str(tmp_path / "n"), assume_fast=True)
+    assert tests_in(open(str(tmp_path / "n.hip")).read()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("min_prims", ["1", "4", "32", "0"])
+def test_saturation_culling_changes_nothing(monkeypatch, min_prims):
+    """Union trees (32 / 128 spheres, smoothness 0.5 and 2), random nested scenes and scene4 with a saturation test on
+    every operand that may have one / from 4 / from 32 primitives (default) / none: every pixel, distance, id and step count
+    against the oracle; lol_gpu_sdf_batch at scattered points too."""
+    import torch
+    import test_gpu_fuzz as F
+    from test_gpu_parity import check_against_oracle, gpu_render
+    monkeypatch.setenv("LOL_GPU_SAT_CULL_MIN_PRIMS", min_prims)
+    r = gpu.Renderer(0)
+    for depth, smooth, w, h in ((5, 0.5, 64, 36), (7, 0.5, 40, 24), (5, 2.0, 48, 28)):
+        sc = _tree_scene(depth, smooth)
+        g = gpu_render(torch, r, sc, w, h)
+        assert r.kernel_name() == "lol_render_spec"
+        check_against_oracle(g, sc, w, h)
+    rng = np.random.default_rng(77)
+    for _ in range(10):
+        sc = S.Scene.parse_string(F.rand_scene(rng))
+        w, h = int(rng.integers(17, 60)), int(rng.integers(9, 36))
+        check_against_oracle(gpu_render(torch, r, sc, w, h), sc, w, h)
+    # the SDF alone, far from and inside the tree, incl. non-finite points
+    sc = _tree_scene(6)
+    pts = (rng.uniform(-1, 1, size=(2048, 3)) * [14, 6, 12] + [0, 1, -9]).astype(np.float32)
+    pts[:4] = [[np.inf, 0, 0], [np.nan, 1, 1], [1e30, -1e30, 0], [0, 3e38, 0]]
+    l = O.lib()
+    want_d = np.zeros(len(pts), dtype=np.float32)
+    want_id = np.zeros(len(pts), dtype=np.int32)
+    for i, p in enumerate(pts):
+        oid = C.c_uint32()
+        want_d[i] = l.lol_oracle_sdf(sc.ptr, float(p[0]), float(p[1]), float(p[2]), C.byref(oid))
+        want_id[i] = oid.value
+    r.prepare(sc)
+    d_pts = torch.from_numpy(pts.copy()).cuda()
+    d_dist = torch.zeros(len(pts), dtype=torch.float32, device="cuda")
+    d_id = torch.zeros(len(pts), dtype=torch.int32, device="cuda")
+    r.sdf_batch(d_pts.data_ptr(), d_dist.data_ptr(), d_id.data_ptr(), len(pts), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = d_dist.cpu().numpy()
+    both_nan = np.isnan(got) & np.isnan(want_d)
+    assert np.array_equal(got.view(np.uint32)[~both_nan], want_d.view(np.uint32)[~both_nan])
+    assert np.array_equal(d_id.cpu().numpy(), want_id)
+    r.close()
