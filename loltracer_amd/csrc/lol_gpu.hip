@@ -265,23 +265,26 @@ struct FastPaths {
  * equal distance wins — is kept by comparing ids on ties wherever an object is evaluated after one that follows
  * it in the file:  t < best || (t == best && best_id > id)   (best_id = 0 only while best = +inf, where the
  * reference's inf < inf is false too). */
+struct Sphere { bool ok; double c[3], r; uint32_t levels = 1; };   /* levels: nesting depth of the operations under it (a primitive is 1) */
+
 struct RootBound {
 	uint32_t first = 0, top = 0;        /* ops [first, top) compute the object, ops[top] is its LOL_OP_TOP */
 	uint32_t id = 0, prims = 0;
 	bool     bounded = false;
 	double   c[3] = { 0, 0, 0 }, r = 0;
+	uint32_t levels = 1;                /* nesting depth of its expression (sets the rounding slack of its test) */
+	Sphere   sphere() const { return { bounded, { c[0], c[1], c[2] }, r, levels }; }
 };
 
-struct Sphere { bool ok; double c[3], r; };
-
 Sphere enclose(const Sphere& a, const Sphere& b) {
-	if (!a.ok || !b.ok) return { false, { 0, 0, 0 }, 0 };
+	const uint32_t levels = a.levels > b.levels ? a.levels : b.levels;
+	if (!a.ok || !b.ok) return { false, { 0, 0, 0 }, 0, levels };
 	const double dx = b.c[0] - a.c[0], dy = b.c[1] - a.c[1], dz = b.c[2] - a.c[2];
 	const double d = sqrt(dx * dx + dy * dy + dz * dz);
-	if (d + b.r <= a.r) return a;
-	if (d + a.r <= b.r) return b;
+	if (d + b.r <= a.r) { Sphere r = a; r.levels = levels; return r; }
+	if (d + a.r <= b.r) { Sphere r = b; r.levels = levels; return r; }
 	const double R = 0.5 * (d + a.r + b.r), t = d > 0 ? (R - a.r) / d : 0.0;
-	return { true, { a.c[0] + dx * t, a.c[1] + dy * t, a.c[2] + dz * t }, R * (1.0 + 1e-12) };
+	return { true, { a.c[0] + dx * t, a.c[1] + dy * t, a.c[2] + dz * t }, R * (1.0 + 1e-12), levels };
 }
 
 std::vector<RootBound> analyse_roots(const lol_program& P) {
@@ -317,6 +320,7 @@ std::vector<RootBound> analyse_roots(const lol_program& P) {
 			Sphere u = enclose(a, b);
 			if (!(sane(o.f[0]) && o.f[0] > 0)) u.ok = false;
 			u.r += 0.25 * (double)o.f[0];
+			u.levels++;
 			st.push_back(u);
 			break;
 		}
@@ -324,7 +328,7 @@ std::vector<RootBound> analyse_roots(const lol_program& P) {
 			Sphere v = st.back(); st.pop_back();
 			cur.top = i; cur.id = o.id;
 			cur.bounded = v.ok && sane(v.r);
-			cur.c[0] = v.c[0]; cur.c[1] = v.c[1]; cur.c[2] = v.c[2]; cur.r = v.r;
+			cur.c[0] = v.c[0]; cur.c[1] = v.c[1]; cur.c[2] = v.c[2]; cur.r = v.r; cur.levels = v.levels;
 			roots.push_back(cur);
 			cur = RootBound();
 			cur.first = i + 1;
@@ -335,15 +339,26 @@ std::vector<RootBound> analyse_roots(const lol_program& P) {
 	return roots;
 }
 
-struct CullTest { float c[3]; float rm; };
+struct CullTest { float c[3]; float rm; float k; };     /* skip iff u = (best + rm)*k > 0 and |p - c|^2 > u^2 */
 
-/* the in-kernel test's constants from a double-precision bound: centre rounded to binary32, radius inflated
- * (see the derivation above; the centre's rounding error is covered by the |C| 2^-20 term) */
+/* The in-kernel test's constants from a double-precision bound: centre rounded to binary32 (its rounding error is
+ * covered by the |C| 2^-20 term), radius and comparison inflated by the rounding the guarded expression can
+ * accumulate.  With D = |p-C|: the exact-arithmetic value is >= D - R; one smooth minimum evaluated in binary32 adds
+ * at most 2^-24 (4 M + 8.5 k) to the error of its operands (it is 1-Lipschitz in them), a primitive at most
+ * 2^-24 * 4 M, with M <= D + R and k <= 4 R — so the binary32 value is >= D(1 - e) - R(1 + e), e = 40 * 2^-24 * levels.
+ * The test gives D > (best + R')K(1 - 2^-21); with K >= 1 + 2e + 2^-19 and R' >= R(1 + 2(K-1) + 2e) that is
+ * > best in both signs of best (for best < 0 use |best| < R').  Shallow objects (levels <= 50) keep the constants
+ * of the first version, K = 1 + 2^-12 and R' = R(1 + 2^-10): a chain of 500 unions gets K = 1.0024. */
 CullTest make_test(const Sphere& b) {
 	CullTest t;
 	double cmax = 0;
 	for (int j = 0; j < 3; j++) { t.c[j] = (float)b.c[j]; cmax = fmax(cmax, fabs(b.c[j])); }
-	const double rm = b.r * (1.0 + 0x1p-10) + (cmax + 1.0) * 0x1p-20;
+	const double e = 40.0 * 0x1p-24 * (double)b.levels;
+	const double K = 1.0 + fmax(0x1p-12, 2.0 * e + 0x1p-19);
+	t.k = (float)K;
+	if ((double)t.k < K) t.k = nextafterf(t.k, INFINITY);
+	const double rho = fmax(0x1p-10, 2.0 * ((double)t.k - 1.0) + 2.0 * e);
+	const double rm = b.r * (1.0 + rho) + (cmax + 1.0) * 0x1p-20;
 	t.rm = nextafterf((float)rm, INFINITY);
 	return t;
 }
@@ -374,11 +389,11 @@ bool culling_enabled(int want) {
 static void kd_build(const std::vector<RootBound>& roots, std::vector<uint32_t>& ids, size_t lo, size_t hi,
                      size_t base, bool has_predecessor, size_t leaf_max, uint32_t min_prims, CullPlan& plan) {
 	const size_t count = hi - lo;
-	Sphere g = { true, { roots[ids[lo]].c[0], roots[ids[lo]].c[1], roots[ids[lo]].c[2] }, roots[ids[lo]].r };
+	Sphere g = roots[ids[lo]].sphere();
 	uint32_t prims = roots[ids[lo]].prims;
 	for (size_t k = lo + 1; k < hi; k++) {
 		const RootBound& r = roots[ids[k]];
-		g = enclose(g, { true, { r.c[0], r.c[1], r.c[2] }, r.r });
+		g = enclose(g, r.sphere());
 		prims += r.prims;
 	}
 	/* a test needs a running minimum to compare with (something evaluated before the run); a node that covers
@@ -391,7 +406,7 @@ static void kd_build(const std::vector<RootBound>& roots, std::vector<uint32_t>&
 			for (size_t k = lo; k < hi; k++) {
 				const RootBound& r = roots[ids[k]];
 				if (r.prims >= min_prims && (has_predecessor || k > 0))
-					plan.intervals.push_back({ base + k, base + k + 1, make_test({ true, { r.c[0], r.c[1], r.c[2] }, r.r }) });
+					plan.intervals.push_back({ base + k, base + k + 1, make_test(r.sphere()) });
 			}
 		return;
 	}
@@ -489,6 +504,7 @@ std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast, co
 			c[0] = (n + 1 < begins[oi] ? lol::CULLC_NEXT : 0u) | (begins[iv.end] ? lol::CULLC_AFTER : 0u);
 			for (int j = 0; j < 3; j++) c[2 + j] = fbits32(iv.test.c[j]);
 			c[5] = fbits32(iv.test.rm);
+			c[6] = fbits32(iv.test.k);
 			at[next_iv] = out.size();
 			out.insert(out.end(), c, c + lol::MOP_DWORDS);
 		}
@@ -590,7 +606,7 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 			         "\t\t  } else cool[0]--;\n"
 			         "\t\t  if (need%d) {\n",
 			         k, k, fbits(ct.c[0]).c_str(), k, fbits(ct.c[1]).c_str(), k, fbits(ct.c[2]).c_str(),
-			         k, k, k, k, k, k, k, k, fbits(ct.rm).c_str(), fbits(1.0f + 0x1p-12f).c_str(), k, k, k, k, k,
+			         k, k, k, k, k, k, k, k, fbits(ct.rm).c_str(), fbits(ct.k).c_str(), k, k, k, k, k,
 			         k, k, k, cooldown, k);
 		else
 			snprintf(line, sizeof line,
@@ -600,7 +616,7 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 			         "\t\t  const bool skip%d = cl%d > cu%d * cu%d && cu%d > 0.f;\n"
 			         "\t\t  if (__ballot(care && !skip%d) != 0) {\n",
 			         k, fbits(ct.c[0]).c_str(), k, fbits(ct.c[1]).c_str(), k, fbits(ct.c[2]).c_str(),
-			         k, k, k, k, k, k, k, k, fbits(ct.rm).c_str(), fbits(1.0f + 0x1p-12f).c_str(), k, k, k, k, k, k);
+			         k, k, k, k, k, k, k, k, fbits(ct.rm).c_str(), fbits(ct.k).c_str(), k, k, k, k, k, k);
 		s += line;
 	};
 	uint32_t max_id_seen = 0;
@@ -619,15 +635,15 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 			auto sane = [](double v) { return v - v == 0.0 && fabs(v) < 1e15; };
 			for (uint32_t i = R.first; i < R.top; i++) {
 				const lol_op& o = P.ops[i];
-				Node n{ i, -1, -1, { false, { 0, 0, 0 }, 0 }, 1 };
+				Node n{ i, -1, -1, { false, { 0, 0, 0 }, 0, 1 }, 1 };
 				if (o.op == LOL_OP_SPHERE) {
-					n.bound = { sane(o.f[0]) && sane(o.f[1]) && sane(o.f[2]) && sane(o.f[3]), { o.f[0], o.f[1], o.f[2] }, o.f[3] > 0 ? (double)o.f[3] : 0.0 };
+					n.bound = { sane(o.f[0]) && sane(o.f[1]) && sane(o.f[2]) && sane(o.f[3]), { o.f[0], o.f[1], o.f[2] }, o.f[3] > 0 ? (double)o.f[3] : 0.0, 1 };
 				} else if (o.op == LOL_OP_RBOX) {
 					bool ok = true;
 					for (int j = 0; j < 7; j++) ok = ok && sane(o.f[j]);
 					ok = ok && o.f[3] >= 0 && o.f[4] >= 0 && o.f[5] >= 0 && o.f[6] >= 0;
 					const double hb = sqrt((double)o.f[3] * o.f[3] + (double)o.f[4] * o.f[4] + (double)o.f[5] * o.f[5]);
-					n.bound = { ok, { o.f[0], o.f[1], o.f[2] }, hb * (1.0 + 1e-12) + o.f[6] };
+					n.bound = { ok, { o.f[0], o.f[1], o.f[2] }, hb * (1.0 + 1e-12) + o.f[6], 1 };
 				} else if (o.op == LOL_OP_SMIN || o.op == LOL_OP_SMIN_R) {
 					const int top = st.back(); st.pop_back();
 					const int under = st.back(); st.pop_back();
@@ -636,6 +652,7 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 					n.bound = enclose(nodes[n.a].bound, nodes[n.b].bound);
 					if (!(sane(o.f[0]) && o.f[0] > 0)) n.bound.ok = false;
 					n.bound.r += 0.25 * (double)o.f[0];
+					n.bound.levels++;
 					if (!sane(n.bound.r)) n.bound.ok = false;
 					n.prims = nodes[n.a].prims + nodes[n.b].prims;
 				}
@@ -692,7 +709,7 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 				         r, q, b, kss.c_str(), q, b, q,
 				         q, fbits(ct.c[0]).c_str(), q, fbits(ct.c[1]).c_str(), q, fbits(ct.c[2]).c_str(),
 				         q, q, q, q, q, q, q,
-				         q, q, fbits(ct.rm).c_str(), fbits(1.0f + 0x1p-12f).c_str(),
+				         q, q, fbits(ct.rm).c_str(), fbits(ct.k).c_str(),
 				         q, q, q, q, q, q, kss.c_str(), q, q);
 				s += line;
 				const int a = emit_node(n.a);
@@ -1161,7 +1178,7 @@ int lol_gpu_cull_bounds(const lol_program* prog, uint32_t root, float c_out[3], 
 	if (root >= roots.size()) return LOL_GPU_ERR_ARG;
 	const RootBound& R = roots[root];
 	if (!R.bounded) return 0;
-	const CullTest t = make_test({ true, { R.c[0], R.c[1], R.c[2] }, R.r });
+	const CullTest t = make_test(R.sphere());
 	c_out[0] = t.c[0]; c_out[1] = t.c[1]; c_out[2] = t.c[2];
 	*r_out = t.rm;
 	return 1;

@@ -422,7 +422,7 @@ constexpr u32 MOPB_SMIN_EXACT = 8192u;  /* unproven k: sminf_ with the correctly
 /* Exact object culling (lol_gpu.hip, "exact culling") in the interpreter: a record that finishes a top-level object
  * (MOP_TOP) may carry MOPB_CULL_NEXT / MOPB_CULL_CHAIN — the NEXT record is then not a macro-op but a test's constants
  * {word 0 = CULLC_* flags, word 1 = how many records after it belong to the objects the test guards, f[2..4] = C,
- * f[5] = R'}; if every lane that cares may skip them, they are jumped over.  Runs nest (lol_gpu.hip, plan_culling):
+ * f[5] = R', f[6] = K}; if every lane that cares may skip them, they are jumped over.  Runs nest (lol_gpu.hip, plan_culling):
  * CULLC_NEXT says the record after this one is the test of a run nested in this one, CULLC_AFTER that the record
  * after the guarded ones is the test of the run that follows.  Lives in the rare TAIL branch, so ordinary records
  * pay nothing. */
@@ -430,7 +430,6 @@ constexpr u32 MOPB_CULL_NEXT = 16384u;    /* the test of the run of ALL bounded 
 constexpr u32 MOPB_CULL_CHAIN = 65536u;   /* one or more tests of inner runs follow (after the NEXT one, if both) */
 constexpr u32 CULLC_NEXT = 1u, CULLC_AFTER = 2u;
 constexpr u32 MOP_TIE = 32768u;         /* with MOP_TOP: evaluated after an object that follows it in the file → ties go to the lower id */
-constexpr float CULL_K = 1.0f + 0x1p-12f;
 constexpr u32 CULL_COOLDOWN = 3u;       /* after a test that did not allow the skip, this many evaluations do not test */
 __host__ __device__ constexpr u32 mop_smin_bits(u32 hdr) {
 	return !(hdr & MOPB_SMIN) ? 0u : !(hdr & MOP_FASTDIV) ? MOPB_SMIN_EXACT : (hdr & MOPB_X_IS_A) ? MOPB_SMIN_XF : MOPB_SMIN_AF;
@@ -525,7 +524,7 @@ struct Interp {
 							LOL_KEEP_BRANCH();
 							const float cx = p.x - F(2), cy = p.y - F(3), cz = p.z - F(4);
 							const float l2 = (cx * cx + cy * cy) + cz * cz;
-							const float u = (best + F(5)) * CULL_K;
+							const float u = (best + F(5)) * F(6);
 							const bool skip = l2 > u * u && u > 0.f;
 							if (__ballot(care && !skip) == 0) {
 								LOL_KEEP_BRANCH();
@@ -548,7 +547,7 @@ struct Interp {
 							more = ch & CULLC_NEXT;
 							const float cx = p.x - F(2), cy = p.y - F(3), cz = p.z - F(4);
 							const float l2 = (cx * cx + cy * cy) + cz * cz;
-							const float u = (best + F(5)) * CULL_K;
+							const float u = (best + F(5)) * F(6);
 							const bool skip = l2 > u * u && u > 0.f;
 							if (__ballot(care && !skip) == 0) {
 								LOL_KEEP_BRANCH();
