@@ -565,14 +565,14 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 		/* out of line the cool-down state is per call (always 0: every evaluation tests) */
 		/* (amdgpu_waves_per_eu applies to kernels only: the function is scheduled with the default register budget) */
 		(void)occupancy;
-		snprintf(line, sizeof line, "__device__ __noinline__ SdfOut %s_fn(float px, float py, float pz, u32 rg_lo, u32 rg_hi, bool care) {\n"
+		snprintf(line, sizeof line, "__device__ __noinline__ SdfOut %s_fn(float px, float py, float pz, u32 rg_lo, u32 rg_hi, u64 care) {\n"
 		         "\t\tconst V3 p = { px, py, pz };\n\t\tRange rg; rg.lo = rg_lo; rg.hi = rg_hi;\n\t\tfloat best; u32 best_id;\n\t%s",
 		         name, cool_decl);
 		s += line;
 	} else {
-		snprintf(line, sizeof line, "struct %s {\n\tRange rg;\n%s", name, cool_decl);
+		snprintf(line, sizeof line, "struct %s {\n\tstatic constexpr bool MASKS = true;\n\tRange rg;\n%s", name, cool_decl);
 		s += line;
-		s += "\t__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id, bool care = true) {\n";
+		s += "\t__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id, u64 care = ~0ull) {\n";
 	}
 	s += "\t\tbest = __builtin_inff(); best_id = 0u;\n";
 	int t = 0, n_tests = 0;
@@ -600,23 +600,21 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 			         "\t\t  const float cx%d = p.x - %s, cy%d = p.y - %s, cz%d = p.z - %s;\n"
 			         "\t\t  const float cl%d = (cx%d * cx%d + cy%d * cy%d) + cz%d * cz%d;\n"
 			         "\t\t  const float cu%d = (best + %s) * %s;\n"
-			         "\t\t  const bool skip%d = cl%d > cu%d * cu%d && cu%d > 0.f;\n"
-			         "\t\t  need%d = __ballot(care && !skip%d) != 0;\n"
+			         "\t\t  need%d = ((vote(!(cl%d > cu%d * cu%d)) | vote(!(cu%d > 0.f))) & care) != 0;\n"
 			         "\t\t  if (need%d) cool[0] = %du;\n"
 			         "\t\t  } else cool[0]--;\n"
 			         "\t\t  if (need%d) {\n",
 			         k, k, fbits(ct.c[0]).c_str(), k, fbits(ct.c[1]).c_str(), k, fbits(ct.c[2]).c_str(),
 			         k, k, k, k, k, k, k, k, fbits(ct.rm).c_str(), fbits(ct.k).c_str(), k, k, k, k, k,
-			         k, k, k, cooldown, k);
+			         k, cooldown, k);
 		else
 			snprintf(line, sizeof line,
 			         "\t\t{ const float cx%d = p.x - %s, cy%d = p.y - %s, cz%d = p.z - %s;\n"
 			         "\t\t  const float cl%d = (cx%d * cx%d + cy%d * cy%d) + cz%d * cz%d;\n"
 			         "\t\t  const float cu%d = (best + %s) * %s;\n"
-			         "\t\t  const bool skip%d = cl%d > cu%d * cu%d && cu%d > 0.f;\n"
-			         "\t\t  if (__ballot(care && !skip%d) != 0) {\n",
+			         "\t\t  if (((vote(!(cl%d > cu%d * cu%d)) | vote(!(cu%d > 0.f))) & care) != 0) {\n",
 			         k, fbits(ct.c[0]).c_str(), k, fbits(ct.c[1]).c_str(), k, fbits(ct.c[2]).c_str(),
-			         k, k, k, k, k, k, k, k, fbits(ct.rm).c_str(), fbits(ct.k).c_str(), k, k, k, k, k, k);
+			         k, k, k, k, k, k, k, k, fbits(ct.rm).c_str(), fbits(ct.k).c_str(), k, k, k, k);
 		s += line;
 	};
 	uint32_t max_id_seen = 0;
@@ -704,13 +702,12 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 				         "\t\t  const float sx%d = p.x - %s, sy%d = p.y - %s, sz%d = p.z - %s;\n"
 				         "\t\t  const float sl%d = (sx%d * sx%d + sy%d * sy%d) + sz%d * sz%d;\n"
 				         "\t\t  const float su%d = (sb%d + %s) * %s;\n"
-				         "\t\t  const bool ss%d = sl%d > su%d * su%d && su%d > 0.f && sw%d <= -%s && sl%d < 0x1p120f;\n"
-				         "\t\t  if (__ballot(care && !ss%d) != 0) {\n",
+				         "\t\t  if (((vote(!(sl%d > su%d * su%d)) | vote(!(su%d > 0.f)) | vote(!(sw%d <= -%s)) | vote(!(sl%d < 0x1p120f))) & care) != 0) {\n",
 				         r, q, b, kss.c_str(), q, b, q,
 				         q, fbits(ct.c[0]).c_str(), q, fbits(ct.c[1]).c_str(), q, fbits(ct.c[2]).c_str(),
 				         q, q, q, q, q, q, q,
 				         q, q, fbits(ct.rm).c_str(), fbits(ct.k).c_str(),
-				         q, q, q, q, q, q, kss.c_str(), q, q);
+				         q, q, q, q, q, kss.c_str(), q);
 				s += line;
 				const int a = emit_node(n.a);
 				if (sat_arith)
@@ -747,7 +744,7 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 	}
 	if (out_of_line) {
 		s += "\t\treturn { best, best_id, rg.lo, rg.hi };\n}\n";
-		snprintf(line, sizeof line, "struct %s {\n\tRange rg;\n\t__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id, bool care = true) {\n"
+		snprintf(line, sizeof line, "struct %s {\n\tstatic constexpr bool MASKS = true;\n\tRange rg;\n\t__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id, u64 care = ~0ull) {\n"
 		         "\t\tconst SdfOut o = %s_fn(p.x, p.y, p.z, rg.lo, rg.hi, care);\n"
 		         "\t\tbest = o.best; best_id = o.id; rg.lo = o.lo; rg.hi = o.hi;\n\t}\n};\n", name, name);
 		s += line;
@@ -804,7 +801,7 @@ std::string generate_source(const lol_program& P, const FastPaths* fast, bool cu
 	if (any_fast) {
 		s += "\tlol::SpecSdfFast fast;\n";
 		s += "\tlol::Pixel P = lol::shade_pixel(L, fast, lds);\n";
-		s += "\tif (__ballot(fast.rg.outside()) != 0) {\n";
+		s += "\tif (lol::vote(fast.rg.outside()) != 0) {\n";
 		s += "\t\tlol::SpecSdfExact exact;\n";
 		s += "\t\tP = lol::shade_pixel(L, exact, lds);\n";
 		s += "\t}\n";

@@ -22,7 +22,7 @@
  *
  * Shape of the code on a 64-wide wavefront:
  *  - control flow is wave-uniform: the march / shadow loops run while
- *    __ballot(alive) != 0 and lanes that have hit or escaped keep their state
+ *    vote(alive) != 0 and lanes that have hit or escaped keep their state
  *    by predication;
  *  - lights and materials are staged once per block into LDS and read back
  *    with wave-uniform (lights) or per-lane (material of the hit) addresses;
@@ -96,6 +96,14 @@ struct Launch {
 struct V3 { float x, y, z; };
 
 /* ---- float.h / vec.h semantics (see oracle/lol_oracle.c for the citations) ---- */
+/* Wave vote.  The compiler turns a vote on a COMPARISON into that comparison writing its lane mask to an SGPR pair,
+ * but a vote on anything else — `a && b`, a bool carried around a loop — is first materialised as 0 / 1 in a VGPR
+ * (v_cndmask) and compared again (v_cmp_ne): two half-rate instructions and a hazard nop per vote, and this pipeline
+ * votes six times per SDF evaluation.  So votes are only ever taken on single comparisons and combined as masks on
+ * the scalar side: "which lanes still care" travels as a mask (`care`), not as a per-lane bool. */
+typedef unsigned long long u64;
+__device__ __forceinline__ u64 vote(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 __device__ __forceinline__ float minf_(float a, float b) { return a < b ? a : b; }   /* MINSS: b on NaN/equal */
 __device__ __forceinline__ float maxf_(float a, float b) { return a > b ? a : b; }   /* MAXSS */
 __device__ __forceinline__ float clampf_(float v, float lo, float hi) { return minf_(maxf_(v, lo), hi); }
@@ -349,9 +357,9 @@ __device__ __forceinline__ float sminf_fastdiv(float a, float b, float k, float 
  * WAVE — when every lane that still cares is saturated — so it costs one compare and a scalar branch where it does
  * not apply: two spheres more than k apart in distance is the common case away from the seams of a blob
  * (scene4 C3: +8.7 %).  NaN dlt is never saturated. */
-__device__ __forceinline__ float sminf_fastdiv_sat(float a, float b, float k, float k2, float hrk, float ks, bool care) {
+__device__ __forceinline__ float sminf_fastdiv_sat(float a, float b, float k, float k2, float hrk, float ks, u64 care) {
 	const float dlt = b - a;
-	if (__ballot(care && !(__builtin_fabsf(dlt) >= ks)) == 0) {
+	if ((vote(!(__builtin_fabsf(dlt) >= ks)) & care) == 0) {
 #ifdef LOL_SAT_CLOBBER
 		asm volatile("" ::: "memory");
 #else
@@ -452,6 +460,10 @@ struct Interp {
 
 	/* Inlined into the march / normal / shadow loops: as a real (noinline) function it was 8 % slower — arguments
 	 * travel in VGPRs and need v_readfirstlane, plus call / return and the callee's register shuffling. */
+	/* `care` stays a per-lane bool here and the loops around it vote on `alive` itself (MASKS = false): this kernel is
+	 * bound by its scalar side, where the mask bookkeeping of the other form costs more than the two vector
+	 * instructions per vote it saves (measured: -1.8 % with masks; the specialised kernel +4.1 %) */
+	static constexpr bool MASKS = false;
 	__device__ __forceinline__ void eval(V3 p, float& best_out, u32& id_out, bool care = true) {
 		/* everything the loop carries is a local: the trip count and the list pointer must stay provably
 		 * wave-uniform (scalar loop, scalar loads, scalar branches), which they do not when they live behind
@@ -526,13 +538,14 @@ struct Interp {
 							const float l2 = (cx * cx + cy * cy) + cz * cz;
 							const float u = (best + F(5)) * F(6);
 							const bool skip = l2 > u * u && u > 0.f;
-							if (__ballot(care && !skip) == 0) {
+							const u64 needed = vote(care && !skip);     /* any lane that cares and may not skip */
+							if (needed == 0) {
 								LOL_KEEP_BRANCH();
 								const u32 k = rec[1];                       /* to the last record: nothing follows that run */
 								rec += k * MOP_DWORDS;
 								left -= k;
 							}
-							if (__ballot(care && !skip) != 0) { LOL_KEEP_BRANCH(); cl = CULL_COOLDOWN + 1u; }
+							if (needed != 0) { LOL_KEEP_BRANCH(); cl = CULL_COOLDOWN + 1u; }
 						}
 						cl = cl ? cl - 1u : 0u;
 					}
@@ -549,7 +562,7 @@ struct Interp {
 							const float l2 = (cx * cx + cy * cy) + cz * cz;
 							const float u = (best + F(5)) * F(6);
 							const bool skip = l2 > u * u && u > 0.f;
-							if (__ballot(care && !skip) == 0) {
+							if (vote(care && !skip) == 0) {
 								LOL_KEEP_BRANCH();
 								const u32 k = rec[1];
 								rec += k * MOP_DWORDS;
@@ -581,17 +594,20 @@ __device__ __forceinline__ Hit march(Sdf& sdf, V3 ro, V3 rd, int max_steps) {
 	float dist = 0.f;
 	u32 id = 0, steps = 0;
 	bool alive = true;
+	u64 marching = vote(true);                    /* `alive` as a mask (see vote()); kept up only where Sdf::MASKS */
 	for (int i = 0; i < max_steps; i++) {
-		if (__ballot(alive) == 0) break;              /* every lane has hit or escaped */
+		if ((Sdf::MASKS ? marching : vote(alive)) == 0) break;       /* every lane has hit or escaped */
 		V3 p = add(ro, scale(rd, dist));
 		float d; u32 did;
-		sdf.eval(p, d, did, alive);        /* lanes that are done do not care: they do not keep an object from being culled */
+		/* lanes that are done do not care: they do not keep an object from being culled */
+		if constexpr (Sdf::MASKS) sdf.eval(p, d, did, marching); else sdf.eval(p, d, did, alive);
 		if (alive) {
 			dist += d;
 			id = did;
 			steps++;
 			if (d < EPSILON || dist > MAX_DIST) alive = false;
 		}
+		if constexpr (Sdf::MASKS) marching &= ~(vote(d < EPSILON) | vote(dist > MAX_DIST));     /* (finished lanes: bits already clear) */
 	}
 	if (dist >= MAX_DIST) id = 0;
 	return { dist, id, steps };
@@ -604,17 +620,19 @@ __device__ __forceinline__ float soft_shadow(Sdf& sdf, V3 p, V3 dir, float max_d
 	V3 ro = add(p, dir);
 	float res = 1.f, t = 0.f;
 	bool alive = needed;          /* a lane that does not need the factor never marches (returns 1) */
+	u64 marching = Sdf::MASKS ? vote(needed) : 0;
 	for (int i = 0; i < 128; i++) {
-		if (__ballot(alive) == 0) break;
+		if ((Sdf::MASKS ? marching : vote(alive)) == 0) break;
 		V3 q = add(ro, scale(dir, t));
 		float s; u32 sid;
-		sdf.eval(q, s, sid, alive);
+		if constexpr (Sdf::MASKS) sdf.eval(q, s, sid, marching); else sdf.eval(q, s, sid, alive);
 		if (alive) {
 			res = minf_(res, 50.f * s / t);
 			t += s;
 			steps++;
 			if (res < -1.f || t > max_dist) alive = false;
 		}
+		if constexpr (Sdf::MASKS) marching &= ~(vote(res < -1.f) | vote(t > max_dist));
 	}
 	return maxf_(res, 0.f);
 }
@@ -700,7 +718,7 @@ __device__ __forceinline__ Pixel shade_pixel(const Launch& L, Sdf& sdf, const u3
 	 * and the shadow marches (about 13 % of all SDF evaluations on scene4) and falls through to the same
 	 * `0 + ambient*mat.ambient` expression; a wave with at least one hit runs everything for all its lanes.
 	 */
-	const bool lit = !((L.flags & FLAG_MISS_SKIP) && __ballot(hit.id != 0u) == 0);
+	const bool lit = !((L.flags & FLAG_MISS_SKIP) && vote(hit.id != 0u) == 0);
 
 	/* get_light, naive_renderer.c:129-175 */
 	V3 total = { 0.f, 0.f, 0.f };
@@ -792,7 +810,7 @@ void render_interp(const Launch L) {
 	__syncthreads();
 	Interp<SSIZE, KIND> sdf{ L.ops, L.n_ops, {}, 0u };
 	Pixel P = shade_pixel(L, sdf, lds);
-	if (KIND != 0 && __ballot(sdf.rg.outside()) != 0) {
+	if (KIND != 0 && vote(sdf.rg.outside()) != 0) {
 		Interp<SSIZE, 0> exact{ L.ops, L.n_ops, {}, 0u };
 		P = shade_pixel(L, exact, lds);
 	}
@@ -809,7 +827,7 @@ __device__ __forceinline__ void sdf_points(SdfFast& fast, SdfExact& exact, bool 
 	float d; u32 k;
 	if (have_fast) {
 		fast.eval(p, d, k);
-		if (__ballot(fast.rg.outside()) != 0) exact.eval(p, d, k);
+		if (vote(fast.rg.outside()) != 0) exact.eval(p, d, k);
 	} else {
 		exact.eval(p, d, k);
 	}
