@@ -74,6 +74,7 @@ struct lol_gpu {
 	bool         dark_skip = false;      /* the uploaded program qualifies (dark_skip_ok) */
 	int          interp_sqrt_kind = 0;   /* fast sqrt of the interpreter: 3 (sqrt_r2) when proven and allowed, else 0 */
 	int          sqrt_verified = -1;     /* -1 not run, 0 none proven, else the lol::sqrt_fast KIND proven on this device */
+	bool         sqrt_tiny_ok = false;   /* the second counter of that run was 0 too (sd_sphere_fast_nr) */
 	std::vector<std::pair<uint32_t, bool>> div_verified;   /* k bits → proven */
 	unsigned long long* d_bad = nullptr; /* mismatch counter of the verification kernels */
 	int          wave_w = LOL_WAVE_W, wave_h = LOL_WAVE_H, waves_x = LOL_WAVES_X;   /* footprint of the spec kernel */
@@ -166,16 +167,23 @@ constexpr unsigned VERIFY_BLOCKS = 65536, VERIFY_THREADS = 256, VERIFY_ITERS = 2
 template <int KIND>
 __global__ __launch_bounds__(VERIFY_THREADS) void verify_sqrt_kernel(unsigned long long* bad) {
 	uint32_t base = blockIdx.x * VERIFY_THREADS + threadIdx.x;
-	unsigned n = 0;
+	unsigned n = 0, m = 0;
 	for (uint32_t it = 0; it < VERIFY_ITERS; it++) {
 		float x = __builtin_bit_cast(float, base + it * (VERIFY_BLOCKS * VERIFY_THREADS));
 		/* The fast roots are only ever given a sum of squares (len2): never negative.  A wave that saw
 		 * an argument outside [2^-96, inf) re-shades through the plain path (lol::Range), so the proof
 		 * obligation is exactly that interval plus NaN. */
 		bool in_domain = (x >= lol::SQRT_FAST_MIN && x < __builtin_inff()) || x != x;
-		if (in_domain && !same_float(lol::sqrt_fast<KIND>(x), __builtin_sqrtf(x))) n++;
+		const float r = lol::sqrt_fast<KIND>(x);
+		if (in_domain && !same_float(r, __builtin_sqrtf(x))) n++;
+		/* second counter — what sd_sphere_fast_nr relies on: below the proven domain (x in [+0, 2^-96)) the fast root
+		 * is NaN or tiny, and +inf gives NaN (never a wrong finite value, never inf) */
+		const uint32_t xb = __builtin_bit_cast(uint32_t, x);
+		if (xb < lol::SQRT_FAST_MIN_BITS && !(r != r || __builtin_fabsf(r) < 0x1p-47f)) m++;
+		if (xb == lol::F32_INF_BITS && !(r != r)) m++;
 	}
 	if (n) atomicAdd(bad, (unsigned long long)n);
+	if (m) atomicAdd(bad + 1, (unsigned long long)m);
 }
 
 /* smooth_sat_threshold: the |dlt| from which sminf_fastdiv_sat treats the blend factor as saturated: k(1 + 2^-20),
@@ -209,19 +217,20 @@ __global__ __launch_bounds__(256) void powf_batch_kernel(const float* x, const f
 }
 
 /* returns mismatch count, or ~0ull when the check itself could not run */
-unsigned long long run_verify(lol_gpu* ctx, int sqrt_kind, float k) {
-	if (!ctx->d_bad && hipMalloc(reinterpret_cast<void**>(&ctx->d_bad), sizeof(unsigned long long)) != hipSuccess)
+unsigned long long run_verify(lol_gpu* ctx, int sqrt_kind, float k, unsigned long long* second = nullptr) {
+	if (!ctx->d_bad && hipMalloc(reinterpret_cast<void**>(&ctx->d_bad), 2 * sizeof(unsigned long long)) != hipSuccess)
 		return ~0ull;
-	unsigned long long bad = 0;
-	if (hipMemcpy(ctx->d_bad, &bad, sizeof bad, hipMemcpyHostToDevice) != hipSuccess) return ~0ull;
+	unsigned long long bad[2] = { 0, 0 };
+	if (hipMemcpy(ctx->d_bad, bad, sizeof bad, hipMemcpyHostToDevice) != hipSuccess) return ~0ull;
 	if (sqrt_kind == 3) hipLaunchKernelGGL(verify_sqrt_kernel<3>, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, ctx->d_bad);
 	else if (sqrt_kind == 2) hipLaunchKernelGGL(verify_sqrt_kernel<2>, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, ctx->d_bad);
 	else if (sqrt_kind == 1) hipLaunchKernelGGL(verify_sqrt_kernel<1>, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, ctx->d_bad);
 	else hipLaunchKernelGGL(verify_div_kernel, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, k, 2.0f * k, 0.5f * (1.0f / k),
 	                        smooth_sat_threshold(k), ctx->d_bad);
 	if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return ~0ull;
-	if (hipMemcpy(&bad, ctx->d_bad, sizeof bad, hipMemcpyDeviceToHost) != hipSuccess) return ~0ull;
-	return bad;
+	if (hipMemcpy(bad, ctx->d_bad, sizeof bad, hipMemcpyDeviceToHost) != hipSuccess) return ~0ull;
+	if (second) *second = bad[1];
+	return bad[0];
 }
 
 /* ------------------------------------------------- scene → HIP source (the "JIT") */
@@ -237,6 +246,7 @@ std::string fbits(float v) {
 /* Which proven-exact shortcuts the generated code may use (see lol_kernel.h "fast exact paths"). */
 struct FastPaths {
 	int sqrt_kind = 0;                    /* 0 plain sqrtf; 1 sqrt_pm, 2 sqrt_gs, 3 sqrt_r2 — proven on this device */
+	bool sqrt_tiny_ok = false;            /* ... and NaN-or-tiny below its domain: spheres may drop the range tracker (sd_sphere_fast_nr) */
 	std::vector<float> div_ok;            /* smoothness constants k whose smin_h_fast verified */
 	bool has(float k) const {
 		for (float v : div_ok) if (memcmp(&v, &k, 4) == 0) return true;
@@ -566,11 +576,11 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 		/* (amdgpu_waves_per_eu applies to kernels only: the function is scheduled with the default register budget) */
 		(void)occupancy;
 		snprintf(line, sizeof line, "__device__ __noinline__ SdfOut %s_fn(float px, float py, float pz, u32 rg_lo, u32 rg_hi, u64 care) {\n"
-		         "\t\tconst V3 p = { px, py, pz };\n\t\tRange rg; rg.lo = rg_lo; rg.hi = rg_hi;\n\t\tfloat best; u32 best_id;\n\t%s",
+		         "\t\tconst V3 p = { px, py, pz };\n\t\tRange rg; rg.lo = rg_lo; rg.hi = rg_hi;\n\t\tu64 nan = 0;\n\t\tfloat best; u32 best_id;\n\t%s",
 		         name, cool_decl);
 		s += line;
 	} else {
-		snprintf(line, sizeof line, "struct %s {\n\tstatic constexpr bool MASKS = true;\n\tRange rg;\n%s", name, cool_decl);
+		snprintf(line, sizeof line, "struct %s {\n\tstatic constexpr bool MASKS = true;\n\tRange rg;\n\tu64 nan = 0;\n%s", name, cool_decl);
 		s += line;
 		s += "\t__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id, u64 care = ~0ull) {\n";
 	}
@@ -584,6 +594,9 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 	if (const char* e = getenv("LOL_GPU_CULL_COOLDOWN")) cooldown = atoi(e);
 	/* LOL_GPU_SMIN_SAT=0: smooth minima without the per-wave saturation shortcut (sminf_fastdiv_sat), for A/B runs */
 	const bool smin_sat = !(getenv("LOL_GPU_SMIN_SAT") && atoi(getenv("LOL_GPU_SMIN_SAT")) == 0);
+	/* LOL_GPU_NAN_FLAG=0: every sphere keeps the range tracker (A/B runs) */
+	const bool nan_flag = fast && fast->sqrt_tiny_ok && !(getenv("LOL_GPU_NAN_FLAG") && atoi(getenv("LOL_GPU_NAN_FLAG")) == 0);
+	bool object_has_nr = false;
 	/* LOL_GPU_SAT_CULL_MIN_PRIMS: `a` operands of a smooth union with at least this many primitives get a saturation-
 	 * culling test (see emit_node below); 0 = none.  Measured (tools/tree_scene_ab.py, balanced trees of spheres at
 	 * 1080p, profiles/r2_tree_scene_ab.jsonl): the 17-instruction test pays from a few dozen primitives — 128 spheres
@@ -670,6 +683,11 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 			const lol_op& o = P.ops[n.op];
 			switch (o.op) {
 			case LOL_OP_SPHERE:
+				if (fsqrt && nan_flag && o.f[3] >= 0x1p-20f && std::isfinite(o.f[3])) {      /* sd_sphere_fast_nr: no range tracker */
+					snprintf(line, sizeof line, "\t\tconst float t%d = sd_sphere_fast_nr<%d>(p, %s, %s, %s, %s);\n", t, fsqrt,
+					         fbits(o.f[0]).c_str(), fbits(o.f[1]).c_str(), fbits(o.f[2]).c_str(), fbits(o.f[3]).c_str());
+					object_has_nr = true;
+				} else
 				snprintf(line, sizeof line, "\t\tconst float t%d = sd_sphere%s(p, %s, %s, %s, %s%s);\n", t, fs,
 				         fbits(o.f[0]).c_str(), fbits(o.f[1]).c_str(), fbits(o.f[2]).c_str(), fbits(o.f[3]).c_str(),
 				         fsqrt ? ", rg" : "");
@@ -732,7 +750,12 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 				snprintf(line, sizeof line, "\t\tconst float t%d = sminf_(t%d, t%d, %s);\n", t, a, b, kk.c_str());
 			s += line; return t++;
 		};
+		object_has_nr = false;
 		const int d = emit_node((int)nodes.size() - 1);
+		if (object_has_nr) {                 /* a NaN from a sphere without range tracker reaches the object's value */
+			snprintf(line, sizeof line, "\t\tnan |= vote(t%d != t%d);\n", d, d);
+			s += line;
+		}
 		if (R.id < max_id_seen)      /* evaluated after an object that follows it in the file: ties go to the lower id */
 			snprintf(line, sizeof line, "\t\tif (t%d < best || (t%d == best && best_id > %uu)) { best = t%d; best_id = %uu; }\n", d, d, R.id, d, R.id);
 		else
@@ -743,10 +766,10 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 			if (iv.end == oi + 1) s += "\t\t} }\n";
 	}
 	if (out_of_line) {
-		s += "\t\treturn { best, best_id, rg.lo, rg.hi };\n}\n";
-		snprintf(line, sizeof line, "struct %s {\n\tstatic constexpr bool MASKS = true;\n\tRange rg;\n\t__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id, u64 care = ~0ull) {\n"
+		s += "\t\treturn { best, best_id, rg.lo, rg.hi, nan };\n}\n";
+		snprintf(line, sizeof line, "struct %s {\n\tstatic constexpr bool MASKS = true;\n\tRange rg;\n\tu64 nan = 0;\n\t__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id, u64 care = ~0ull) {\n"
 		         "\t\tconst SdfOut o = %s_fn(p.x, p.y, p.z, rg.lo, rg.hi, care);\n"
-		         "\t\tbest = o.best; best_id = o.id; rg.lo = o.lo; rg.hi = o.hi;\n\t}\n};\n", name, name);
+		         "\t\tbest = o.best; best_id = o.id; rg.lo = o.lo; rg.hi = o.hi; nan |= o.nan;\n\t}\n};\n", name, name);
 		s += line;
 	} else {
 		s += "\t}\n};\n";
@@ -789,7 +812,7 @@ std::string generate_source(const lol_program& P, const FastPaths* fast, bool cu
 		if (sscanf(e, "%d,%d", &lo, &hi) == 2 && lo >= 1 && hi >= lo && hi <= 8) { waves_lo = lo; waves_hi = hi; }
 	}
 	const std::string occupancy = " __attribute__((amdgpu_waves_per_eu(" + std::to_string(waves_lo) + ", " + std::to_string(waves_hi) + ")))";
-	if (ool) s += "struct SdfOut { float best; u32 id; u32 lo, hi; };\n";
+	if (ool) s += "struct SdfOut { float best; u32 id; u32 lo, hi; u64 nan; };\n";
 	emit_sdf(s, P, "SpecSdfExact", nullptr, ool, roots, plan, occupancy);
 	const bool any_fast = fast && (fast->sqrt_kind || !fast->div_ok.empty());
 	if (any_fast) emit_sdf(s, P, "SpecSdfFast", fast, ool, roots, plan, occupancy);
@@ -801,7 +824,7 @@ std::string generate_source(const lol_program& P, const FastPaths* fast, bool cu
 	if (any_fast) {
 		s += "\tlol::SpecSdfFast fast;\n";
 		s += "\tlol::Pixel P = lol::shade_pixel(L, fast, lds);\n";
-		s += "\tif (lol::vote(fast.rg.outside()) != 0) {\n";
+		s += "\tif (lol::unproven(fast)) {\n";
 		s += "\t\tlol::SpecSdfExact exact;\n";
 		s += "\t\tP = lol::shade_pixel(L, exact, lds);\n";
 		s += "\t}\n";
@@ -1015,10 +1038,13 @@ FastPaths prove_fast_paths(lol_gpu* ctx, const lol_program& prog) {
 	if (!ctx->want_fast || (fenv && fenv[0] == '0')) return fast;
 	if (ctx->sqrt_verified < 0) {
 		ctx->sqrt_verified = 0;                     /* cheapest proven sequence wins */
-		for (int kind = 3; kind >= 1 && !ctx->sqrt_verified; kind--)
-			if (run_verify(ctx, kind, 0.f) == 0) ctx->sqrt_verified = kind;
+		for (int kind = 3; kind >= 1 && !ctx->sqrt_verified; kind--) {
+			unsigned long long tiny_bad = 1;
+			if (run_verify(ctx, kind, 0.f, &tiny_bad) == 0) { ctx->sqrt_verified = kind; ctx->sqrt_tiny_ok = tiny_bad == 0; }
+		}
 	}
 	fast.sqrt_kind = ctx->sqrt_verified;
+	fast.sqrt_tiny_ok = ctx->sqrt_tiny_ok;
 	for (uint32_t i = 0; i < prog.n_ops; i++) {
 		const lol_op& o = prog.ops[i];
 		if (o.op != LOL_OP_SMIN && o.op != LOL_OP_SMIN_R) continue;
@@ -1494,6 +1520,7 @@ int lol_gpu_compile_offline(const lol_program* prog, const char* arch, const cha
 	FastPaths fast;
 	if (assume_fast) {                 /* ISA inspection only: pretend every shortcut was proven */
 		fast.sqrt_kind = assume_fast >= 1 && assume_fast <= 3 ? 4 - assume_fast : 3;   /* 1 → sqrt_r2, 2 → sqrt_gs, 3 → sqrt_pm */
+		fast.sqrt_tiny_ok = true;
 		for (uint32_t i = 0; i < prog->n_ops; i++)
 			if ((prog->ops[i].op == LOL_OP_SMIN || prog->ops[i].op == LOL_OP_SMIN_R) && !fast.has(prog->ops[i].f[0]))
 				fast.div_ok.push_back(prog->ops[i].f[0]);

@@ -381,6 +381,21 @@ __device__ __forceinline__ float sd_sphere_fast(V3 p, float cx, float cy, float 
 	rg.see(l2);
 	return sqrt_fast<KIND>(l2) - r;
 }
+/* The same without the range tracker, for spheres of radius r >= 2^-20 once the device has also shown that the
+ * fast root of every x in [0, 2^-96) is either NaN or smaller than 2^-47 in magnitude (verify_sqrt_kernel, second
+ * counter).  Then the sphere's value is right or NaN for EVERY l2:
+ *   l2 in [2^-96, inf): the proven domain;   l2 = +inf or NaN: the fast root gives NaN (the plain one inf / NaN);
+ *   l2 in [0, 2^-96): the true root is < 2^-48 < ulp(r)/2, so the true value is exactly -r, and so is (root') - r for
+ *   any root' below 2^-47 — or it is NaN.
+ * A NaN operand makes every smooth minimum above it NaN (dlt = NaN, h clamps to 0, b - NaN*0 = NaN), so it reaches
+ * the object's value, where the generated code votes on `t != t` — one comparison per OBJECT instead of a min and a
+ * max per squared length (six half-rate instructions per evaluation of scene4's blob).  A wave with such a NaN
+ * shades its pixels again through the plain path, like one that left the range. */
+template <int KIND>
+__device__ __forceinline__ float sd_sphere_fast_nr(V3 p, float cx, float cy, float cz, float r) {
+	V3 q = { p.x - cx, p.y - cy, p.z - cz };
+	return sqrt_fast<KIND>(len2(q)) - r;
+}
 template <int KIND>
 __device__ __forceinline__ float sd_round_box_fast(V3 p, float cx, float cy, float cz, float bx, float by, float bz, float r, Range& rg) {
 	V3 q = { __builtin_fabsf(p.x - cx) - bx, __builtin_fabsf(p.y - cy) - by, __builtin_fabsf(p.z - cz) - bz };
@@ -457,6 +472,7 @@ struct Interp {
 	u32        n_mops;
 	Range      rg;       /* KIND != 0: range of the squared lengths given to the proven fast sqrt (see above) */
 	u32        cool;     /* evaluations left before a CULL_NEXT record tests again (wave-uniform) */
+	u64        nan = 0;  /* (the specialised SDF's "an untracked sphere went NaN" mask; never set here) */
 
 	/* Inlined into the march / normal / shadow loops: as a real (noinline) function it was 8 % slower — arguments
 	 * travel in VGPRs and need v_readfirstlane, plus call / return and the callee's register shuffling. */
@@ -582,6 +598,11 @@ struct Interp {
 		id_out = best_id;
 	}
 };
+
+/* did this wave's fast SDF leave what was proven for it (a squared length outside the fast root's domain, or a NaN
+ * from a sphere that carries no range tracker)?  Then its results are not used. */
+template <class Sdf>
+__device__ __forceinline__ bool unproven(const Sdf& sdf) { return (vote(sdf.rg.outside()) | sdf.nan) != 0; }
 
 /* --------------------------------------------------------------- the pipeline */
 
@@ -810,7 +831,7 @@ void render_interp(const Launch L) {
 	__syncthreads();
 	Interp<SSIZE, KIND> sdf{ L.ops, L.n_ops, {}, 0u };
 	Pixel P = shade_pixel(L, sdf, lds);
-	if (KIND != 0 && vote(sdf.rg.outside()) != 0) {
+	if (KIND != 0 && unproven(sdf)) {
 		Interp<SSIZE, 0> exact{ L.ops, L.n_ops, {}, 0u };
 		P = shade_pixel(L, exact, lds);
 	}
@@ -827,7 +848,7 @@ __device__ __forceinline__ void sdf_points(SdfFast& fast, SdfExact& exact, bool 
 	float d; u32 k;
 	if (have_fast) {
 		fast.eval(p, d, k);
-		if (vote(fast.rg.outside()) != 0) exact.eval(p, d, k);
+		if (unproven(fast)) exact.eval(p, d, k);
 	} else {
 		exact.eval(p, d, k);
 	}

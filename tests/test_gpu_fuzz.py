@@ -105,6 +105,13 @@ def test_degenerate_inputs(torch_cuda):
     cases.append("materials { { shininess = 4, diffuse = (.2,.2,.2), specular = (.3,.3,.3), ambient = (.1,.1,.1) } } scene {"
                  " camera { point = (0,1,0), direction = (0,0,-1), fov = 90 }, sphere { point = (100000000000000000000, 0, 0), radius = 1 },"
                  " sphere { point = (0,1,-4), radius = 1 }, point_light { point = (3,5,0), diffuse_intensity = (2,2,2), specular_intensity = (1,1,1) } }")
+    # the camera sits exactly on a sphere's centre (squared length 0: the fast root gives NaN there), next to a sphere
+    # too small for the NaN flag (radius 2^-21: keeps the range tracker), inside a smooth union and on its own
+    cases.append("materials { { shininess = 4, diffuse = (.2,.2,.2), specular = (.3,.3,.3), ambient = (.1,.1,.1) } } scene {"
+                 " camera { point = (0,1,0), direction = (0,0,-1), fov = 90 }, sphere { point = (0,1,0), radius = 0.25 },"
+                 " smooth_union { smoothness = 0.5, a = sphere { point = (0,1,0), radius = 0.125 }, b = sphere { point = (1,1,-3), radius = 1 } },"
+                 " sphere { point = (0,1,0), radius = 0.000000476837158203125 }, plane { y = -1 },"
+                 " point_light { point = (0,1,0), diffuse_intensity = (2,2,2), specular_intensity = (1,1,1) } }")
     for mode in (1, 4):
         r = gpu.Renderer(0, specialize=mode)
         for text in cases:

@@ -72,3 +72,46 @@ def test_device_frames_equal_the_reference_composition(scenes, name, mode):
     else:
         assert np.abs(d["rgb"] - g[f"{name}_rgb"]).max() <= 1e-4
     r.close()
+
+
+@pytest.mark.parametrize("mode", [1, 4], ids=["spec", "interp"])
+def test_points_where_the_fast_root_has_no_proof(scenes, mode):
+    """scene4's spheres carry no range tracker in the specialised kernel (sd_sphere_fast_nr): a squared length of 0,
+    a denormal one, one below 2^-96 and an overflowing one must all come out as the oracle's value — through the NaN
+    vote and the plain path where the fast root gives NaN, directly where the offset is far below half an ulp of r."""
+    import ctypes as C
+    import torch
+    import oracle_lib as O
+    sc = scenes["scene4"]
+    centres = np.array([[0, 1, -6], [-1, 0.5, -3], [-3, 4.5, -3], [2, 2, -10], [6, 2, -10]], dtype=np.float32)
+    pts = [c.copy() for c in centres]                                     # l2 == 0
+    for c in centres:
+        for eps in (1e-45, 1e-30, 1e-22, 1e-20, 1e-18, 1e-17, 1e-16, 3e-15, 1e-14, 1e-10):   # l2 = 0, denormal, [2^-126, 2^-96), just above
+            for ax in range(3):
+                q = c.copy().astype(np.float64)
+                if c[ax] == 0:                                             # (an offset that small only survives next to 0)
+                    q[ax] += eps
+                    pts.append(q.astype(np.float32))
+    pts += [np.array([1e20, 0, 0], dtype=np.float32), np.array([0, -3e38, 0], dtype=np.float32),
+            np.array([np.inf, 1, 1], dtype=np.float32), np.array([np.nan, 0, 0], dtype=np.float32)]
+    pts = np.array(pts, dtype=np.float32)
+    pts = np.concatenate([pts, np.tile(centres[1], (64, 1))])            # a whole wave on one centre
+    l = O.lib()
+    want_d = np.zeros(len(pts), dtype=np.float32)
+    want_id = np.zeros(len(pts), dtype=np.int32)
+    for i, p in enumerate(pts):
+        oid = C.c_uint32()
+        want_d[i] = l.lol_oracle_sdf(sc.ptr, float(p[0]), float(p[1]), float(p[2]), C.byref(oid))
+        want_id[i] = oid.value
+    r = gpu.Renderer(0, specialize=mode)
+    r.prepare(sc)
+    d_pts = torch.from_numpy(pts.copy()).cuda()
+    d_dist = torch.zeros(len(pts), dtype=torch.float32, device="cuda")
+    d_id = torch.zeros(len(pts), dtype=torch.int32, device="cuda")
+    r.sdf_batch(d_pts.data_ptr(), d_dist.data_ptr(), d_id.data_ptr(), len(pts), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = d_dist.cpu().numpy()
+    both_nan = np.isnan(got) & np.isnan(want_d)
+    assert np.array_equal(got.view(np.uint32)[~both_nan], want_d.view(np.uint32)[~both_nan])
+    assert np.array_equal(d_id.cpu().numpy(), want_id)
+    r.close()
