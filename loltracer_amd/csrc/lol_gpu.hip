@@ -708,7 +708,7 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 			const bool proven = fast && fast->has(o.f[0]);
 			/* the arithmetic shortcut only where the SDF is inlined: in the out-of-line function its four-way branching
 			 * costs more than it saves (504-op chain: 100 -> 42 Mpixels/s) */
-			const bool sat_arith = smin_sat && !out_of_line && ks > 0.f;
+			const bool sat_arith = smin_sat && (!out_of_line || (getenv("LOL_GPU_SMIN_SAT") && atoi(getenv("LOL_GPU_SMIN_SAT")) == 2)) && ks > 0.f;
 			const std::string kk = fbits(o.f[0]), k2 = fbits(2.0f * o.f[0]), hrk = fbits(0.5f * (1.0f / o.f[0])), kss = fbits(ks);
 			if (proven && ks > 0.f && sat_cull_min_prims > 0 && nodes[n.a].bound.ok && nodes[n.a].prims >= (uint32_t)sat_cull_min_prims) {
 				const int b = emit_node(n.b);
