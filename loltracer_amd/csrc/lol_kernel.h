@@ -360,11 +360,7 @@ __device__ __forceinline__ float sminf_fastdiv(float a, float b, float k, float 
 __device__ __forceinline__ float sminf_fastdiv_sat(float a, float b, float k, float k2, float hrk, float ks, u64 care) {
 	const float dlt = b - a;
 	if ((vote(!(__builtin_fabsf(dlt) >= ks)) & care) == 0) {
-#ifdef LOL_SAT_CLOBBER
-		asm volatile("" ::: "memory");
-#else
 		asm volatile("");                         /* keep the branch: if-converted, every evaluation would pay for both sides */
-#endif
 		const float r1 = b - dlt;
 		const float r0 = b - dlt * 0.f;
 		return dlt > 0.f ? r1 : r0;
