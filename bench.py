@@ -202,6 +202,13 @@ def main():
         # exits with their status.
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
+    # stdout carries ONE line, the JSON record: native libraries write there too (RCCL prints a version banner
+    # on communicator creation), so file descriptor 1 points at stderr for the rest of the run and the record
+    # goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    record_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -385,9 +392,9 @@ def main():
                          "bytes_per_pixel": BYTES_PER_PIXEL,
                          "note": "north_star names the HBM-write roofline; the path is FP32-VALU-bound, see `valu`"},
         }
-        if world == 1 and not orbit:
+        if world == 1 and not orbit and local is not None:       # (local is None in the 1-rank gather rehearsal)
             out["kernels"] = both_kernels(r, sc, local, w, h, max_steps, cams[0], stream, k_avg, px_per_launch)
-        if world == 1 and not args.no_cpu_baseline and not orbit:
+        if world == 1 and not args.no_cpu_baseline and not orbit and local is not None:
             base, ctr = cpu_baseline(sc, cfg, gpu_frame=local.cpu().numpy().view(np.uint32))
             out["cpu_baseline"] = base
             fpp = (ctr.sdf_evals * flops_per_sdf(r.program) + ctr.march_steps * 9 + ctr.shadow_steps * 12) / ctr.pixels
@@ -396,7 +403,8 @@ def main():
             out["valu"] = {"flops_per_pixel": round(fpp, 1), "sdf_evals_per_pixel": round(ctr.sdf_evals / ctr.pixels, 2),
                            "achieved": round(tops, 3), "peak": VALU_PEAK_TOPS, "unit": "Tops/s (unfused FP32)",
                            "frac": round(tops / VALU_PEAK_TOPS, 4)}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(record_fd, (json.dumps(out) + "\n").encode())
 
     r.close()
     if dist.is_initialized():

@@ -22,8 +22,8 @@ def _bench(args, **env):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True, timeout=420)
     assert p.returncode == 0, p.stderr[-3000:]
-    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, p.stdout
+    lines = p.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout      # stdout is the record and nothing else
     return json.loads(lines[0]), p.stderr
 
 
@@ -48,3 +48,10 @@ def test_default_line_carries_roofline_cpu_baseline_and_both_kernels():
     ks = out["kernels"]
     assert ks["lol_render_spec"]["mpixels_per_s"] > 0 and ks["render_interp"]["mpixels_per_s"] > 0
     assert ks["render_interp"]["frame_equal_to_spec"] is True
+
+
+def test_the_real_backends_chatter_stays_off_stdout():
+    """With the nccl (RCCL) process group up — one rank, LOL_BENCH_FORCE_PIPE — the library prints its version banner
+    from native code; stdout must still be the one JSON line (the driver parses it), the banner goes to stderr."""
+    out, err = _bench(["--steps", "3", "--warmup", "1", "--workload", "c4", "--no-cpu-baseline"], LOL_BENCH_FORCE_PIPE="1")
+    assert out["backend"] == "nccl" and out["gather_ms"] is not None
