@@ -491,8 +491,16 @@ struct Interp {
 		float best = __builtin_inff();
 		u32 best_id = 0;
 		for (u32 left = n; left != 0u; left--, rec += MOP_DWORDS) {       /* (the TAIL branch may jump further) */
-			const u32 hdr = rec[0];
-			auto F = [&](int j) { return __builtin_bit_cast(float, rec[j]); };
+			/* the whole record at once, up here: read where they are used, the fields arrived in three or four
+			 * separate scalar loads per record, each with its own wait (the branches below are barriers for the
+			 * compiler's load merging) — one s_load_dwordx8 + one x4 and ONE wait instead */
+			const u32 w0 = rec[0], w1 = rec[1], w2 = rec[2], w3 = rec[3], w4 = rec[4], w5 = rec[5], w6 = rec[6], w7 = rec[7],
+			          w8 = rec[8], w9 = rec[9], w10 = rec[10], w11 = rec[11];
+			asm volatile("" :: "s"(w0), "s"(w1), "s"(w2), "s"(w3), "s"(w4), "s"(w5), "s"(w6), "s"(w7), "s"(w8), "s"(w9), "s"(w10), "s"(w11));
+			const u32 hdr = w0;
+			const u32 wv[MOP_DWORDS] = { w0, w1, w2, w3, w4, w5, w6, w7, w8, w9, w10, w11 };
+			auto F = [&](int j) { return __builtin_bit_cast(float, wv[j]); };
+			auto C = [&](int j) { return __builtin_bit_cast(float, rec[j]); };      /* a test's constants record, after rec has moved on to it */
 			/* one-hot header bits, tested one by one (s_bitcmp1 + s_cbranch each) with no else-chains: every `if`
 			 * is a plain skip-ahead, which the compiler lowers without the flag registers it needs for if / else-if */
 			/* LOL_KEEP_BRANCH: an empty volatile asm keeps the compiler from turning a rarely taken uniform branch into
@@ -537,7 +545,7 @@ struct Interp {
 				}
 				if (hdr & MOP_TOP) {                                    /* (tests only follow finished objects) */
 					LOL_KEEP_BRANCH();
-					const u32 id = rec[1];
+					const u32 id = w1;
 					if (!(hdr & MOP_TIE)) { LOL_KEEP_BRANCH(); if (x < best) { best = x; best_id = id; } }
 					if (hdr & MOP_TIE) { LOL_KEEP_BRANCH(); if (x < best || (x == best && best_id > id)) { best = x; best_id = id; } }
 					if (hdr & MOPB_CULL_NEXT) {                             /* the run of all bounded objects: the test that cools down */
@@ -546,9 +554,9 @@ struct Interp {
 						left--;
 						if (cl == 0u) {
 							LOL_KEEP_BRANCH();
-							const float cx = p.x - F(2), cy = p.y - F(3), cz = p.z - F(4);
+							const float cx = p.x - C(2), cy = p.y - C(3), cz = p.z - C(4);
 							const float l2 = (cx * cx + cy * cy) + cz * cz;
-							const float u = (best + F(5)) * F(6);
+							const float u = (best + C(5)) * C(6);
 							const bool skip = l2 > u * u && u > 0.f;
 							const u64 needed = vote(care && !skip);     /* any lane that cares and may not skip */
 							if (needed == 0) {
@@ -570,9 +578,9 @@ struct Interp {
 							left--;
 							const u32 ch = rec[0];
 							more = ch & CULLC_NEXT;
-							const float cx = p.x - F(2), cy = p.y - F(3), cz = p.z - F(4);
+							const float cx = p.x - C(2), cy = p.y - C(3), cz = p.z - C(4);
 							const float l2 = (cx * cx + cy * cy) + cz * cz;
-							const float u = (best + F(5)) * F(6);
+							const float u = (best + C(5)) * C(6);
 							const bool skip = l2 > u * u && u > 0.f;
 							if (vote(care && !skip) == 0) {
 								LOL_KEEP_BRANCH();
