@@ -2,6 +2,7 @@
 """bench.py — Mpixels/s of the gfx950 sphere-tracer on BASELINE.json's configs.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|orbit]
+                    [--transport dist|cabi] [--emulate-root-of N]
 
 A step = one frame of the hot path (camera ray → march → normal → shadows/Phong → gamma →
 XRGB8888) rendered from the scene already resident on the device, into a device framebuffer.
@@ -11,7 +12,14 @@ XRGB8888) rendered from the scene already resident on the device, into a device 
   N > 1   workload "c4": scene4.lol, 7680x4320, rows band-interleaved over the N ranks (one process
           per GPU), each rank renders its bands, then ONE RCCL gather to rank 0 which un-interleaves
           them into the final framebuffer.  Total work is fixed as N grows → "scaling": "strong".
+          The root also receives and un-interleaves the whole frame, so its share of the rows is smaller
+          (loltracer_amd.multi.Partition; LOL_BENCH_ROOT_SHARE = auto | equal | k: `auto` times a few frames
+          of each candidate split during set-up and keeps the fastest).
   orbit   256-frame camera orbit of scene4 at 3840x2160, frames striped over ranks, no collective.
+  --transport cabi       ONE process drives all N devices through lol_gpu_multi_* (the in-process path the
+                         reference's C host calls: band partition + RCCL send/recv group + assembly kernel).
+  --emulate-root-of N    one GPU plays rank 0 of an N-rank run: renders the root's share of C4, gathers through a
+                         1-rank RCCL group, assembles the whole frame — the root's cadence and host cost per frame.
 
 The JSON line carries `roofline` (HBM-write roofline named by BASELINE.json: 4 B per pixel over the
 render kernel's average launch duration measured with HIP events on the launch stream) and
@@ -71,18 +79,23 @@ def flops_per_sdf(prog: S.Program) -> float:
     return float(sum(cost[prog.ops[i].op] for i in range(prog.n_ops)))
 
 
-def pmc_traffic(kernel: str, workload: str, pixels_per_launch: int):
+def pmc_traffic(kernel: str, workload: str, pixels_per_launch: int, kernel_key: str):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json:
     WRITE_SIZE + 2 x FETCH_SIZE, one counter group per pass, the gfx950 FETCH correction applied).  PMC
     counters cannot be read from inside this process, so the figure comes from the profile of the same
-    command; it is reported only for the kernel / workload / launch size it was measured on."""
+    command; it is reported only for the kernel / workload / launch size AND CODE it was measured on: the
+    profile records lol_gpu_kernel_key() of the kernel it saw, and a kernel whose key differs gets null."""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"].get(kernel)
     except (OSError, ValueError, KeyError):
-        return None
+        return None, "profiles/pmc_traffic.json is missing or has no record of this kernel"
     if not rec or rec.get("workload") != workload or rec.get("pixels_per_launch") != pixels_per_launch:
-        return None
-    return rec["traffic_bytes"]
+        return None, "profiles/pmc_traffic.json was measured on another workload / launch size"
+    if rec.get("kernel_key") != kernel_key:
+        return None, (f"profiles/pmc_traffic.json was measured on kernel code {rec.get('kernel_key')}, this run is "
+                      f"{kernel_key}: not quoted (re-run tools/final_profile.sh)")
+    return rec["traffic_bytes"], ("profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command on this kernel code, "
+                                  "tools/pmc_summary.py; not re-measured in this run)")
 
 
 def cpu_baseline(sc: S.Scene, cfg: dict, target_s: float = 15.0, gpu_frame=None):
@@ -119,6 +132,10 @@ def cpu_baseline(sc: S.Scene, cfg: dict, target_s: float = 15.0, gpu_frame=None)
     cores = cores_all
     base = dict(value=ctr.pixels / t / 1e6, unit="Mpixels/s", cores=cores, kind="port",
                 value_1_thread=round(c1.pixels / t1 / 1e6, 4),
+                # tie-back to the true reference: seconds per frame of this port / of the unmodified
+                # naive_renderer.c, both timed in the build container with gcc -O2 and the reference's -m flags, 1 thread
+                port_over_reference_time={"scene4.lol": 0.80, "scene.lol": 1.15,
+                                          "source": "DESIGN.md §6 / BASELINE.md §2 (survey probe of naive_renderer.c)"},
                 sample=f"every {stride}th row of the {w}x{h} frame ({ctr.pixels} px, {t:.1f} s, "
                        f"{cores} threads claiming rows from an atomic counter)")
     if gpu_frame is not None:
@@ -135,13 +152,17 @@ def cpu_baseline(sc: S.Scene, cfg: dict, target_s: float = 15.0, gpu_frame=None)
 
 
 def both_kernels(r, sc, spec_frame, w, h, max_steps, fc, stream, spec_ms, px, frames: int = 5):
-    """After the timed region: the same frame on the OTHER kernel of the library — the ahead-of-time LDS
-    op-list interpreter `render_interp` (the literal north-star kernel; what runs when hipRTC is unavailable) —
+    """After the timed region: the same frame on the OTHER kernel of the library — the ahead-of-time macro-op
+    interpreter `render_interp` (scene as data, fetched with scalar loads; what runs when hipRTC is unavailable) —
     timed with HIP events, and compared with the frame the default kernel just rendered."""
     out = {r.kernel_name(): {"mpixels_per_s": round(px / (spec_ms * 1e-3) / 1e6, 1), "kernel_ms_avg": round(spec_ms, 4)}}
     ri = gpu.Renderer(torch.cuda.current_device(), specialize=4 if r.kernel_name() == "lol_render_spec" else 1)
     try:
         ri.prepare(sc)
+        if ri.kernel_name() == r.kernel_name():
+            # LOL_GPU_SPECIALIZE=0 (or a failed hipRTC) forces both renderers onto the same kernel: nothing to compare
+            out["note"] = f"the second renderer runs {ri.kernel_name()} too (LOL_GPU_SPECIALIZE / hipRTC): no second kernel timed"
+            return out
         buf = torch.zeros_like(spec_frame)
         ri.render_into(buf.data_ptr(), w, h, max_steps, stream=stream, frame_camera=fc)      # warm-up
         ev = []
@@ -186,6 +207,130 @@ def launch_ranks(n: int, argv: list) -> int:
         return proc.wait()
 
 
+def host_surface_rates(r, sc, cfg, cams, frames: int = 12):
+    """Through the boundary the reference's host uses (naive_renderer.c:233-235: surf->pixels is HOST memory): whole
+    frames into a pitched host surface, synchronously per frame (what render_thread does) in each host mode, and
+    with two frames in flight (lol_gpu_render_host_begin / _end).  Wall-clock, never part of `value`."""
+    w, h, ms = cfg["w"], cfg["h"], cfg["max_steps"]
+    pitch = (w + 16) * 4
+    surf = np.zeros(h * pitch, dtype=np.uint8)
+    cam_list = [sc.c.camera] if cams is None else cams
+    out = {"pitch_bytes": pitch, "frames": frames}
+
+    def rate(dt):
+        return round(frames * w * h / dt / 1e6, 1)
+
+    for name, mode in (("direct", gpu.HOST_DIRECT), ("copy", gpu.HOST_COPY), ("pageable", gpu.HOST_PAGEABLE)):
+        r.set_host_mode(mode)
+        for i in range(3):
+            r.render_host(surf.ctypes.data, w, h, ms, camera=cam_list[i % len(cam_list)], pitch_bytes=pitch)
+        t0 = time.perf_counter()
+        for i in range(frames):
+            r.render_host(surf.ctypes.data, w, h, ms, camera=cam_list[i % len(cam_list)], pitch_bytes=pitch)
+        out[f"sync_{name}_mpixels_per_s"] = rate(time.perf_counter() - t0)
+        out[f"sync_{name}_mode_used"] = ("direct", "copy", "pageable")[r.host_mode_used()]
+    for name, mode in (("pinned", gpu.HOST_COPY), ("pageable", gpu.HOST_PAGEABLE)):
+        r.set_host_mode(mode)
+        r.render_host_begin(w, h, ms, camera=cam_list[0])
+        r.render_host_begin(w, h, ms, camera=cam_list[1 % len(cam_list)])
+        r.render_host_end(surf.ctypes.data, pitch, w, h)
+        t0 = time.perf_counter()
+        for i in range(frames):
+            r.render_host_begin(w, h, ms, camera=cam_list[(i + 2) % len(cam_list)])
+            r.render_host_end(surf.ctypes.data, pitch, w, h)
+        out[f"pipelined_{name}_mpixels_per_s"] = rate(time.perf_counter() - t0)
+        r.render_host_end(surf.ctypes.data, pitch, w, h)
+    r.set_host_mode(gpu.HOST_DIRECT)
+    out["host_surface_mpixels_per_s"] = {"sync": out["sync_direct_mpixels_per_s"], "pipelined": out["pipelined_pinned_mpixels_per_s"]}
+    return out
+
+
+def root_share_candidates(world: int):
+    """(parts_per_rank, root_parts) splits to try, by LOL_BENCH_ROOT_SHARE: `equal` = one part per rank;
+    `k` = the root takes part in k of LOL_BENCH_PARTS_PER_RANK (default 8) rounds; `auto` (default) = the equal split
+    and a few weighted ones, timed during set-up (main)."""
+    mode = os.environ.get("LOL_BENCH_ROOT_SHARE", "auto")
+    per = max(1, min(int(os.environ.get("LOL_BENCH_PARTS_PER_RANK", "8")), 64 // world))
+    if world == 1 or mode == "equal":
+        return [(1, 1)]
+    if mode != "auto":
+        k = int(mode)
+        if not 0 <= k <= per:
+            raise SystemExit(f"LOL_BENCH_ROOT_SHARE={mode}: want auto, equal or 0..{per}")
+        return [(per, k)]
+    return [(1, 1)] + [(per, k) for k in range(per - 1, max(per - 4, 0), -1)]
+
+
+def run_cabi(args, record_fd):
+    """--transport cabi: ONE process, N devices behind lol_gpu_multi_* (lol_multi.hip) — what the reference's C host
+    reaches through hip_renderer --devices: every device renders its bands, one grouped ncclSend/ncclRecv brings the
+    parts to devices[0], the library's assembly kernel un-interleaves them.  Same workload, timing and record as the
+    one-process-per-GPU transport."""
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: there is no CPU rendering path")
+    n = args.gpus
+    if torch.cuda.device_count() < n:
+        raise SystemExit(f"--transport cabi --gpus {n}: only {torch.cuda.device_count()} device(s) visible")
+    name = args.workload or ("c3" if n == 1 else "c4")
+    if name == "orbit":
+        raise SystemExit("--transport cabi renders whole frames over all devices; the orbit stripes frames over ranks")
+    cfg = WORKLOADS[name]
+    w, h, max_steps = cfg["w"], cfg["h"], cfg["max_steps"]
+    sc = S.Scene.parse_file(os.path.join(ROOT, "tests", "golden", "scenes", cfg["scene"] + ".lol"))
+    m = gpu.MultiRenderer(list(range(n)))
+    m.prepare(sc)
+    torch.cuda.set_device(0)
+    frames = [torch.zeros((h, w), dtype=torch.int32, device="cuda:0") for _ in range(2)]
+    fc = sc.frame_camera(w, h)
+
+    def run(k):
+        for i in range(k):
+            m.render_into(frames[i % 2].data_ptr(), w, h, max_steps, frame_camera=fc)
+        m.sync()
+
+    per_env = os.environ.get("LOL_BENCH_PARTS_PER_DEVICE")
+    trials = []
+    cands = root_share_candidates(n) if per_env is None else [(int(per_env), int(per_env))]
+    best = cands[0]
+    if len(cands) > 1:
+        for per, k in cands:
+            m.set_parts_per_device(per); m.set_root_parts(k)
+            run(4)
+            t0 = time.perf_counter(); run(12); dt = time.perf_counter() - t0
+            trials.append({"parts_per_device": per, "root_parts": k, "ms_per_frame": round(dt / 12 * 1e3, 4)})
+        best = min(zip(cands, trials), key=lambda ct: ct[1]["ms_per_frame"])[0]
+    m.set_parts_per_device(best[0]); m.set_root_parts(best[1])
+    run({"c2": 400, "c3": 100, "c4": 32}[name])
+    run(args.warmup)
+    t0 = time.perf_counter()
+    run(args.steps)
+    dt = time.perf_counter() - t0
+    check = None
+    if os.environ.get("LOL_BENCH_CHECK") == "1":
+        r1 = gpu.Renderer(0)
+        r1.prepare(sc)
+        ref = torch.zeros((h, w), dtype=torch.int32, device="cuda:0")
+        r1.render_into(ref.data_ptr(), w, h, max_steps, frame_camera=fc)
+        r1.sync()
+        check = bool(torch.equal(ref, frames[(args.steps - 1) % 2]))
+        print(f"[check] assembled {n}-device frame == single-launch frame: {check}", file=sys.stderr, flush=True)
+        r1.close()
+        assert check
+    out = {
+        "metric": f"Mpixels/s at {w}x{h}, <={max_steps} march steps; max |pixel delta| vs naive_renderer.c",
+        "value": round(args.steps * w * h / dt / 1e6, 2), "unit": "Mpixels/s", "n_gpus": n, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{name}: tests/golden/scenes/{cfg['scene']}.lol {w}x{h}, {max_steps} march steps, rows in bands "
+                               f"over {n} device(s) of ONE process (lol_gpu_multi_*: RCCL send/recv group to device 0 + assembly kernel)",
+                   "width": w, "height": h, "max_steps": max_steps, "transport": "cabi",
+                   "parts_per_device": best[0], "root_parts": best[1], "kernel": m.kernel_name()},
+        "root_share_trials": trials or None, "frame_equal_to_single_launch": check,
+    }
+    os.write(record_fd, (json.dumps(out) + "\n").encode())
+    m.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -194,7 +339,15 @@ def main():
     ap.add_argument("--workload", default=None, choices=list(WORKLOADS))
     ap.add_argument("--band-rows", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--transport", default="dist", choices=["dist", "cabi"])
+    ap.add_argument("--emulate-root-of", type=int, default=0, metavar="N")
     args = ap.parse_args()
+
+    if args.transport == "cabi":
+        sys.stdout.flush()
+        record_fd = os.dup(1)
+        os.dup2(2, 1)                                 # RCCL's banner must not reach stdout (see below)
+        return run_cabi(args, record_fd)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # `python bench.py --gpus N`: this process becomes the launcher.  It starts the N ranks as CHILD
@@ -232,7 +385,10 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    name = args.workload or ("c3" if world == 1 else "c4")
+    emulate = args.emulate_root_of
+    if emulate and (world != 1 or emulate < 2):
+        raise SystemExit("--emulate-root-of N wants N >= 2 and ONE process (it plays rank 0 of an N-rank run on one GPU)")
+    name = args.workload or ("c3" if world == 1 and not emulate else "c4")
     cfg = WORKLOADS[name]
     w, h, max_steps = cfg["w"], cfg["h"], cfg["max_steps"]
     sc = S.Scene.parse_file(os.path.join(ROOT, "tests", "golden", "scenes", cfg["scene"] + ".lol"))
@@ -253,56 +409,101 @@ def main():
         torch.cuda.synchronize()
 
     orbit = name == "orbit"
-    if orbit:
-        band, rows, n_local = h, None, h
-        frames_total = cfg["frames"]
-        my_frames = list(range(rank, frames_total, world))
-        cams = [sc.frame_camera(w, h, orbit_camera(i, frames_total)) for i in my_frames]
-    else:
-        band = args.band_rows or (multi.choose_band_rows(h, world) if world > 1 else h)
-        if world > 1 and (band <= 0 or h % (band * world)):
-            raise SystemExit(f"cannot split {h} rows evenly over {world} ranks")
-        rows = gpu.Rows(band, world, rank) if world > 1 else None
-        n_local = gpu.part_rows(h, rows)
-        cams = [sc.frame_camera(w, h)]
-
+    if orbit and emulate:
+        raise SystemExit("--emulate-root-of renders whole frames")
     # N>1: two frames in flight per rank — frame i's gather overlaps frame i+1's kernel (multi.GatherPipeline).
     depth = max(1, int(os.environ.get("LOL_BENCH_PIPELINE_DEPTH", "2")))     # 1 = gather each frame before the next renders
     # LOL_BENCH_FORCE_PIPE=1 under a 1-rank torchrun: exercise the real backend's gather path on one device
-    force_pipe = os.environ.get("LOL_BENCH_FORCE_PIPE") == "1" and not orbit
+    force_pipe = (os.environ.get("LOL_BENCH_FORCE_PIPE") == "1" or bool(emulate)) and not orbit
     if force_pipe and world == 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    pipe = (multi.GatherPipeline(w, h, band if not orbit else h, dev, depth=depth, force_collective=force_pipe)
-            if ((world > 1 or force_pipe) and not orbit) else None)
-    local = torch.zeros((n_local, w), dtype=torch.int32, device=dev) if pipe is None else None
+    piped = (world > 1 or force_pipe) and not orbit
+
+    def assembler(staging, frame, P, stream_handle):
+        """the root's un-interleave: the library's uint4 kernel on the assembly stream (lol_gpu_assemble_parts_at)"""
+        gpu.assemble_parts_at(r, staging.data_ptr(), P.part_row0, P.band, w, h, frame.data_ptr(), w * 4, stream_handle)
+
+    if os.environ.get("LOL_BENCH_ASSEMBLE") == "torch":     # A/B: the round-2 torch index copy instead
+        assembler = None
 
     kernel_ms = []
+    state = {"P": None, "pipe": None}
+
+    def make_pipeline(per_rank, root_parts):
+        P = multi.Partition(h, emulate or world, per_rank, root_parts, args.band_rows)
+        state["P"] = P
+        state["pipe"] = multi.GatherPipeline(w, h, P.band, dev, depth=depth, force_collective=force_pipe, partition=P,
+                                             assembler=assembler)
+
+    if orbit:
+        frames_total = cfg["frames"]
+        my_frames = list(range(rank, frames_total, world))
+        cams = [sc.frame_camera(w, h, orbit_camera(i, frames_total)) for i in my_frames]
+    else:
+        cams = [sc.frame_camera(w, h)]
+    local = torch.zeros((h, w), dtype=torch.int32, device=dev) if not piped else None
 
     def launch(dst_tensor, fc, timed):
+        P = state["P"]
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        r.render_into(dst_tensor.data_ptr(), w, h, max_steps, rows=rows, stream=stream, frame_camera=fc)
+        if P is None:
+            r.render_into(dst_tensor.data_ptr(), w, h, max_steps, stream=stream, frame_camera=fc)
+        else:
+            for p in P.parts_of[rank]:               # one launch per part this rank owns, back to back in its buffer
+                if P.rows_of[p]:
+                    r.render_into(dst_tensor.data_ptr() + P.local_row0[p] * w * 4, w, h, max_steps,
+                                  rows=gpu.Rows(P.band, P.n_parts, p), stream=stream, frame_camera=fc)
         if timed:
             e1.record()
             kernel_ms.append((e0, e1))
 
     def step(i, timed):
         fc = cams[i % len(cams)]
-        if pipe is None:
+        if not piped:
             launch(local, fc, timed)
         else:
-            pipe.submit(lambda part: launch(part, fc, timed))
+            state["pipe"].submit(lambda part: launch(part, fc, timed))
 
     def fence():
-        if pipe is not None:
-            pipe.drain()
+        if state["pipe"] is not None:
+            state["pipe"].drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # Set-up: the split.  The root's extra work (receiving 7/8 of the frame, un-interleaving all of it) depends on the
+    # machine, so `auto` measures instead of guessing: a few frames of each candidate, slowest rank's time, keep the best.
+    trials = []
+    if piped:
+        cands = root_share_candidates(emulate or world)
+        if emulate and len(cands) > 1:
+            cands = cands[:2]                         # one GPU cannot rank the splits: the equal one and the first weighted
+            cands = [cands[1]] if os.environ.get("LOL_BENCH_ROOT_SHARE", "auto") == "auto" else cands[:1]
+        best = cands[0]
+        if len(cands) > 1:
+            for per, k in cands:
+                make_pipeline(per, k)
+                for i in range(4):
+                    step(i, False)
+                fence()
+                t0 = time.perf_counter()
+                for i in range(16):
+                    step(i, False)
+                fence()
+                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+                if world > 1:
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                trials.append({"parts_per_rank": per, "root_parts": k, "ms_per_frame": round(float(t.item()) / 16 * 1e3, 4)})
+                state["pipe"] = None
+            # every rank holds the same all-reduced times, so every rank picks the same split
+            best = min(zip(cands, trials), key=lambda ct: ct[1]["ms_per_frame"])[0]
+        make_pipeline(*best)
+    pipe, P = state["pipe"], state["P"]
 
     steps = args.steps
     if orbit:
@@ -310,16 +511,19 @@ def main():
     # Set-up, not measurement: keep the device busy for about a quarter of a second so that the clocks have ramped before
     # the W warm-up steps — the timed region of the default run is only ~40 ms, and a cold start moved it by several %.
     # A fixed frame count per workload (every rank issues the same number of gathers), none for the 256-frame orbit.
-    prewarm = 0 if orbit else {"c2": 400, "c3": 100, "c4": 32 * world}[name]
+    prewarm = 0 if orbit else {"c2": 400, "c3": 100, "c4": 32 * max(world, emulate)}[name]
     for i in range(prewarm):
         step(i, False)
     fence()
     for i in range(args.warmup):
         step(i, False)
     fence()
+    host_s = 0.0
     t0 = time.perf_counter()
     for i in range(steps):
+        th = time.perf_counter()
         step(i, True)
+        host_s += time.perf_counter() - th            # host time spent issuing the frame (launches, gather, assembly)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -328,7 +532,7 @@ def main():
         dt = float(t.item())
     if force_pipe and world == 1 and rank == 0:
         print("[force-pipe] 1-rank nccl gather path completed", file=sys.stderr, flush=True)
-    if os.environ.get("LOL_BENCH_CHECK") == "1" and pipe is not None:
+    if os.environ.get("LOL_BENCH_CHECK") == "1" and pipe is not None and not emulate:
         # correctness rehearsal: the assembled frame on rank 0 must equal a single-launch render of the frame
         final = pipe.drain()
         if rank == 0:
@@ -354,7 +558,8 @@ def main():
 
     k_ms = [a.elapsed_time(b) for a, b in kernel_ms]
     k_avg = sum(k_ms) / max(len(k_ms), 1)
-    px_per_launch = n_local * w
+    px_per_launch = (P.rank_rows[rank] if P is not None else h) * w      # pixels this rank renders per frame
+    launches_per_frame = len([p for p in P.parts_of[rank] if P.rows_of[p]]) if P is not None else 1
     if orbit:
         total_px = cfg["frames"] * w * h              # all ranks together render each frame once
         steps_reported = cfg["frames"]
@@ -365,33 +570,48 @@ def main():
 
     if rank == 0:
         achieved = px_per_launch * BYTES_PER_PIXEL / (k_avg * 1e-3) / 1e9
+        traffic, traffic_source = pmc_traffic(r.kernel_name(), name, px_per_launch, r.kernel_key())
+        band = P.band if P is not None else h
         out = {
-            "metric": "Mpixels/s at 3840x2160, <=256 march steps; max |pixel delta| vs naive_renderer.c",
+            "metric": f"Mpixels/s at {w}x{h}, <={max_steps} march steps; max |pixel delta| vs naive_renderer.c",
             "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": steps_reported,
             "warmup": args.warmup, "ms_per_step": round(dt / steps_reported * 1e3, 4), "higher_is_better": True,
             "scaling": "weak" if orbit else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{name}: tests/golden/scenes/{cfg['scene']}.lol {w}x{h}, {max_steps} march steps"
                                    + (f", {cfg['frames']}-frame orbit striped over ranks" if orbit else
-                                      (f", rows in bands of {band} interleaved over {world} ranks + RCCL gather to rank 0"
-                                       if world > 1 else ", one kernel launch per frame")),
+                                      (f", rows in bands of {band} dealt over {P.n_parts} parts / {P.world} ranks + RCCL gather to rank 0"
+                                       if P is not None else ", one kernel launch per frame")),
                        "width": w, "height": h, "max_steps": max_steps, "band_rows": band,
-                       "kernel": r.kernel_name()},
+                       "kernel": r.kernel_name(), "kernel_key": r.kernel_key(), "transport": "dist"},
             # what the process group really is: ranks seen by torch.distributed and its backend ("nccl" = RCCL)
             "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
             "backend": dist.get_backend() if dist.is_initialized() else None,
             "gather_ms": gather_ms,
+            "partition": P.describe() if P is not None else None,
+            "root_share_trials": trials or None,
+            "assembly": None if pipe is None else ("lol_gpu_assemble_parts_at (library kernel, own stream)" if assembler else "torch index_select"),
+            "host_issue_us_per_frame": round(host_s / max(steps, 1) * 1e6, 1),
             "prewarm_frames": prewarm,            # untimed set-up frames before the W warm-up steps (clock ramp)
             "parity_checker": "oracle/lol_oracle.c — the CPU restatement of naive_renderer.c (DESIGN.md §5)",
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 6),
-                         "traffic": pmc_traffic(r.kernel_name(), name, px_per_launch),
-                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command, "
-                                           "tools/pmc_summary.py; not re-measured in this run)",
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes": px_per_launch * BYTES_PER_PIXEL,
                          "kernel_ms_avg": round(k_avg, 4), "pixels_per_launch": px_per_launch,
+                         "launches_per_frame": launches_per_frame,
                          "bytes_per_pixel": BYTES_PER_PIXEL,
                          "note": "north_star names the HBM-write roofline; the path is FP32-VALU-bound, see `valu`"},
         }
+        if emulate:
+            # not a benchmark line: ONE GPU playing rank 0 of an N-rank run.  `ms_per_step` is the root's cadence —
+            # its share of the kernels + the gather through RCCL (1 rank: the self-copy) + the whole-frame assembly.
+            out["metric"] = f"EMULATION: cadence of rank 0 of a {emulate}-rank {name} run, on one GPU (ms per frame)"
+            out["value"] = round(dt / steps * 1e3, 4)
+            out["unit"] = "ms/frame"
+            out["higher_is_better"] = False
+            out["emulated_world"] = emulate
+            out["root_kernel_ms"] = round(k_avg, 4)
+            out["implied_mpixels_per_s_if_root_is_the_critical_path"] = round(w * h / (dt / steps) / 1e6, 1)
         if world == 1 and not orbit and local is not None:       # (local is None in the 1-rank gather rehearsal)
             out["kernels"] = both_kernels(r, sc, local, w, h, max_steps, cams[0], stream, k_avg, px_per_launch)
         if world == 1 and not args.no_cpu_baseline and not orbit and local is not None:
@@ -403,6 +623,10 @@ def main():
             out["valu"] = {"flops_per_pixel": round(fpp, 1), "sdf_evals_per_pixel": round(ctr.sdf_evals / ctr.pixels, 2),
                            "achieved": round(tops, 3), "peak": VALU_PEAK_TOPS, "unit": "Tops/s (unfused FP32)",
                            "frac": round(tops / VALU_PEAK_TOPS, 4)}
+        if world == 1 and local is not None and os.environ.get("LOL_BENCH_HOST_SURFACE", "1") != "0":
+            torch.cuda.synchronize()
+            hs_cams = [orbit_camera(i, 256) for i in range(0, 256, 16)] if orbit else None
+            out["host_surface"] = host_surface_rates(r, sc, cfg, hs_cams)
         sys.stdout.flush()
         os.write(record_fd, (json.dumps(out) + "\n").encode())
 

@@ -56,7 +56,24 @@ typedef struct lol_gpu_rows {
 	int32_t band_rows;
 	int32_t n_parts;
 	int32_t part;
+	int32_t in_place;   /* 0: the part is stored compactly (above); 1: `dst` is the whole frame and every row of the part
+	                     * lands at its frame position — what a part written straight into a shared surface needs */
 } lol_gpu_rows;
+
+/*
+ * How a colour becomes a pixel: SDL_MapRGB(surf->format, r, g, b) of renderer.h:17-22 for a non-palettised format
+ * (SDL2, src/video/SDL_pixels.c):  (r >> Rloss) << Rshift | (g >> Gloss) << Gshift | (b >> Bloss) << Bshift | Amask.
+ * The fields are SDL_PixelFormat's.  The reference stores one Uint32 per pixel whatever the format
+ * (naive_renderer.c:233-235), so only 4-byte formats make sense; anything else is refused, never approximated.
+ * Default (and NULL): XRGB8888 = shifts 16 / 8 / 0, no loss, Amask 0.
+ */
+typedef struct lol_gpu_pixel_format {
+	uint8_t  r_shift, g_shift, b_shift;
+	uint8_t  r_loss, g_loss, b_loss;
+	uint8_t  bytes_per_pixel;     /* must be 4 */
+	uint8_t  palettised;          /* must be 0 (format->palette != NULL) */
+	uint32_t a_mask;
+} lol_gpu_pixel_format;
 
 /* Optional per-pixel diagnostics, all device pointers, each may be NULL.
  * Indexed by local row like the pixel destination, `w` elements per row. */
@@ -79,8 +96,14 @@ int  lol_gpu_device(const lol_gpu* ctx);          /* the HIP device ordinal of a
 
 /* Copy the flattened scene (lol_scene_flatten) to the device.  May be called
  * again at any time (it first waits for everything queued on the device);
- * frames issued afterwards use the new program. */
+ * frames issued afterwards use the new program.  All or nothing: when it fails
+ * (malformed or oversized program, a failed copy) the context keeps rendering
+ * the scene it had. */
 int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog);
+
+/* Pixel format of every frame launched afterwards (NULL = XRGB8888).  LOL_GPU_ERR_UNSUPPORTED for palettised or
+ * non-32-bit formats and shifts / losses that do not describe 8-bit channels in a 32-bit word. */
+int lol_gpu_set_pixel_format(lol_gpu* ctx, const lol_gpu_pixel_format* fmt);
 
 /* Number of local rows a part owns (for sizing destinations). */
 int lol_gpu_part_rows(int h, const lol_gpu_rows* rows);
@@ -100,11 +123,32 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 
 /*
  * Whole frame into a HOST surface (what render_thread does with surf->pixels,
- * naive_renderer.c:233-235): renders into the context's device framebuffer,
- * copies `h` rows of w*4 bytes honouring `pitch_bytes`, and waits.
+ * naive_renderer.c:233-235), honouring `pitch_bytes`; returns when the surface holds the frame.
+ *
+ * The surface is page-locked and mapped for the device on first sight (lol_gpu_pin_host below; kept while the host
+ * keeps handing the same memory, re-done when pointer or size change — main.c:182-187 re-fetches the surface every
+ * frame).  Then, by LOL_GPU_HOST_MODE / lol_gpu_set_host_mode:
+ *   "direct" (default)  the kernel stores its pixels straight into the mapped surface — no device framebuffer, no copy;
+ *   "copy"              device framebuffer + one asynchronous pitched copy into the pinned surface;
+ *   "pageable"          the same copy without pinning (what a surface that cannot be pinned falls back to).
  */
 int lol_gpu_render_host(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h, int max_steps,
                         void* host_pixels, size_t pitch_bytes);
+enum { LOL_GPU_HOST_DIRECT = 0, LOL_GPU_HOST_COPY = 1, LOL_GPU_HOST_PAGEABLE = 2 };
+int lol_gpu_set_host_mode(lol_gpu* ctx, int mode);
+/* the mode the last host-surface frame really used (a surface that could not be pinned is copied pageable) */
+int lol_gpu_host_mode_used(const lol_gpu* ctx);
+
+/*
+ * Page-lock [ptr, ptr + bytes) and map it for every device (hipHostRegister, portable + mapped); process-wide,
+ * remembered by address range, at most four ranges (the oldest is released).  Returns 0 and the address the
+ * CURRENT device uses for `ptr` in *dev_ptr (may be NULL), or LOL_GPU_ERR_HIP when the memory cannot be registered.
+ * The host-surface entry points call this themselves; a host that frees its surface while the library is alive
+ * may call lol_gpu_unpin_host(ptr) first (not required: a range that changes size or moves is re-registered, and the
+ * kernel driver tracks unmapped ranges).  LOL_GPU_PIN_HOST=0 turns pinning off.
+ */
+int lol_gpu_pin_host(void* ptr, size_t bytes, void** dev_ptr);
+int lol_gpu_unpin_host(void* ptr);        /* ptr = NULL: every range */
 
 /*
  * The same with two frames in flight, for hosts that can give the next frame's camera before they consume the
@@ -113,10 +157,17 @@ int lol_gpu_render_host(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h,
  * begin() queues the frame's kernel and returns; end() copies the OLDEST queued frame into the host surface and
  * waits for that copy — which runs while the next frame's kernel does (main.c:182-194 is the loop this overlaps).
  * At most two frames may be begun and not yet ended; lol_gpu_render_host_pending() says how many are.
+ *
+ * The surface may change size between begin() and end() (the reference's window is resizable, main.c:157,182-187):
+ * end() takes the size of the surface it is given and refuses (LOL_GPU_ERR_ARG, nothing written, frame kept) a frame
+ * of another size; lol_gpu_render_host_pending_size() tells the size of the oldest queued frame beforehand and
+ * lol_gpu_render_host_discard() drops every queued frame.  Frames of different sizes may be in flight together.
  */
 int lol_gpu_render_host_begin(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h, int max_steps);
-int lol_gpu_render_host_end(lol_gpu* ctx, void* host_pixels, size_t pitch_bytes);
+int lol_gpu_render_host_end(lol_gpu* ctx, void* host_pixels, size_t pitch_bytes, int w, int h);
 int lol_gpu_render_host_pending(const lol_gpu* ctx);
+int lol_gpu_render_host_pending_size(const lol_gpu* ctx, int* w, int* h);   /* 0 x 0 when nothing is queued */
+int lol_gpu_render_host_discard(lol_gpu* ctx);
 
 /* Wait for everything issued on the context's own stream. */
 int lol_gpu_sync(lol_gpu* ctx);
@@ -129,6 +180,10 @@ int lol_gpu_memcpy_d2h(lol_gpu* ctx, void* host, const void* dev, size_t bytes);
 /* Name of the kernel a launch uses (for matching rocprofv3 kernel-trace rows):
  * "lol_render_spec" (scene-specialised, compiled by hipRTC at upload) or "render_interp". */
 const char* lol_gpu_kernel_name(const lol_gpu* ctx);
+/* Identity of the code that kernel is: 16 hex digits — FNV-1a of the hipRTC code object for "lol_render_spec", of the
+ * pipeline source this library was built from for "render_interp".  Profiles record it (profiles/pmc_traffic.json) so
+ * that a counter figure is only ever quoted for the code it was measured on. */
+const char* lol_gpu_kernel_key(const lol_gpu* ctx);
 
 /*
  * Scene specialisation (the GPU analogue of the reference's tracing JIT, whose render_prepare
@@ -238,15 +293,29 @@ int  lol_gpu_part_frame_row(int h, const lol_gpu_rows* rows, int local_row);
 int  lol_gpu_multi_render_device(lol_gpu_multi* m, const lol_frame_camera* cam, int w, int h, int max_steps,
                                  void* dst, size_t pitch_bytes);
 /* What render_thread does with surf->pixels: one frame over all devices into a HOST surface; waits.  No exchange is
- * needed for this: every device copies its own bands straight into the surface (one strided copy per part), so N
- * devices use N PCIe links in parallel.  set_host_via_root(m, 1) (or LOL_GPU_MULTI_HOST_VIA_ROOT=1) instead assembles
- * on the root with the RCCL exchange and copies from there. */
+ * needed for this: the surface is pinned and mapped for every device (lol_gpu_pin_host) and every device writes its
+ * own bands into it — its kernels store straight into the surface (host mode "direct", the default) or its copy
+ * stream copies its parts there (one strided asynchronous copy per part, host mode "copy"), all devices at once, each
+ * over its own PCIe link.  set_host_via_root(m, 1) (or LOL_GPU_MULTI_HOST_VIA_ROOT=1) instead assembles on the root
+ * with the RCCL exchange and copies from there. */
 int  lol_gpu_multi_render_host(lol_gpu_multi* m, const lol_frame_camera* cam, int w, int h, int max_steps,
                                void* host_pixels, size_t pitch_bytes);
 int  lol_gpu_multi_set_host_via_root(lol_gpu_multi* m, int enable);
-/* Parts per device (default 1): device d owns parts d, d + n, d + 2n, … of n * parts.  Finer interleaving of the rows,
- * and the way a single-GPU machine exercises the multi-part code paths.  n * parts <= 64. */
+int  lol_gpu_multi_set_host_mode(lol_gpu_multi* m, int mode);          /* LOL_GPU_HOST_* for every device */
+int  lol_gpu_multi_set_pixel_format(lol_gpu_multi* m, const lol_gpu_pixel_format* fmt);
+/* Parts per device (default 1): the frame's bands are dealt over n_parts parts and the parts over the devices, `parts`
+ * rounds of one part per device (lol_gpu_deal_parts).  Finer interleaving of the rows, the unit of the root's smaller
+ * share below, and the way a single-GPU machine exercises the multi-part code paths.  n * parts <= 64. */
 int  lol_gpu_multi_set_parts_per_device(lol_gpu_multi* m, int parts);
+/* The cost-weighted split: the root (devices[0]) also receives and un-interleaves the whole frame, so with an equal
+ * share it finishes last.  root_parts in [0, parts_per_device] (default = parts_per_device, equal shares) is how many
+ * of the rounds the root takes part in: its share of the rows is root_parts / ((n - 1) * parts + root_parts). */
+int  lol_gpu_multi_set_root_parts(lol_gpu_multi* m, int root_parts);
+/* The dealing itself, pure host logic: owner[p] = device index (0 = root) of part p; returns the number of parts
+ * (n_devices - 1) * per_dev + root_parts (one device: per_dev), or a negative status.  owner may be NULL. */
+int  lol_gpu_deal_parts(int n_devices, int per_dev, int root_parts, int* owner, int cap);
+/* Band height for such a deal: the multiple of 4 up to 16 that leaves the busiest device the fewest rows. */
+int  lol_gpu_choose_band_rows_for(int h, const int* owner, int n_parts, int n_devices);
 int  lol_gpu_multi_sync(lol_gpu_multi* m);
 /* Memory on the root device (for destinations of lol_gpu_multi_render_device). */
 int  lol_gpu_multi_malloc(lol_gpu_multi* m, size_t bytes, void** out);
@@ -260,6 +329,10 @@ int  lol_gpu_multi_memcpy_d2h(lol_gpu_multi* m, void* host, const void* dev, siz
  */
 int  lol_gpu_assemble_parts(lol_gpu* ctx, const void* parts, int n_parts, int band_rows, int w, int h,
                             void* dst, size_t pitch_bytes, void* stream);
+/* The same for parts that do not lie back to back in part order (gathered per rank, padded to a common size, several
+ * parts per rank): part_row0[p] = the row of `parts` (w pixels per row) where part p starts. */
+int  lol_gpu_assemble_parts_at(lol_gpu* ctx, const void* parts, const uint32_t* part_row0, int n_parts, int band_rows,
+                               int w, int h, void* dst, size_t pitch_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -10,10 +10,15 @@
  *                   flatten the scene, upload it.  Renderer flags start at
  *                   argv[3] (main.c:223-242): --device N (one GPU),
  *                   --pipeline (one GPU: the copy of frame i into the surface runs
- *                   under frame i+1's kernel; the surface then shows frame i-1),
+ *                   under frame i+1's kernel; the surface then shows frame i-1;
+ *                   the first frame, and the first one after the window changed
+ *                   size, are delivered at once),
  *                   --devices A,B,... (the frame's rows are dealt in bands over
- *                   these GPUs and the parts gathered with RCCL on the first one,
- *                   include/lol_gpu.h lol_gpu_multi_*), --max-steps N, and
+ *                   these GPUs, each writing its bands into the surface,
+ *                   include/lol_gpu.h lol_gpu_multi_*), --parts-per-device N,
+ *                   --root-parts N (the first device's smaller share),
+ *                   --host-mode direct|copy|pageable (how pixels reach
+ *                   surf->pixels, lol_gpu_render_host), --max-steps N, and
  *                   --dump-kernel BASE, the counterpart of the JIT renderer's
  *                   -j/--jitdump (tracing_jit_renderer.dasc:424-433): writes the
  *                   scene-specialised kernel as BASE.hip (generated source) and
@@ -47,12 +52,32 @@ struct hip_renderer {
 	int         max_steps;      /* MAX_STEPS, naive_renderer.c:49 */
 	int         pipeline;       /* --pipeline: frame i's copy into the surface overlaps frame i+1's kernel (one frame of latency) */
 	int         ready;
+	int         have_format;    /* the surface's pixel format has been handed to the library ... */
+	lol_gpu_pixel_format format;/* ... and was this */
+	int         format_refused; /* ... or was refused (reported once) */
 };
+
+/* surf->format → the library (colorf_to_pixfmt maps through the SURFACE's format, renderer.h:17-22; the host re-fetches
+ * the surface every frame, main.c:182).  Returns 0 when this format cannot be rendered. */
+static int sync_format(struct hip_renderer* r, host_surface* surf) {
+	lol_gpu_pixel_format f;
+	memset(&f, 0, sizeof f);
+	HOST_SURF_FORMAT(surf, &f);
+	if (r->have_format && !memcmp(&f, &r->format, sizeof f)) return !r->format_refused;
+	int st = r->multi ? lol_gpu_multi_set_pixel_format(r->multi, &f) : lol_gpu_set_pixel_format(r->gpu, &f);
+	r->have_format = 1;
+	r->format = f;
+	r->format_refused = st != LOL_GPU_OK;
+	if (st != LOL_GPU_OK)
+		fprintf(stderr, "hip_renderer: %s\n", r->multi ? lol_gpu_multi_error(r->multi) : lol_gpu_error(r->gpu));
+	return st == LOL_GPU_OK;
+}
 
 void render_prepare(struct render_data* data, int argc, const char* argv[]) {
 	struct hip_renderer* r = calloc(1, sizeof *r);
 	int device = 0;
 	int devices[LOL_GPU_MULTI_MAX_DEVICES], n_devices = 0;
+	int parts_per_device = 0, root_parts = -1, host_mode = -1;
 	const char* dump = NULL;
 	HOST_PRIVATE(data) = r;
 	if (!r) { fprintf(stderr, "hip_renderer: out of memory\n"); return; }
@@ -60,14 +85,22 @@ void render_prepare(struct render_data* data, int argc, const char* argv[]) {
 	for (int i = 3; i < argc; i++) {
 		const int is_device = !strcmp(argv[i], "--device"), is_devices = !strcmp(argv[i], "--devices");
 		const int is_steps = !strcmp(argv[i], "--max-steps"), is_dump = !strcmp(argv[i], "--dump-kernel");
+		const int is_ppd = !strcmp(argv[i], "--parts-per-device"), is_root = !strcmp(argv[i], "--root-parts");
+		const int is_mode = !strcmp(argv[i], "--host-mode");
 		if (!strcmp(argv[i], "--pipeline")) { r->pipeline = 1; continue; }
-		if (!(is_device || is_devices || is_steps || is_dump)) continue;      /* the host's own flags */
+		if (!(is_device || is_devices || is_steps || is_dump || is_ppd || is_root || is_mode)) continue;      /* the host's own flags */
 		if (i + 1 >= argc) { fprintf(stderr, "hip_renderer: %s needs a value, ignored\n", argv[i]); break; }
 		const char* v = argv[++i];
 		if (is_device) device = atoi(v);
 		else if (is_steps) r->max_steps = atoi(v);
 		else if (is_dump) dump = v;
-		else {
+		else if (is_ppd) parts_per_device = atoi(v);
+		else if (is_root) root_parts = atoi(v);
+		else if (is_mode) {
+			host_mode = !strcmp(v, "direct") ? LOL_GPU_HOST_DIRECT : !strcmp(v, "copy") ? LOL_GPU_HOST_COPY :
+			            !strcmp(v, "pageable") ? LOL_GPU_HOST_PAGEABLE : -1;
+			if (host_mode < 0) fprintf(stderr, "hip_renderer: --host-mode wants direct, copy or pageable\n");
+		} else {
 			n_devices = 0;
 			for (const char* p = v; *p && n_devices < LOL_GPU_MULTI_MAX_DEVICES;) {
 				char* end;
@@ -97,11 +130,17 @@ void render_prepare(struct render_data* data, int argc, const char* argv[]) {
 	if (n_devices > 0) {
 		st = lol_gpu_multi_create(devices, n_devices, &r->multi);
 		if (st != LOL_GPU_OK) { fprintf(stderr, "hip_renderer: cannot set up %d device(s) (status %d)\n", n_devices, st); return; }
+		if (parts_per_device > 0 && lol_gpu_multi_set_parts_per_device(r->multi, parts_per_device) != LOL_GPU_OK)
+			fprintf(stderr, "hip_renderer: --parts-per-device %d refused\n", parts_per_device);
+		if (root_parts >= 0 && lol_gpu_multi_set_root_parts(r->multi, root_parts) != LOL_GPU_OK)
+			fprintf(stderr, "hip_renderer: --root-parts %d refused\n", root_parts);
+		if (host_mode >= 0) lol_gpu_multi_set_host_mode(r->multi, host_mode);
 		st = lol_gpu_multi_upload_program(r->multi, &r->program);
 		if (st != LOL_GPU_OK) { fprintf(stderr, "hip_renderer: %s\n", lol_gpu_multi_error(r->multi)); return; }
 	} else {
 		st = lol_gpu_create(device, &r->gpu);
 		if (st != LOL_GPU_OK) { fprintf(stderr, "hip_renderer: no usable HIP device %d (status %d)\n", device, st); return; }
+		if (host_mode >= 0) lol_gpu_set_host_mode(r->gpu, host_mode);
 		st = lol_gpu_upload_program(r->gpu, &r->program);
 		if (st != LOL_GPU_OK) { fprintf(stderr, "hip_renderer: %s\n", lol_gpu_error(r->gpu)); return; }
 	}
@@ -124,8 +163,8 @@ int render_thread(void* ptr) {
 			struct hip_renderer* r = HOST_PRIVATE(data);
 			if (!r || !r->ready) {
 				fprintf(stderr, "hip_renderer: not initialised, frame skipped\n");
-			} else if (HOST_SURF_BPP(surf) != 4) {
-				fprintf(stderr, "hip_renderer: only 32-bit surfaces are supported\n");
+			} else if (!sync_format(r, surf)) {
+				/* palettised or not 32 bits per pixel: refused (reported once by sync_format), never approximated */
 			} else {
 				lol_camera cam;
 				lol_frame_camera fc;
@@ -136,10 +175,16 @@ int render_thread(void* ptr) {
 					st = lol_gpu_multi_render_host(r->multi, &fc, width, height, r->max_steps, surf->pixels, (size_t)surf->pitch);
 				} else if (r->pipeline) {
 					/* queue this frame, then deliver the one queued on the previous call: the surface shows frame i-1
-					 * while frame i renders (the very first call delivers nothing and leaves the surface as it is) */
+					 * while frame i renders.  The window is resizable (main.c:157) and the surface is re-fetched every
+					 * frame (main.c:182): a frame queued for another size can never go into this surface — it is
+					 * dropped, and this call's frame is delivered at once instead (so is the very first frame). */
+					int pw = 0, ph = 0;
+					lol_gpu_render_host_pending_size(r->gpu, &pw, &ph);
+					const int fresh = pw != width || ph != height;          /* nothing queued, or queued for another size */
+					if (fresh) lol_gpu_render_host_discard(r->gpu);
 					st = lol_gpu_render_host_begin(r->gpu, &fc, width, height, r->max_steps);
-					if (st == LOL_GPU_OK && lol_gpu_render_host_pending(r->gpu) == 2)
-						st = lol_gpu_render_host_end(r->gpu, surf->pixels, (size_t)surf->pitch);
+					if (st == LOL_GPU_OK && (fresh || lol_gpu_render_host_pending(r->gpu) == 2))
+						st = lol_gpu_render_host_end(r->gpu, surf->pixels, (size_t)surf->pitch, width, height);
 				} else {
 					st = lol_gpu_render_host(r->gpu, &fc, width, height, r->max_steps, surf->pixels, (size_t)surf->pitch);
 				}

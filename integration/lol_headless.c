@@ -5,7 +5,14 @@
  *
  *   lol_headless <threads> <scene.lol> [--size WxH] [--frames N] [--out frame.ppm]
  *                [--orbit] [--keys SCRIPT] [--dump-camera FILE] [--pipeline]
- *                [renderer flags: --device N | --devices A,B,.. --max-steps N]
+ *                [--format NAME] [--resize-script WxH,WxH,..] [--dump-frames PREFIX]
+ *                [renderer flags: --device N | --devices A,B,.. --max-steps N --host-mode M ...]
+ *   --format NAME            pixel format of the surface, as SDL names it: xrgb8888 (default), argb8888, bgrx8888,
+ *                            rgba8888, abgr8888; rgb565 and index8 exist to see the plug-in refuse them
+ *   --resize-script LIST     the window is resizable (main.c:157) and its surface re-fetched every frame (main.c:182):
+ *                            frame i is rendered at the i-th size of the list (the last one repeats); a change of size
+ *                            frees the surface and allocates a new one, as SDL does
+ *   --dump-frames PREFIX     after every frame: PREFIX%04d.raw = "LOLF", w, h (int32), then h rows of w pixels
  *   --keys "W,W,WA,<,<^,."   held keys per frame (W A S D, _ = Space, c = LCtrl, ^ v < > = arrows): the camera is moved
  *                            by main.c's update_camera before every frame, as the windowed host does with key events
  *   --dump-camera FILE       one line per frame: the camera's point and direction as binary32 hex
@@ -38,6 +45,22 @@ sem_t*     frame_exit_barrier;
 
 static void* worker_main(void* arg) { render_thread(arg); return NULL; }
 
+/* SDL_PixelFormat fields of the formats --format knows (SDL_pixels.h: SDL_PIXELFORMAT_*8888 are packed 32-bit) */
+static int format_by_name(const char* name, lol_gpu_pixel_format* f, int* bytes_per_pixel) {
+	static const struct { const char* name; lol_gpu_pixel_format f; } known[] = {
+		{ "xrgb8888", { 16, 8, 0, 0, 0, 0, 4, 0, 0x00000000u } },
+		{ "argb8888", { 16, 8, 0, 0, 0, 0, 4, 0, 0xFF000000u } },
+		{ "bgrx8888", { 8, 16, 24, 0, 0, 0, 4, 0, 0x00000000u } },
+		{ "rgba8888", { 24, 16, 8, 0, 0, 0, 4, 0, 0x000000FFu } },
+		{ "abgr8888", { 0, 8, 16, 0, 0, 0, 4, 0, 0xFF000000u } },
+		{ "rgb565",   { 11, 5, 0, 3, 2, 3, 2, 0, 0x00000000u } },
+		{ "index8",   { 0, 0, 0, 8, 8, 8, 1, 1, 0x00000000u } },
+	};
+	for (size_t i = 0; i < sizeof known / sizeof known[0]; i++)
+		if (!strcmp(name, known[i].name)) { *f = known[i].f; *bytes_per_pixel = known[i].f.bytes_per_pixel; return 1; }
+	return 0;
+}
+
 static double now_ms(void) {
 	struct timespec ts;
 	clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -61,6 +84,10 @@ int main(int argc, const char* argv[]) {
 	const char* out = NULL;
 	const char* keys = NULL;
 	const char* dump_camera = NULL;
+	const char* resize_script = NULL;
+	const char* dump_frames = NULL;
+	lol_gpu_pixel_format format = { 16, 8, 0, 0, 0, 0, 4, 0, 0 };
+	int bytes_per_pixel = 4;
 	for (int i = 3; i < argc; i++) {
 		if (!strcmp(argv[i], "--size") && i + 1 < argc) sscanf(argv[++i], "%dx%d", &w, &h);
 		else if (!strcmp(argv[i], "--frames") && i + 1 < argc) frames = atoi(argv[++i]);
@@ -69,6 +96,25 @@ int main(int argc, const char* argv[]) {
 		else if (!strcmp(argv[i], "--keys") && i + 1 < argc) keys = argv[++i];
 		else if (!strcmp(argv[i], "--dump-camera") && i + 1 < argc) dump_camera = argv[++i];
 		else if (!strcmp(argv[i], "--pipeline")) pipeline = 1;      /* also read by the plug-in: the surface lags one frame */
+		else if (!strcmp(argv[i], "--resize-script") && i + 1 < argc) resize_script = argv[++i];
+		else if (!strcmp(argv[i], "--dump-frames") && i + 1 < argc) dump_frames = argv[++i];
+		else if (!strcmp(argv[i], "--format") && i + 1 < argc) {
+			if (!format_by_name(argv[++i], &format, &bytes_per_pixel)) { fprintf(stderr, "unknown --format %s\n", argv[i]); return 2; }
+		}
+	}
+	/* --resize-script: sizes[f] for frame f */
+	int sizes[64][2], n_sizes = 0;
+	if (resize_script) {
+		for (const char* q = resize_script; *q && n_sizes < 64;) {
+			int a = 0, b = 0, used = 0;
+			if (sscanf(q, "%dx%d%n", &a, &b, &used) != 2 || a < 1 || b < 1) { fprintf(stderr, "bad --resize-script\n"); return 2; }
+			sizes[n_sizes][0] = a; sizes[n_sizes][1] = b; n_sizes++;
+			q += used;
+			if (*q == ',') q++;
+		}
+		if (n_sizes == 0) { fprintf(stderr, "bad --resize-script\n"); return 2; }
+		w = sizes[0][0]; h = sizes[0][1];
+		if (frames < n_sizes) frames = n_sizes;
 	}
 	if (threads < 1) threads = 1;
 	if (!path || w < 1 || h < 1) {
@@ -92,7 +138,7 @@ int main(int argc, const char* argv[]) {
 	frame_exit_barrier = &exit_;
 	atomic_store(&exiting, 0);
 
-	host_surface surf = { .w = w, .h = h, .pitch = (w + 13) * 4, .bytes_per_pixel = 4 };
+	host_surface surf = { .w = w, .h = h, .pitch = (w + 13) * 4, .bytes_per_pixel = bytes_per_pixel, .format = format };
 	surf.pixels = calloc((size_t)surf.pitch, (size_t)h);
 	struct render_data data = { .surf = &surf, .scene = scene, .private_ = NULL };
 
@@ -119,6 +165,15 @@ int main(int argc, const char* argv[]) {
 			                     scene->camera.direction.x, scene->camera.direction.y, scene->camera.direction.z };
 			for (int j = 0; j < 6; j++) { uint32_t u; memcpy(&u, &v[j], 4); fprintf(cam_fp, "%08x%c", u, j == 5 ? '\n' : ' '); }
 		}
+		if (n_sizes) {                                           /* SDL_GetWindowSurface after a resize: a new surface */
+			const int k = f < n_sizes ? f : n_sizes - 1;
+			if (sizes[k][0] != surf.w || sizes[k][1] != surf.h) {
+				free(surf.pixels);
+				w = surf.w = sizes[k][0]; h = surf.h = sizes[k][1];
+				surf.pitch = (w + 13) * 4;
+				surf.pixels = calloc((size_t)surf.pitch, (size_t)h);
+			}
+		}
 		atomic_store(&current_line, 0);
 		double t0 = now_ms();
 		for (int i = 0; i < threads; i++) sem_post(&entry);
@@ -129,6 +184,17 @@ int main(int argc, const char* argv[]) {
 		tsum += dt;
 		LOG("Frame %d: %.3fms (min: %.3f max: %.3f avg: %.3f) %.1f Mpixels/s", f + 1, dt, tmin, tmax,
 		    tsum / (f + 1), w * (double)h / dt / 1e3);
+		if (dump_frames) {
+			char name[512];
+			snprintf(name, sizeof name, "%s%04d.raw", dump_frames, f);
+			FILE* fp = fopen(name, "wb");
+			if (!fp) { perror(name); return 1; }
+			const int32_t hdr[2] = { w, h };
+			fwrite("LOLF", 1, 4, fp);
+			fwrite(hdr, 4, 2, fp);
+			for (int y = 0; y < h; y++) fwrite((const char*)surf.pixels + (size_t)y * surf.pitch, 4, (size_t)w, fp);
+			fclose(fp);
+		}
 	}
 
 	if (out) {
@@ -138,7 +204,9 @@ int main(int argc, const char* argv[]) {
 		for (int y = 0; y < h; y++) {
 			const uint32_t* row = (const uint32_t*)((const char*)surf.pixels + (size_t)y * surf.pitch);
 			for (int x = 0; x < w; x++) {
-				unsigned char rgb[3] = { (unsigned char)(row[x] >> 16), (unsigned char)(row[x] >> 8), (unsigned char)row[x] };
+				unsigned char rgb[3] = { (unsigned char)((row[x] >> format.r_shift) << format.r_loss),
+				                         (unsigned char)((row[x] >> format.g_shift) << format.g_loss),
+				                         (unsigned char)((row[x] >> format.b_shift) << format.b_loss) };
 				fwrite(rgb, 1, 3, fp);
 			}
 		}

@@ -7,7 +7,8 @@
  * every call fails.
  *
  * Two kernels render the same bits:
- *  - render_interp<STACK>   compiled ahead of time; interprets the op list from LDS;
+ *  - render_interp<STACK>   compiled ahead of time; interprets the scene's macro-op list, fetched with
+ *    wave-uniform scalar loads (lol_kernel.h, Interp);
  *  - lol_render_spec        compiled by hipRTC in lol_gpu_upload_program() from
  *    lol_kernel.h + a generated SpecSdf::eval() — the scene's SDF as straight-line
  *    code with immediates (the GPU analogue of tracing_jit_renderer.dasc:76-216,
@@ -24,6 +25,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <functional>
 #include <cstddef>
@@ -48,16 +50,24 @@ static_assert(sizeof(lol_frame_camera) == sizeof(lol::Cam), "lol_frame_camera la
 struct lol_gpu {
 	int          device = -1;
 	hipStream_t  stream = nullptr;
-	lol_program* d_prog = nullptr;       /* device: lights, materials, root_material tables */
-	uint32_t*    d_mops = nullptr;       /* device: the interpreter's macro-op list (lol_kernel.h, Interp) */
+	/* device tables, two sets: an upload fills the set no frame reads and flips `cur` only when every fallible step
+	 * has succeeded (lol_gpu_upload_program is all-or-nothing) */
+	lol_program* d_prog[2] = { nullptr, nullptr };   /* lights, materials, root_material tables */
+	uint32_t*    d_mops[2] = { nullptr, nullptr };   /* the interpreter's macro-op list (lol_kernel.h, Interp) */
+	int          cur = 0;
 	uint32_t     n_mops = 0;
 	lol_program  h_prog;                 /* host mirror (counts, max_stack) */
 	bool         have_prog = false;
-	uint32_t*    d_frame = nullptr;      /* framebuffer for lol_gpu_render_host */
+	/* the surface's pixel format (lol_gpu_set_pixel_format), packed as lol::Launch wants it; default XRGB8888 */
+	uint32_t     fmt_shift = 16u | 8u << 8 | 0u << 16, fmt_loss = 0, fmt_amask = 0;
+	/* host-surface path */
+	int          host_mode = LOL_GPU_HOST_DIRECT, host_mode_used = -1;
+	uint32_t*    d_frame = nullptr;      /* framebuffer for lol_gpu_render_host in the copy modes */
 	size_t       frame_bytes = 0;
-	/* lol_gpu_render_host_begin / _end: two frames in flight */
+	/* lol_gpu_render_host_begin / _end: two frames in flight, one device framebuffer each (sized per slot, so frames of
+	 * different sizes can be in flight while the host's window is being resized) */
 	uint32_t*    d_pipe[2] = { nullptr, nullptr };
-	size_t       pipe_bytes = 0;
+	size_t       pipe_bytes[2] = { 0, 0 };
 	hipStream_t  copy_stream = nullptr;
 	hipEvent_t   pipe_rendered[2] = { nullptr, nullptr }, pipe_copied[2] = { nullptr, nullptr };
 	int          pipe_w[2] = { 0, 0 }, pipe_h[2] = { 0, 0 };
@@ -67,6 +77,7 @@ struct lol_gpu {
 	hipFunction_t spec_fn = nullptr;
 	hipFunction_t spec_sdf_fn = nullptr; /* lol_sdf_spec of the same module (lol_gpu_sdf_batch) */
 	std::string  spec_log;
+	std::string  spec_key;               /* FNV-1a of the code object the frames run (lol_gpu_kernel_key) */
 	int          want_fast = 1;          /* allow the proven-exact shortcuts in the specialised kernel */
 	int          want_miss_skip = 1;     /* allow FLAG_MISS_SKIP when the program qualifies */
 	int          want_cull = 1;          /* allow the exact culling of top-level objects (plan_culling) */
@@ -97,6 +108,64 @@ int fail(lol_gpu* ctx, int status, const char* what, hipError_t e = hipSuccess) 
 		hipError_t e_ = (call);                                                   \
 		if (e_ != hipSuccess) return fail((ctx), LOL_GPU_ERR_HIP, #call, e_);     \
 	} while (0)
+
+/* ------------------------------------------------------------- pinned host surfaces
+ * The reference's renderer writes into surf->pixels, host memory the HOST owns (SDL's window surface, main.c:182).
+ * Copies into pageable memory are staged by the HIP runtime through its own pinned buffers, synchronously on the
+ * calling thread: half the frame time of the boundary path in round 2.  So the surface itself is page-locked and
+ * mapped for the devices (hipHostRegister; the kernel driver keeps such a range coherent through unmap / remap with
+ * MMU notifiers), once per (address, size) — the host re-fetches the surface every frame and it only changes when
+ * the window is resized.  Process-wide, because every device of a multi-device host writes the same surface. */
+struct HostPins {
+	struct Range { char* base; size_t bytes; unsigned long stamp; };
+	static constexpr int MAX = 4;
+	std::mutex mu;
+	Range r[MAX] = {};
+	int n = 0;
+	unsigned long clock = 0;
+	bool enabled() const { const char* e = getenv("LOL_GPU_PIN_HOST"); return !(e && e[0] == '0'); }
+	void drop(int i) {
+		(void)hipHostUnregister(r[i].base);
+		r[i] = r[--n];
+	}
+	/* true when [p, p + bytes) is registered afterwards */
+	bool pin(void* ptr, size_t bytes) {
+		if (!ptr || !bytes || !enabled()) return false;
+		std::lock_guard<std::mutex> lock(mu);
+		const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+		char* lo = reinterpret_cast<char*>(reinterpret_cast<uintptr_t>(ptr) & ~(uintptr_t)(page - 1));
+		char* hi = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(ptr) + bytes + page - 1) & ~(uintptr_t)(page - 1));
+		for (int i = 0; i < n; i++)
+			if (r[i].base <= lo && hi <= r[i].base + r[i].bytes) { r[i].stamp = ++clock; return true; }
+		/* a range that overlaps without covering is the old surface at (partly) the same address: release it */
+		for (int i = n - 1; i >= 0; i--)
+			if (r[i].base < hi && lo < r[i].base + r[i].bytes) drop(i);
+		if (n == MAX) {
+			int oldest = 0;
+			for (int i = 1; i < n; i++) if (r[i].stamp < r[oldest].stamp) oldest = i;
+			drop(oldest);
+		}
+		if (hipHostRegister(lo, (size_t)(hi - lo), hipHostRegisterPortable | hipHostRegisterMapped) != hipSuccess) {
+			(void)hipGetLastError();
+			return false;
+		}
+		r[n++] = { lo, (size_t)(hi - lo), ++clock };
+		return true;
+	}
+	void unpin(void* ptr) {
+		std::lock_guard<std::mutex> lock(mu);
+		for (int i = n - 1; i >= 0; i--)
+			if (!ptr || (r[i].base <= static_cast<char*>(ptr) && static_cast<char*>(ptr) < r[i].base + r[i].bytes)) drop(i);
+	}
+} g_pins;
+std::atomic<int> g_live_contexts{0};     /* the last context to go releases the pinned ranges */
+
+/* the device's address of pinned host memory, nullptr when it has none */
+void* device_view(void* host_ptr) {
+	void* d = nullptr;
+	if (hipHostGetDevicePointer(&d, host_ptr, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+	return d;
+}
 
 template <int SSIZE>
 hipError_t launch_sdf_interp(const uint32_t* mops, uint32_t n_mops, const float* pts, float* dist, uint32_t* id, uint32_t n,
@@ -866,6 +935,14 @@ struct Roctx {
 	}
 } g_roctx;
 
+std::string fnv_hex(const void* data, size_t n) {
+	unsigned long long h = 0xcbf29ce484222325ull;
+	for (size_t i = 0; i < n; i++) { h ^= static_cast<const unsigned char*>(data)[i]; h *= 0x100000001b3ull; }
+	char b[20];
+	snprintf(b, sizeof b, "%016llx", h);
+	return b;
+}
+
 /* Process-wide cache of compiled kernels: hosts (and the tests) upload the same scene many times. */
 std::mutex g_cache_mutex;
 std::unordered_map<std::string, std::vector<char>> g_code_cache;
@@ -1116,6 +1193,7 @@ bool specialise(lol_gpu* ctx) {
 	}
 	if (hipModuleGetFunction(&ctx->spec_sdf_fn, ctx->spec_module, "lol_sdf_spec") != hipSuccess) ctx->spec_sdf_fn = nullptr;
 	snprintf(ctx->kernel_name, sizeof ctx->kernel_name, "lol_render_spec");
+	ctx->spec_key = fnv_hex(code.data(), code.size());
 	return true;
 }
 
@@ -1139,14 +1217,19 @@ int lol_gpu_create(int device, lol_gpu** out) {
 	ctx->device = device;
 	hipError_t e = hipSetDevice(device);
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-	if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_prog), sizeof(lol_program));
-	/* at most one macro-op per op, plus the group test's constants record */
-	if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_mops), (size_t)(2 * LOL_MAX_OPS) * lol::MOP_DWORDS * 4);   /* macro-ops + test records <= 1.5 x ops */
+	for (int i = 0; i < 2 && e == hipSuccess; i++) {
+		e = hipMalloc(reinterpret_cast<void**>(&ctx->d_prog[i]), sizeof(lol_program));
+		/* macro-ops + test records <= 1.5 x ops */
+		if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_mops[i]), (size_t)(2 * LOL_MAX_OPS) * lol::MOP_DWORDS * 4);
+	}
+	if (const char* hm = getenv("LOL_GPU_HOST_MODE"))
+		ctx->host_mode = !strcmp(hm, "copy") ? LOL_GPU_HOST_COPY : !strcmp(hm, "pageable") ? LOL_GPU_HOST_PAGEABLE : LOL_GPU_HOST_DIRECT;
 	if (e != hipSuccess) {
 		fprintf(stderr, "lol_gpu_create: %s\n", hipGetErrorString(e));
 		lol_gpu_destroy(ctx);
 		return LOL_GPU_ERR_HIP;
 	}
+	g_live_contexts++;
 	*out = ctx;
 	return LOL_GPU_OK;
 }
@@ -1156,8 +1239,10 @@ void lol_gpu_destroy(lol_gpu* ctx) {
 	if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
 	if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
 	if (ctx->spec_module) (void)hipModuleUnload(ctx->spec_module);
-	if (ctx->d_prog) (void)hipFree(ctx->d_prog);
-	if (ctx->d_mops) (void)hipFree(ctx->d_mops);
+	for (int i = 0; i < 2; i++) {
+		if (ctx->d_prog[i]) (void)hipFree(ctx->d_prog[i]);
+		if (ctx->d_mops[i]) (void)hipFree(ctx->d_mops[i]);
+	}
 	if (ctx->d_frame) (void)hipFree(ctx->d_frame);
 	if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
 	for (int i = 0; i < 2; i++) {
@@ -1166,7 +1251,9 @@ void lol_gpu_destroy(lol_gpu* ctx) {
 		if (ctx->pipe_copied[i]) (void)hipEventDestroy(ctx->pipe_copied[i]);
 	}
 	if (ctx->d_bad) (void)hipFree(ctx->d_bad);
+	const bool counted = ctx->stream != nullptr && ctx->d_mops[1] != nullptr;     /* lol_gpu_create got to the end */
 	delete ctx;
+	if (counted && --g_live_contexts == 0) g_pins.unpin(nullptr);
 }
 
 const char* lol_gpu_error(const lol_gpu* ctx) { return ctx ? ctx->err : "null context"; }
@@ -1261,26 +1348,31 @@ int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog) {
 	/* frames already queued — on the context's stream or on a caller's — still read the old tables and code
 	 * object: drain the whole device before replacing them */
 	LOL_HIP(ctx, hipDeviceSynchronize());
+	/* Everything that can fail happens on the side: the tables for both kernels and the interpreter's macro-op list
+	 * (smooth unions whose blend factor is proven on this device carry {k, 2k, .5/k}; the proven sqrt is selected by
+	 * instantiation at launch) go to the table set no frame reads.  Only then is the context switched over, so a
+	 * rejected program leaves the previous scene rendering (the reference asserts instead: scene.c:284-292). */
+	FastPaths fast = prove_fast_paths(ctx, *prog);
+	const std::vector<RootBound> roots = analyse_roots(*prog);
+	const std::vector<uint32_t> mops = build_mops(*prog, &fast, roots, plan_culling(roots, culling_enabled(ctx->want_cull)));
+	const uint32_t n_mops = (uint32_t)(mops.size() / lol::MOP_DWORDS);
+	if (n_mops > 2 * LOL_MAX_OPS) return fail(ctx, LOL_GPU_ERR_UNSUPPORTED, "program exceeds interpreter limits");
+	const int next = ctx->cur ^ 1;
+	hipError_t e = getenv("LOL_GPU_TEST_FAIL_UPLOAD") ? hipErrorOutOfMemory      /* fault injection for tests/test_gpu_resize.py */
+	                                                  : hipMemcpy(ctx->d_prog[next], prog, sizeof *prog, hipMemcpyHostToDevice);
+	if (e == hipSuccess && !mops.empty())
+		e = hipMemcpy(ctx->d_mops[next], mops.data(), mops.size() * 4, hipMemcpyHostToDevice);
+	if (e != hipSuccess) return fail(ctx, LOL_GPU_ERR_HIP, "hipMemcpy(program)", e);
+	/* commit */
+	ctx->cur = next;
 	ctx->h_prog = *prog;
 	ctx->have_prog = true;
-	/* tables for both kernels, and the interpreter's macro-op list: smooth unions whose blend factor is proven on
-	 * this device carry {k, 2k, .5/k}; the proven sqrt is selected by instantiation at launch */
-	{
-		FastPaths fast = prove_fast_paths(ctx, *prog);
-		ctx->interp_sqrt_kind = fast.sqrt_kind == 3 ? 3 : 0;
-		const std::vector<RootBound> roots = analyse_roots(*prog);
-		std::vector<uint32_t> mops = build_mops(*prog, &fast, roots, plan_culling(roots, culling_enabled(ctx->want_cull)));
-		ctx->n_mops = (uint32_t)(mops.size() / lol::MOP_DWORDS);
-		if (ctx->n_mops > 2 * LOL_MAX_OPS) return fail(ctx, LOL_GPU_ERR_UNSUPPORTED, "program exceeds interpreter limits");
-		hipError_t e = hipMemcpy(ctx->d_prog, prog, sizeof *prog, hipMemcpyHostToDevice);
-		if (e == hipSuccess && !mops.empty())
-			e = hipMemcpy(ctx->d_mops, mops.data(), mops.size() * 4, hipMemcpyHostToDevice);
-		if (e != hipSuccess) return fail(ctx, LOL_GPU_ERR_HIP, "hipMemcpy(program)", e);
-	}
+	ctx->n_mops = n_mops;
+	ctx->interp_sqrt_kind = fast.sqrt_kind == 3 ? 3 : 0;
 	const char* ms = getenv("LOL_GPU_MISS_SKIP");
 	ctx->miss_skip = ctx->want_miss_skip && !(ms && ms[0] == '0') && miss_skip_ok(*prog);
 	ctx->dark_skip = ctx->want_miss_skip && !(ms && ms[0] == '0') && dark_skip_ok(*prog);
-	specialise(ctx);
+	specialise(ctx);          /* a failed specialisation is not an error: the interpreter renders the new scene */
 	return LOL_GPU_OK;
 }
 
@@ -1322,15 +1414,17 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	L.band_rows = R->band_rows; L.n_parts = R->n_parts; L.part = R->part;
 	const lol_program& P = ctx->h_prog;
 	L.n_ops = ctx->n_mops; L.n_lights = P.n_lights; L.n_materials = P.n_materials; L.n_roots = P.n_roots;
-	const char* base = reinterpret_cast<const char*>(ctx->d_prog);
-	L.ops           = ctx->d_mops;
+	const char* base = reinterpret_cast<const char*>(ctx->d_prog[ctx->cur]);
+	L.ops           = ctx->d_mops[ctx->cur];
 	L.lights        = reinterpret_cast<const uint32_t*>(base + offsetof(lol_program, lights));
 	L.materials     = reinterpret_cast<const uint32_t*>(base + offsetof(lol_program, materials));
 	L.root_material = reinterpret_cast<const uint32_t*>(base + offsetof(lol_program, root_material));
 	L.ambient[0] = P.ambient_color.x; L.ambient[1] = P.ambient_color.y; L.ambient[2] = P.ambient_color.z;
-	L.flags = (ctx->miss_skip ? lol::FLAG_MISS_SKIP : 0u) | (ctx->dark_skip ? lol::FLAG_DARK_SKIP : 0u);
+	L.flags = (ctx->miss_skip ? lol::FLAG_MISS_SKIP : 0u) | (ctx->dark_skip ? lol::FLAG_DARK_SKIP : 0u) |
+	          (R->in_place ? lol::FLAG_IN_PLACE : 0u);
 	L.dst = static_cast<uint32_t*>(dst);
 	L.pitch_px = (uint32_t)(pitch_bytes / 4);
+	L.fmt_shift = ctx->fmt_shift; L.fmt_loss = ctx->fmt_loss; L.fmt_amask = ctx->fmt_amask;
 	if (dbg) {
 		L.dbg_rgb = dbg->rgb; L.dbg_hit_dist = dbg->hit_dist;
 		L.dbg_hit_id = dbg->hit_id; L.dbg_steps = dbg->steps;
@@ -1366,12 +1460,67 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	return LOL_GPU_OK;
 }
 
+int lol_gpu_set_pixel_format(lol_gpu* ctx, const lol_gpu_pixel_format* fmt) {
+	if (!ctx) return LOL_GPU_ERR_ARG;
+	static const lol_gpu_pixel_format xrgb8888 = { 16, 8, 0, 0, 0, 0, 4, 0, 0 };
+	const lol_gpu_pixel_format& f = fmt ? *fmt : xrgb8888;
+	/* the reference stores a Uint32 per pixel whatever the format says (naive_renderer.c:233-235): 4-byte formats only,
+	 * and SDL_MapRGB's shift formula only describes non-palettised ones */
+	if (f.palettised) return fail(ctx, LOL_GPU_ERR_UNSUPPORTED, "palettised surfaces are not supported");
+	if (f.bytes_per_pixel != 4) return fail(ctx, LOL_GPU_ERR_UNSUPPORTED, "only 32-bit surfaces are supported");
+	if (f.r_shift > 31 || f.g_shift > 31 || f.b_shift > 31 || f.r_loss > 8 || f.g_loss > 8 || f.b_loss > 8)
+		return fail(ctx, LOL_GPU_ERR_UNSUPPORTED, "pixel format shifts / losses out of range");
+	ctx->fmt_shift = (uint32_t)f.r_shift | (uint32_t)f.g_shift << 8 | (uint32_t)f.b_shift << 16;
+	ctx->fmt_loss = (uint32_t)f.r_loss | (uint32_t)f.g_loss << 8 | (uint32_t)f.b_loss << 16;
+	ctx->fmt_amask = f.a_mask;
+	return LOL_GPU_OK;
+}
+
+int lol_gpu_set_host_mode(lol_gpu* ctx, int mode) {
+	if (!ctx || mode < LOL_GPU_HOST_DIRECT || mode > LOL_GPU_HOST_PAGEABLE) return LOL_GPU_ERR_ARG;
+	ctx->host_mode = mode;
+	return LOL_GPU_OK;
+}
+
+int lol_gpu_host_mode_used(const lol_gpu* ctx) { return ctx ? ctx->host_mode_used : -1; }
+
+int lol_gpu_pin_host(void* ptr, size_t bytes, void** dev_ptr) {
+	if (!ptr || !bytes) return LOL_GPU_ERR_ARG;
+	if (!g_pins.pin(ptr, bytes)) return LOL_GPU_ERR_HIP;
+	if (dev_ptr) *dev_ptr = device_view(ptr);
+	return LOL_GPU_OK;
+}
+
+int lol_gpu_unpin_host(void* ptr) { g_pins.unpin(ptr); return LOL_GPU_OK; }
+
+/* Pin the surface (unless the mode says not to) and say how the frame is to reach it:
+ *   returns LOL_GPU_HOST_DIRECT with *direct = the device's address of the surface, or _COPY (pinned), or _PAGEABLE. */
+static int host_route(lol_gpu* ctx, void* host_pixels, size_t pitch_bytes, int w, int h, void** direct) {
+	*direct = nullptr;
+	if (ctx->host_mode == LOL_GPU_HOST_PAGEABLE) return LOL_GPU_HOST_PAGEABLE;
+	/* the last row is w*4 bytes long, not a whole pitch: a surface need not own the padding behind it */
+	if (!g_pins.pin(host_pixels, pitch_bytes * (size_t)(h - 1) + (size_t)w * 4)) return LOL_GPU_HOST_PAGEABLE;
+	if (ctx->host_mode == LOL_GPU_HOST_DIRECT && pitch_bytes % 4 == 0 && reinterpret_cast<uintptr_t>(host_pixels) % 4 == 0)
+		if ((*direct = device_view(host_pixels)) != nullptr) return LOL_GPU_HOST_DIRECT;
+	return LOL_GPU_HOST_COPY;
+}
+
 int lol_gpu_render_host(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h, int max_steps,
                         void* host_pixels, size_t pitch_bytes) {
 	if (!ctx || !host_pixels) return LOL_GPU_ERR_ARG;
 	if (w <= 0 || h <= 0 || pitch_bytes < (size_t)w * 4) return fail(ctx, LOL_GPU_ERR_ARG, "bad frame geometry");
-	size_t need = (size_t)w * h * 4;
 	LOL_HIP(ctx, hipSetDevice(ctx->device));
+	void* direct = nullptr;
+	const int route = host_route(ctx, host_pixels, pitch_bytes, w, h, &direct);
+	ctx->host_mode_used = route;
+	if (route == LOL_GPU_HOST_DIRECT) {
+		/* the kernel's 64-byte row-segment stores go over the PCIe link into the mapped surface: nothing to copy */
+		int st = lol_gpu_render_device(ctx, cam, w, h, max_steps, nullptr, direct, pitch_bytes, nullptr, nullptr);
+		if (st != LOL_GPU_OK) return st;
+		LOL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		return LOL_GPU_OK;
+	}
+	size_t need = (size_t)w * h * 4;
 	if (need > ctx->frame_bytes) {          /* the surface may be resized between frames (main.c:182-187) */
 		if (ctx->d_frame) { LOL_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_frame); }
 		ctx->d_frame = nullptr; ctx->frame_bytes = 0;
@@ -1390,7 +1539,8 @@ int lol_gpu_render_host(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h,
  * The host-surface path with two frames in flight: begin() queues frame i+1's kernel while end() copies frame i
  * into the host's surface, so the 33 MB device-to-host copy of a 4K frame (0.6 ms at PCIe Gen5 rates) runs under
  * the next frame's kernel instead of after its own.  Kernels go to the context's stream, copies to a second
- * stream, two device framebuffers alternate.
+ * stream, two device framebuffers alternate.  The surface is pinned (host_route), so the copy is a real
+ * asynchronous DMA; pageable it is staged by the runtime on the calling thread.
  */
 int lol_gpu_render_host_begin(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h, int max_steps) {
 	if (!ctx || !cam) return LOL_GPU_ERR_ARG;
@@ -1404,20 +1554,19 @@ int lol_gpu_render_host_begin(lol_gpu* ctx, const lol_frame_camera* cam, int w, 
 			LOL_HIP(ctx, hipEventCreateWithFlags(&ctx->pipe_copied[i], hipEventDisableTiming));
 		}
 	}
-	const size_t need = (size_t)w * h * 4;
-	if (need > ctx->pipe_bytes) {               /* the surface grew (main.c:182-187): drain, then reallocate both */
-		LOL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-		LOL_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
-		if (ctx->pipe_begun != ctx->pipe_ended) return fail(ctx, LOL_GPU_ERR_ARG, "cannot resize with a frame in flight: call lol_gpu_render_host_end first");
-		for (int i = 0; i < 2; i++) {
-			if (ctx->d_pipe[i]) (void)hipFree(ctx->d_pipe[i]);
-			ctx->d_pipe[i] = nullptr;
-		}
-		ctx->pipe_bytes = 0;
-		for (int i = 0; i < 2; i++) LOL_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_pipe[i]), need));
-		ctx->pipe_bytes = need;
-	}
 	const int slot = (int)(ctx->pipe_begun & 1u);
+	const size_t need = (size_t)w * h * 4;
+	if (need > ctx->pipe_bytes[slot]) {
+		/* the surface grew (main.c:182-187).  This slot's last frame was ended two calls ago; its copy may still run:
+		 * wait for it, then replace this slot's framebuffer only — the frame queued in the OTHER slot stays valid */
+		LOL_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+		LOL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		if (ctx->d_pipe[slot]) (void)hipFree(ctx->d_pipe[slot]);
+		ctx->d_pipe[slot] = nullptr;
+		ctx->pipe_bytes[slot] = 0;
+		LOL_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_pipe[slot]), need));
+		ctx->pipe_bytes[slot] = need;
+	}
 	/* the copy that last read this framebuffer (two frames ago) must be done before the kernel overwrites it */
 	LOL_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->pipe_copied[slot], 0));
 	int st = lol_gpu_render_device(ctx, cam, w, h, max_steps, nullptr, ctx->d_pipe[slot], (size_t)w * 4, nullptr, nullptr);
@@ -1428,13 +1577,19 @@ int lol_gpu_render_host_begin(lol_gpu* ctx, const lol_frame_camera* cam, int w, 
 	return LOL_GPU_OK;
 }
 
-int lol_gpu_render_host_end(lol_gpu* ctx, void* host_pixels, size_t pitch_bytes) {
+int lol_gpu_render_host_end(lol_gpu* ctx, void* host_pixels, size_t pitch_bytes, int w, int h) {
 	if (!ctx || !host_pixels) return LOL_GPU_ERR_ARG;
 	if (ctx->pipe_begun == ctx->pipe_ended) return fail(ctx, LOL_GPU_ERR_ARG, "no frame in flight");
 	const int slot = (int)(ctx->pipe_ended & 1u);
-	const int w = ctx->pipe_w[slot], h = ctx->pipe_h[slot];
+	/* the surface's size, as the caller sees it NOW, decides what may be written: a frame queued before a resize
+	 * is never copied into a surface of another size (it stays queued: discard it, or end it into a fitting one) */
+	if (w != ctx->pipe_w[slot] || h != ctx->pipe_h[slot])
+		return fail(ctx, LOL_GPU_ERR_ARG, "the queued frame's size differs from the surface's: lol_gpu_render_host_discard");
 	if (pitch_bytes < (size_t)w * 4) return fail(ctx, LOL_GPU_ERR_ARG, "bad frame geometry");
 	LOL_HIP(ctx, hipSetDevice(ctx->device));
+	void* unused = nullptr;
+	const int route = host_route(ctx, host_pixels, pitch_bytes, w, h, &unused);
+	ctx->host_mode_used = route == LOL_GPU_HOST_DIRECT ? LOL_GPU_HOST_COPY : route;
 	LOL_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->pipe_rendered[slot], 0));
 	LOL_HIP(ctx, hipMemcpy2DAsync(host_pixels, pitch_bytes, ctx->d_pipe[slot], (size_t)w * 4, (size_t)w * 4, h,
 	                              hipMemcpyDeviceToHost, ctx->copy_stream));
@@ -1445,6 +1600,22 @@ int lol_gpu_render_host_end(lol_gpu* ctx, void* host_pixels, size_t pitch_bytes)
 }
 
 int lol_gpu_render_host_pending(const lol_gpu* ctx) { return ctx ? (int)(ctx->pipe_begun - ctx->pipe_ended) : 0; }
+
+int lol_gpu_render_host_pending_size(const lol_gpu* ctx, int* w, int* h) {
+	if (!ctx || !w || !h) return LOL_GPU_ERR_ARG;
+	const bool any = ctx->pipe_begun != ctx->pipe_ended;
+	const int slot = (int)(ctx->pipe_ended & 1u);
+	*w = any ? ctx->pipe_w[slot] : 0;
+	*h = any ? ctx->pipe_h[slot] : 0;
+	return LOL_GPU_OK;
+}
+
+int lol_gpu_render_host_discard(lol_gpu* ctx) {
+	if (!ctx) return LOL_GPU_ERR_ARG;
+	/* the kernels still run to completion into their own framebuffers; nothing of them reaches a surface */
+	ctx->pipe_ended = ctx->pipe_begun;
+	return LOL_GPU_OK;
+}
 
 int lol_gpu_sync(lol_gpu* ctx) {
 	if (!ctx) return LOL_GPU_ERR_ARG;
@@ -1477,6 +1648,12 @@ int lol_gpu_memcpy_d2h(lol_gpu* ctx, void* host, const void* dev, size_t bytes) 
 
 const char* lol_gpu_kernel_name(const lol_gpu* ctx) { return ctx ? ctx->kernel_name : ""; }
 
+const char* lol_gpu_kernel_key(const lol_gpu* ctx) {
+	static const std::string aot = fnv_hex(LOL_KERNEL_H_TEXT, sizeof LOL_KERNEL_H_TEXT);
+	if (!ctx) return "";
+	return ctx->spec_fn ? ctx->spec_key.c_str() : aot.c_str();
+}
+
 int lol_gpu_powf_batch(lol_gpu* ctx, const float* x_dev, const float* y_dev, float* out_dev, size_t n, void* stream) {
 	if (!ctx || !x_dev || !y_dev || !out_dev) return LOL_GPU_ERR_ARG;
 	if (n == 0) return LOL_GPU_OK;
@@ -1501,10 +1678,10 @@ int lol_gpu_sdf_batch(lol_gpu* ctx, const float* pts_dev, float* dist_dev, uint3
 	} else {
 		const uint32_t need = ctx->h_prog.max_stack > 1 ? ctx->h_prog.max_stack - 1 : 1;
 		const int kind = ctx->interp_sqrt_kind;
-		if (need <= 1)      e = launch_sdf_interp<1>(ctx->d_mops, ctx->n_mops, pts_dev, dist_dev, id_dev, n32, s, kind);
-		else if (need <= 3) e = launch_sdf_interp<3>(ctx->d_mops, ctx->n_mops, pts_dev, dist_dev, id_dev, n32, s, kind);
-		else if (need <= 7) e = launch_sdf_interp<7>(ctx->d_mops, ctx->n_mops, pts_dev, dist_dev, id_dev, n32, s, kind);
-		else                e = launch_sdf_interp<LOL_MAX_STACK - 1>(ctx->d_mops, ctx->n_mops, pts_dev, dist_dev, id_dev, n32, s, kind);
+		if (need <= 1)      e = launch_sdf_interp<1>(ctx->d_mops[ctx->cur], ctx->n_mops, pts_dev, dist_dev, id_dev, n32, s, kind);
+		else if (need <= 3) e = launch_sdf_interp<3>(ctx->d_mops[ctx->cur], ctx->n_mops, pts_dev, dist_dev, id_dev, n32, s, kind);
+		else if (need <= 7) e = launch_sdf_interp<7>(ctx->d_mops[ctx->cur], ctx->n_mops, pts_dev, dist_dev, id_dev, n32, s, kind);
+		else                e = launch_sdf_interp<LOL_MAX_STACK - 1>(ctx->d_mops[ctx->cur], ctx->n_mops, pts_dev, dist_dev, id_dev, n32, s, kind);
 	}
 	if (e != hipSuccess) return fail(ctx, LOL_GPU_ERR_HIP, "sdf kernel launch", e);
 	return LOL_GPU_OK;

@@ -66,6 +66,7 @@ constexpr int LIGHT_DWORDS = 9, MATERIAL_DWORDS = 10;
 /* Launch.flags */
 constexpr u32 FLAG_MISS_SKIP = 1u;   /* a wave whose rays all escaped may skip normal + lights (see shade_pixel) */
 constexpr u32 FLAG_DARK_SKIP = 2u;   /* lanes whose diffuse incidence for a light is exactly 0 need no shadow march for it */
+constexpr u32 FLAG_IN_PLACE  = 4u;   /* dst is a whole-frame surface: a pixel lands at its FRAME row, not at the part's local row (lol_gpu_rows.in_place) */
 
 /* = lol_frame_camera */
 struct Cam { float origin[3], dir[3], right[3], up[3]; float width, height; };
@@ -85,8 +86,13 @@ struct Launch {
 	const u32* root_material;
 	float  ambient[3];
 	u32    flags;                /* FLAG_* */
-	u32*   dst;                  /* XRGB8888, pitch_px dwords per local row */
+	u32*   dst;                  /* 32-bit pixels (fmt_* below), pitch_px dwords per row (local rows, or frame rows with FLAG_IN_PLACE) */
 	u32    pitch_px;
+	/* SDL_MapRGB's description of the surface's pixel format (renderer.h:17-22; lol_gpu_pixel_format), one byte per channel:
+	 * pixel = (r >> Rloss) << Rshift | (g >> Gloss) << Gshift | (b >> Bloss) << Bshift | Amask */
+	u32    fmt_shift;            /* Rshift | Gshift << 8 | Bshift << 16 */
+	u32    fmt_loss;             /* Rloss  | Gloss  << 8 | Bloss  << 16 */
+	u32    fmt_amask;
 	float* dbg_rgb;
 	float* dbg_hit_dist;
 	u32*   dbg_hit_id;
@@ -696,6 +702,12 @@ __host__ __device__ inline u32 common_lds_dwords(u32 n_lights, u32 n_materials, 
 
 struct Pixel { u32 px; V3 rgb; Hit hit; u32 shadow_steps; };
 
+/* frame row of local row r of this launch's part (the inverse: lol_gpu_part_frame_row) */
+__device__ __forceinline__ int frame_row(const Launch& L, int r) {
+	const int band = r / L.band_rows;
+	return (band * L.n_parts + L.part) * L.band_rows + (r - band * L.band_rows);
+}
+
 /*
  * The per-pixel body, naive_renderer.c:217-235, for the pixel this lane owns.
  * `lds` = lights | materials | root_material | out tile (already staged and synchronised).
@@ -714,8 +726,7 @@ __device__ __forceinline__ Pixel shade_pixel(const Launch& L, Sdf& sdf, const u3
 	/* out-of-frame lanes shade a clamped pixel and skip the store: keeps the wave uniform */
 	x = x < L.w ? x : L.w - 1;
 	r = r < L.n_rows ? r : L.n_rows - 1;
-	const int band = r / L.band_rows;
-	const int y = (band * L.n_parts + L.part) * L.band_rows + (r - band * L.band_rows);
+	const int y = frame_row(L, r);
 
 	/* naive_renderer.c:218-221 */
 	const float vx = ((float)x + .5f) / L.fw * 2.f - 1.f;
@@ -786,7 +797,12 @@ __device__ __forceinline__ Pixel shade_pixel(const Launch& L, Sdf& sdf, const u3
 	/* gamma + colorf_to_pixfmt, naive_renderer.c:231-232, renderer.h:17-22 */
 	const float g = 1.f / 2.2f;
 	c = { powf_glibc(c.x, g), powf_glibc(c.y, g), powf_glibc(c.z, g) };
-	u32 px = ((u32)(c.x * 255.f) & 0xFFu) << 16 | ((u32)(c.y * 255.f) & 0xFFu) << 8 | ((u32)(c.z * 255.f) & 0xFFu);
+	/* Uint8 r = colorf.x * 255 …; SDL_MapRGB(fmt, r, g, b) for a non-palettised format (SDL2 src/video/SDL_pixels.c):
+	 * (r >> Rloss) << Rshift | (g >> Gloss) << Gshift | (b >> Bloss) << Bshift | Amask.  XRGB8888 = shifts 16/8/0, no loss, no alpha. */
+	const u32 r8 = (u32)(c.x * 255.f) & 0xFFu, g8 = (u32)(c.y * 255.f) & 0xFFu, b8 = (u32)(c.z * 255.f) & 0xFFu;
+	const u32 px = (r8 >> (L.fmt_loss & 0xFFu)) << (L.fmt_shift & 0xFFu) |
+	               (g8 >> (L.fmt_loss >> 8 & 0xFFu)) << (L.fmt_shift >> 8 & 0xFFu) |
+	               (b8 >> (L.fmt_loss >> 16 & 0xFFu)) << (L.fmt_shift >> 16 & 0xFFu) | L.fmt_amask;
 	return { px, c, hit, shadow_steps };
 }
 
@@ -808,8 +824,10 @@ __device__ __forceinline__ void store_pixel(const Launch& L, const Pixel& P, u32
 	__syncthreads();
 	const int sx = threadIdx.x % TILE_W, sy = threadIdx.x / TILE_W;
 	const int ox = blockIdx.x * TILE_W + sx, orow = blockIdx.y * TILE_H + sy;
-	if (ox < L.w && orow < L.n_rows)
-		L.dst[(unsigned long long)orow * L.pitch_px + ox] = l_tile[sy * TILE_W + sx];
+	if (ox < L.w && orow < L.n_rows) {
+		const int drow = (L.flags & FLAG_IN_PLACE) ? frame_row(L, orow) : orow;
+		L.dst[(unsigned long long)drow * L.pitch_px + ox] = l_tile[sy * TILE_W + sx];
+	}
 }
 
 /* stage lights | materials | root_material into `lds` (no barrier) */

@@ -17,13 +17,17 @@
  * RCCL itself is resolved with dlopen, and the communicators are created, on the first frame that needs the
  * exchange: librccl is a 570 MB library that a host which never assembles on a device should not have to map.
  *
- * A HOST surface (what render_thread fills, naive_renderer.c:233-235) needs no exchange at all: every device copies
- * its own bands straight into the surface — one strided hipMemcpy3DAsync per part, so N devices drive N PCIe links
- * in parallel instead of funnelling 4 B per pixel through the root's single link (132 MB = 2.4 ms for a C4 frame).
+ * A HOST surface (what render_thread fills, naive_renderer.c:233-235) needs no exchange at all: the surface is pinned
+ * and mapped for every device (lol_gpu_pin_host) and every device writes its own bands into it over its own PCIe link —
+ * its kernels store straight into the surface (lol_gpu_rows.in_place, host mode "direct") or its exchange stream copies
+ * its parts there (one strided asynchronous hipMemcpy3DAsync per part, host mode "copy") — instead of funnelling 4 B per
+ * pixel through the root's single link (132 MB = 2.4 ms for a C4 frame).
  *
- * parts_per_device (default 1) lets one device own several parts (parts p, p + n, p + 2n, … of n * parts_per_device):
- * finer interleaving for load balance, and the means by which a single-GPU box exercises every multi-part code path
- * (strided copies, part table, assembly) — tests/test_multi_device.py.
+ * Parts and their owners.  A frame's bands are dealt round-robin over n_parts PARTS, and the parts round-robin over
+ * the devices: parts_per_device rounds, every device taking one part per round — except that the root sits out the
+ * last (parts_per_device - root_parts) rounds (lol_gpu_deal_parts).  The root also receives, and un-interleaves, the
+ * whole frame, so an equal share makes it the straggler; owning fewer parts is the cost-weighted split.  Several parts
+ * per device are also how a single-GPU box exercises every multi-part code path — tests/test_multi_device.py.
  */
 #include "lol_gpu.h"
 
@@ -129,16 +133,16 @@ bool fill_table(PartTable& tab, int n_parts, int band_rows, int h) {
 	return row == (uint32_t)h;
 }
 
-/* parts stored device by device (device d owns parts d, d + n_dev, d + 2 n_dev, …, back to back): the layout of the
- * per-device buffers and, concatenated in device order, of the root's staging buffer.  dev_row0[d] = first staging
- * row of device d, dev_rows[d] = rows device d owns, tab.row0[part] = staging row where that part starts. */
-bool fill_device_major(PartTable& tab, uint32_t* dev_row0, uint32_t* dev_rows, int n_dev, int per_dev, int band_rows, int h) {
-	const int n_parts = n_dev * per_dev;
+/* parts stored device by device (a device's parts back to back, in part order): the layout of the per-device buffers
+ * and, concatenated in device order, of the root's staging buffer.  dev_row0[d] = first staging row of device d,
+ * dev_rows[d] = rows device d owns, tab.row0[part] = staging row where that part starts. */
+bool fill_device_major(PartTable& tab, uint32_t* dev_row0, uint32_t* dev_rows, const int* owner, int n_parts, int n_dev,
+                       int band_rows, int h) {
 	uint32_t row = 0;
 	for (int d = 0; d < n_dev; d++) {
 		dev_row0[d] = row;
-		for (int j = 0; j < per_dev; j++) {
-			const int part = d + j * n_dev;
+		for (int part = 0; part < n_parts; part++) {
+			if (owner[part] != d) continue;
 			lol_gpu_rows R = { band_rows, n_parts, part };
 			int n = lol_gpu_part_rows(h, &R);
 			if (n < 0) return false;
@@ -159,6 +163,10 @@ struct lol_gpu_multi {
 	bool      comms_up = false;
 	int       band_override = 0;
 	int       per_dev = 1;                             /* parts per device */
+	int       root_parts = 1;                          /* parts of the root (<= per_dev): its smaller share */
+	int       n_parts = 1;
+	int       owner[MAX_PARTS] = { 0 };                /* device index of every part (lol_gpu_deal_parts) */
+	int       host_mode = LOL_GPU_HOST_DIRECT;
 	int       host_via_root = 0;                       /* render_host: assemble on the root first (RCCL) instead of direct copies */
 	uint32_t* staging[SLOTS] = { nullptr, nullptr };   /* root: every part of a frame, back to back */
 	size_t    staging_bytes = 0;
@@ -199,22 +207,24 @@ int ensure_buffers(lol_gpu_multi* m, int w, int h, const uint32_t* dev_rows, boo
 		if (need > D.part_bytes) {
 			M_HIP(m, hipSetDevice(D.id));
 			M_HIP(m, hipDeviceSynchronize());
+			D.part_bytes = 0;                       /* a failed hipMalloc below must not leave a stale size behind */
 			for (int s = 0; s < SLOTS; s++) {
 				if (D.part[s]) (void)hipFree(D.part[s]);
 				D.part[s] = nullptr;
-				M_HIP(m, hipMalloc(reinterpret_cast<void**>(&D.part[s]), need));
 			}
+			for (int s = 0; s < SLOTS; s++) M_HIP(m, hipMalloc(reinterpret_cast<void**>(&D.part[s]), need));
 			D.part_bytes = need;
 		}
 	}
 	if (need_staging > m->staging_bytes) {
 		M_HIP(m, hipSetDevice(m->dev[0].id));
 		M_HIP(m, hipDeviceSynchronize());
+		m->staging_bytes = 0;
 		for (int s = 0; s < SLOTS; s++) {
 			if (m->staging[s]) (void)hipFree(m->staging[s]);
 			m->staging[s] = nullptr;
-			M_HIP(m, hipMalloc(reinterpret_cast<void**>(&m->staging[s]), need_staging));
 		}
+		for (int s = 0; s < SLOTS; s++) M_HIP(m, hipMalloc(reinterpret_cast<void**>(&m->staging[s]), need_staging));
 		m->staging_bytes = need_staging;
 	}
 	return LOL_GPU_OK;
@@ -243,14 +253,67 @@ int lol_gpu_part_frame_row(int h, const lol_gpu_rows* rows, int local_row) {
 	return (band * rows->n_parts + rows->part) * rows->band_rows + (local_row - band * rows->band_rows);
 }
 
+int lol_gpu_deal_parts(int n_devices, int per_dev, int root_parts, int* owner, int cap) {
+	if (n_devices < 1 || per_dev < 1 || root_parts < 0 || root_parts > per_dev) return LOL_GPU_ERR_ARG;
+	if (n_devices == 1) root_parts = per_dev;             /* the only device owns everything */
+	const int n_parts = (n_devices - 1) * per_dev + root_parts;
+	if (n_parts < 1 || n_parts > MAX_PARTS || (owner && cap < n_parts)) return LOL_GPU_ERR_ARG;
+	int p = 0;
+	for (int round = 0; round < per_dev; round++)
+		for (int d = 0; d < n_devices; d++) {
+			if (d == 0 && round >= root_parts) continue;      /* the root sits out the last rounds */
+			if (owner) owner[p] = d;
+			p++;
+		}
+	return n_parts;
+}
+
+int lol_gpu_choose_band_rows_for(int h, const int* owner, int n_parts, int n_devices) {
+	if (h <= 0 || !owner || n_parts < 1 || n_parts > MAX_PARTS || n_devices < 1) return 0;
+	if (n_parts == 1) return h;
+	/* the cost of a frame is its busiest device: fewest rows there wins, the taller band on ties (bands are multiples
+	 * of the kernel's 4-row wave patch, so no wave straddles two bands) */
+	int best = 0;
+	long best_rows = -1;
+	for (int band = 16; band >= 4; band -= 4) {
+		long rows[LOL_GPU_MULTI_MAX_DEVICES] = { 0 };
+		for (int part = 0; part < n_parts; part++) {
+			lol_gpu_rows R = { band, n_parts, part };
+			if (owner[part] < 0 || owner[part] >= n_devices || owner[part] >= LOL_GPU_MULTI_MAX_DEVICES) return 0;
+			rows[owner[part]] += lol_gpu_part_rows(h, &R);
+		}
+		long mx = 0;
+		for (int d = 0; d < n_devices; d++) if (rows[d] > mx) mx = rows[d];
+		if (best_rows < 0 || mx < best_rows) { best_rows = mx; best = band; }
+	}
+	return best;
+}
+
+static int assemble_with(lol_gpu* ctx, const void* parts, const PartTable& tab, int n_parts, int band_rows, int w, int h,
+                         void* dst, size_t pitch_bytes, void* stream);
+
+int lol_gpu_assemble_parts_at(lol_gpu* ctx, const void* parts, const uint32_t* part_row0, int n_parts, int band_rows,
+                              int w, int h, void* dst, size_t pitch_bytes, void* stream) {
+	if (!part_row0 || n_parts < 1 || n_parts > MAX_PARTS) return LOL_GPU_ERR_ARG;
+	PartTable tab;
+	for (int r = 0; r < n_parts; r++) tab.row0[r] = part_row0[r];
+	return assemble_with(ctx, parts, tab, n_parts, band_rows, w, h, dst, pitch_bytes, stream);
+}
+
 int lol_gpu_assemble_parts(lol_gpu* ctx, const void* parts, int n_parts, int band_rows, int w, int h,
                            void* dst, size_t pitch_bytes, void* stream) {
+	if (n_parts < 1 || n_parts > MAX_PARTS || band_rows < 1 || h < 1) return LOL_GPU_ERR_ARG;
+	PartTable tab;
+	if (!fill_table(tab, n_parts, band_rows, h)) return LOL_GPU_ERR_ARG;
+	return assemble_with(ctx, parts, tab, n_parts, band_rows, w, h, dst, pitch_bytes, stream);
+}
+
+static int assemble_with(lol_gpu* ctx, const void* parts, const PartTable& tab, int n_parts, int band_rows, int w, int h,
+                         void* dst, size_t pitch_bytes, void* stream) {
 	if (!ctx || !parts || !dst) return LOL_GPU_ERR_ARG;
 	if (n_parts < 1 || n_parts > MAX_PARTS || band_rows < 1 || w < 1 || h < 1 ||
 	    pitch_bytes % 4 || pitch_bytes < (size_t)w * 4)
 		return LOL_GPU_ERR_ARG;
-	PartTable tab;
-	if (!fill_table(tab, n_parts, band_rows, h)) return LOL_GPU_ERR_ARG;
 	if (hipSetDevice(lol_gpu_device(ctx)) != hipSuccess) return LOL_GPU_ERR_HIP;
 	hipStream_t s = static_cast<hipStream_t>(stream);
 	if (!s) {
@@ -300,6 +363,9 @@ int lol_gpu_multi_create(const int* devices, int n, lol_gpu_multi** out) {
 		if (e != hipSuccess) return bail("event setup", hipGetErrorString(e));
 	}
 	if (const char* e = getenv("LOL_GPU_MULTI_HOST_VIA_ROOT")) m->host_via_root = e[0] == '1';
+	if (const char* hm = getenv("LOL_GPU_HOST_MODE"))
+		m->host_mode = !strcmp(hm, "copy") ? LOL_GPU_HOST_COPY : !strcmp(hm, "pageable") ? LOL_GPU_HOST_PAGEABLE : LOL_GPU_HOST_DIRECT;
+	m->n_parts = lol_gpu_deal_parts(n, m->per_dev, m->root_parts, m->owner, MAX_PARTS);
 	*out = m;
 	return LOL_GPU_OK;
 }
@@ -366,6 +432,32 @@ int lol_gpu_multi_set_parts_per_device(lol_gpu_multi* m, int parts) {
 	int st = lol_gpu_multi_sync(m);
 	if (st != LOL_GPU_OK) return st;
 	m->per_dev = parts;
+	m->root_parts = parts;                                 /* equal shares until lol_gpu_multi_set_root_parts says otherwise */
+	m->n_parts = lol_gpu_deal_parts(m->n, m->per_dev, m->root_parts, m->owner, MAX_PARTS);
+	return LOL_GPU_OK;
+}
+
+int lol_gpu_multi_set_root_parts(lol_gpu_multi* m, int root_parts) {
+	if (!m || root_parts < 0 || root_parts > m->per_dev || (m->n == 1 && root_parts != m->per_dev)) return LOL_GPU_ERR_ARG;
+	int st = lol_gpu_multi_sync(m);
+	if (st != LOL_GPU_OK) return st;
+	m->root_parts = root_parts;
+	m->n_parts = lol_gpu_deal_parts(m->n, m->per_dev, m->root_parts, m->owner, MAX_PARTS);
+	return LOL_GPU_OK;
+}
+
+int lol_gpu_multi_set_host_mode(lol_gpu_multi* m, int mode) {
+	if (!m || mode < LOL_GPU_HOST_DIRECT || mode > LOL_GPU_HOST_PAGEABLE) return LOL_GPU_ERR_ARG;
+	m->host_mode = mode;
+	return LOL_GPU_OK;
+}
+
+int lol_gpu_multi_set_pixel_format(lol_gpu_multi* m, const lol_gpu_pixel_format* fmt) {
+	if (!m) return LOL_GPU_ERR_ARG;
+	for (int i = 0; i < m->n; i++) {
+		int st = lol_gpu_set_pixel_format(m->dev[i].ctx, fmt);
+		if (st != LOL_GPU_OK) return mfail(m, st, "lol_gpu_set_pixel_format", lol_gpu_error(m->dev[i].ctx));
+	}
 	return LOL_GPU_OK;
 }
 
@@ -392,24 +484,29 @@ static int ensure_comms(lol_gpu_multi* m) {
 struct Split { int band; PartTable tab; uint32_t dev_row0[LOL_GPU_MULTI_MAX_DEVICES], dev_rows[LOL_GPU_MULTI_MAX_DEVICES]; };
 
 static int split_frame(lol_gpu_multi* m, int h, Split& S) {
-	const int n_parts = m->n * m->per_dev;
-	S.band = m->band_override > 0 ? m->band_override : lol_gpu_choose_band_rows(h, n_parts);
-	if (!fill_device_major(S.tab, S.dev_row0, S.dev_rows, m->n, m->per_dev, S.band, h)) return mfail(m, LOL_GPU_ERR_ARG, "bad row partition");
+	const bool equal = m->root_parts == m->per_dev;
+	S.band = m->band_override > 0 ? m->band_override
+	       : equal ? lol_gpu_choose_band_rows(h, m->n_parts) : lol_gpu_choose_band_rows_for(h, m->owner, m->n_parts, m->n);
+	if (S.band <= 0 || !fill_device_major(S.tab, S.dev_row0, S.dev_rows, m->owner, m->n_parts, m->n, S.band, h))
+		return mfail(m, LOL_GPU_ERR_ARG, "bad row partition");
 	return LOL_GPU_OK;
 }
 
 /* queue the kernels of one frame: device d renders its parts back to back into part[slot] on its render stream */
-static int render_parts(lol_gpu_multi* m, const lol_frame_camera* cam, int w, int h, int max_steps, const Split& S, int slot) {
-	const int n_parts = m->n * m->per_dev;
+/* `surface` != nullptr: the kernels store straight into that whole-frame surface (device d's view of it: surface[d]),
+ * every row at its frame position, instead of into the compact part buffers */
+static int render_parts(lol_gpu_multi* m, const lol_frame_camera* cam, int w, int h, int max_steps, const Split& S, int slot,
+                        void* const* surface = nullptr, size_t surface_pitch = 0) {
 	for (int d = 0; d < m->n; d++) {
 		Device& D = m->dev[d];
 		M_HIP(m, hipSetDevice(D.id));
 		M_HIP(m, hipStreamWaitEvent(D.render, D.sent[slot], 0));      /* the frame two back has left part[slot] */
-		for (int j = 0; j < m->per_dev; j++) {
-			lol_gpu_rows R = { S.band, n_parts, d + j * m->n };
+		for (int part = 0; part < m->n_parts; part++) {
+			if (m->owner[part] != d) continue;
+			lol_gpu_rows R = { S.band, m->n_parts, part, surface ? 1 : 0 };
 			if (lol_gpu_part_rows(h, &R) <= 0) continue;
-			uint32_t* dst = D.part[slot] + (size_t)(S.tab.row0[R.part] - S.dev_row0[d]) * w;
-			int st = lol_gpu_render_device(D.ctx, cam, w, h, max_steps, &R, dst, (size_t)w * 4, nullptr, D.render);
+			void* dst = surface ? surface[d] : static_cast<void*>(D.part[slot] + (size_t)(S.tab.row0[part] - S.dev_row0[d]) * w);
+			int st = lol_gpu_render_device(D.ctx, cam, w, h, max_steps, &R, dst, surface ? surface_pitch : (size_t)w * 4, nullptr, D.render);
 			if (st != LOL_GPU_OK) return mfail(m, st, "lol_gpu_render_device", lol_gpu_error(D.ctx));
 		}
 		M_HIP(m, hipEventRecord(D.rendered[slot], D.render));
@@ -454,7 +551,7 @@ int lol_gpu_multi_render_device(lol_gpu_multi* m, const lol_frame_camera* cam, i
 		M_HIP(m, hipEventRecord(m->dev[d].sent[slot], m->dev[d].xchg));
 	}
 	M_HIP(m, hipSetDevice(root.id));
-	M_HIP(m, launch_assemble(m->staging[slot], S.tab, n * m->per_dev, S.band, w, h, dst, pitch_bytes, root.xchg));
+	M_HIP(m, launch_assemble(m->staging[slot], S.tab, m->n_parts, S.band, w, h, dst, pitch_bytes, root.xchg));
 	M_HIP(m, hipEventRecord(m->done[slot], root.xchg));
 	return LOL_GPU_OK;
 }
@@ -520,24 +617,44 @@ int lol_gpu_multi_render_host(lol_gpu_multi* m, const lol_frame_camera* cam, int
 		M_HIP(m, hipStreamSynchronize(root.xchg));
 		return LOL_GPU_OK;
 	}
-	/* every device copies its own bands into the surface: N links in parallel, no exchange, no RCCL */
+	/* every device writes its own bands into the surface: N links in parallel, no exchange, no RCCL */
 	Split S;
 	int st = split_frame(m, h, S);
 	if (st != LOL_GPU_OK) return st;
-	st = ensure_buffers(m, w, h, S.dev_rows, false);
-	if (st != LOL_GPU_OK) return st;
+	/* pinned and mapped for every device, so that the copies are real asynchronous DMAs (pageable memory is staged by
+	 * the runtime on THIS thread, one device after the other) — or no copies at all */
+	const bool pinned = m->host_mode != LOL_GPU_HOST_PAGEABLE &&
+	                    lol_gpu_pin_host(host_pixels, pitch_bytes * (size_t)(h - 1) + (size_t)w * 4, nullptr) == LOL_GPU_OK;
+	void* view[LOL_GPU_MULTI_MAX_DEVICES] = { nullptr };
+	bool direct = pinned && m->host_mode == LOL_GPU_HOST_DIRECT && pitch_bytes % 4 == 0 && reinterpret_cast<uintptr_t>(host_pixels) % 4 == 0;
+	for (int d = 0; d < m->n && direct; d++) {
+		M_HIP(m, hipSetDevice(m->dev[d].id));
+		if (hipHostGetDevicePointer(&view[d], host_pixels, 0) != hipSuccess || !view[d]) { (void)hipGetLastError(); direct = false; }
+	}
 	const int slot = (int)(m->frames % SLOTS);
 	m->frames++;
+	if (direct) {
+		st = render_parts(m, cam, w, h, max_steps, S, slot, view, pitch_bytes);
+		if (st != LOL_GPU_OK) return st;
+		for (int d = 0; d < m->n; d++) {
+			M_HIP(m, hipSetDevice(m->dev[d].id));
+			M_HIP(m, hipStreamSynchronize(m->dev[d].render));
+		}
+		M_HIP(m, hipSetDevice(root.id));
+		return LOL_GPU_OK;
+	}
+	st = ensure_buffers(m, w, h, S.dev_rows, false);
+	if (st != LOL_GPU_OK) return st;
 	st = render_parts(m, cam, w, h, max_steps, S, slot);
 	if (st != LOL_GPU_OK) return st;
-	const int n_parts = m->n * m->per_dev;
 	for (int d = 0; d < m->n; d++) {
 		Device& D = m->dev[d];
 		M_HIP(m, hipSetDevice(D.id));
-		for (int j = 0; j < m->per_dev; j++) {
-			lol_gpu_rows R = { S.band, n_parts, d + j * m->n };
+		for (int part = 0; part < m->n_parts; part++) {
+			if (m->owner[part] != d) continue;
+			lol_gpu_rows R = { S.band, m->n_parts, part };
 			if (lol_gpu_part_rows(h, &R) <= 0) continue;
-			st = copy_part_to_host(m, D.part[slot] + (size_t)(S.tab.row0[R.part] - S.dev_row0[d]) * w, R, w, h,
+			st = copy_part_to_host(m, D.part[slot] + (size_t)(S.tab.row0[part] - S.dev_row0[d]) * w, R, w, h,
 			                       static_cast<char*>(host_pixels), pitch_bytes, D.xchg);
 			if (st != LOL_GPU_OK) return st;
 		}

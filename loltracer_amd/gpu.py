@@ -22,7 +22,27 @@ _STATUS = {0: "ok", -1: "no HIP device", -2: "HIP runtime error", -3: "bad argum
 
 class Rows(C.Structure):
     """lol_gpu_rows: band-interleaved row partition (multi-GPU row tiles)."""
-    _fields_ = [("band_rows", C.c_int32), ("n_parts", C.c_int32), ("part", C.c_int32)]
+    _fields_ = [("band_rows", C.c_int32), ("n_parts", C.c_int32), ("part", C.c_int32), ("in_place", C.c_int32)]
+
+
+class PixelFormat(C.Structure):
+    """lol_gpu_pixel_format: the SDL_PixelFormat fields SDL_MapRGB reads (renderer.h:17-22)."""
+    _fields_ = [("r_shift", C.c_uint8), ("g_shift", C.c_uint8), ("b_shift", C.c_uint8),
+                ("r_loss", C.c_uint8), ("g_loss", C.c_uint8), ("b_loss", C.c_uint8),
+                ("bytes_per_pixel", C.c_uint8), ("palettised", C.c_uint8), ("a_mask", C.c_uint32)]
+
+
+# SDL's names for the packed 32-bit formats (SDL_pixels.h) + two the renderer must refuse
+PIXEL_FORMATS = {
+    "xrgb8888": PixelFormat(16, 8, 0, 0, 0, 0, 4, 0, 0x00000000),
+    "argb8888": PixelFormat(16, 8, 0, 0, 0, 0, 4, 0, 0xFF000000),
+    "bgrx8888": PixelFormat(8, 16, 24, 0, 0, 0, 4, 0, 0x00000000),
+    "rgba8888": PixelFormat(24, 16, 8, 0, 0, 0, 4, 0, 0x000000FF),
+    "abgr8888": PixelFormat(0, 8, 16, 0, 0, 0, 4, 0, 0xFF000000),
+    "rgb565": PixelFormat(11, 5, 0, 3, 2, 3, 2, 0, 0),
+    "index8": PixelFormat(0, 0, 0, 8, 8, 8, 1, 1, 0),
+}
+HOST_DIRECT, HOST_COPY, HOST_PAGEABLE = 0, 1, 2
 
 
 class Debug(C.Structure):
@@ -78,10 +98,26 @@ def gpu_lib() -> C.CDLL:
         lib.lol_gpu_render_host.restype = C.c_int
         lib.lol_gpu_render_host_begin.argtypes = [vp, P(S.FrameCamera), C.c_int, C.c_int, C.c_int]
         lib.lol_gpu_render_host_begin.restype = C.c_int
-        lib.lol_gpu_render_host_end.argtypes = [vp, vp, C.c_size_t]
+        lib.lol_gpu_render_host_end.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int]
         lib.lol_gpu_render_host_end.restype = C.c_int
         lib.lol_gpu_render_host_pending.argtypes = [vp]
         lib.lol_gpu_render_host_pending.restype = C.c_int
+        lib.lol_gpu_render_host_pending_size.argtypes = [vp, P(C.c_int), P(C.c_int)]
+        lib.lol_gpu_render_host_pending_size.restype = C.c_int
+        lib.lol_gpu_render_host_discard.argtypes = [vp]
+        lib.lol_gpu_render_host_discard.restype = C.c_int
+        lib.lol_gpu_set_pixel_format.argtypes = [vp, P(PixelFormat)]
+        lib.lol_gpu_set_pixel_format.restype = C.c_int
+        lib.lol_gpu_set_host_mode.argtypes = [vp, C.c_int]
+        lib.lol_gpu_set_host_mode.restype = C.c_int
+        lib.lol_gpu_host_mode_used.argtypes = [vp]
+        lib.lol_gpu_host_mode_used.restype = C.c_int
+        lib.lol_gpu_pin_host.argtypes = [vp, C.c_size_t, P(vp)]
+        lib.lol_gpu_pin_host.restype = C.c_int
+        lib.lol_gpu_unpin_host.argtypes = [vp]
+        lib.lol_gpu_unpin_host.restype = C.c_int
+        lib.lol_gpu_kernel_key.argtypes = [vp]
+        lib.lol_gpu_kernel_key.restype = C.c_char_p
         lib.lol_gpu_sync.argtypes = [vp]
         lib.lol_gpu_sync.restype = C.c_int
         lib.lol_gpu_malloc.argtypes = [vp, C.c_size_t, P(vp)]
@@ -151,6 +187,18 @@ def gpu_lib() -> C.CDLL:
         lib.lol_gpu_multi_memcpy_d2h.restype = C.c_int
         lib.lol_gpu_assemble_parts.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]
         lib.lol_gpu_assemble_parts.restype = C.c_int
+        lib.lol_gpu_assemble_parts_at.argtypes = [vp, vp, P(C.c_uint32), C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]
+        lib.lol_gpu_assemble_parts_at.restype = C.c_int
+        lib.lol_gpu_deal_parts.argtypes = [C.c_int, C.c_int, C.c_int, P(C.c_int), C.c_int]
+        lib.lol_gpu_deal_parts.restype = C.c_int
+        lib.lol_gpu_choose_band_rows_for.argtypes = [C.c_int, P(C.c_int), C.c_int, C.c_int]
+        lib.lol_gpu_choose_band_rows_for.restype = C.c_int
+        lib.lol_gpu_multi_set_root_parts.argtypes = [vp, C.c_int]
+        lib.lol_gpu_multi_set_root_parts.restype = C.c_int
+        lib.lol_gpu_multi_set_host_mode.argtypes = [vp, C.c_int]
+        lib.lol_gpu_multi_set_host_mode.restype = C.c_int
+        lib.lol_gpu_multi_set_pixel_format.argtypes = [vp, P(PixelFormat)]
+        lib.lol_gpu_multi_set_pixel_format.restype = C.c_int
         _lib = lib
     return _lib
 
@@ -167,6 +215,10 @@ EXPORTED_SYMBOLS = [
     "lol_gpu_part_frame_row", "lol_gpu_multi_render_device", "lol_gpu_multi_render_host", "lol_gpu_multi_sync",
     "lol_gpu_multi_malloc", "lol_gpu_multi_free", "lol_gpu_multi_memcpy_d2h", "lol_gpu_assemble_parts",
     "lol_gpu_multi_set_parts_per_device", "lol_gpu_multi_set_host_via_root",
+    "lol_gpu_set_pixel_format", "lol_gpu_set_host_mode", "lol_gpu_host_mode_used", "lol_gpu_pin_host", "lol_gpu_unpin_host",
+    "lol_gpu_render_host_pending_size", "lol_gpu_render_host_discard", "lol_gpu_kernel_key",
+    "lol_gpu_assemble_parts_at", "lol_gpu_deal_parts", "lol_gpu_choose_band_rows_for", "lol_gpu_multi_set_root_parts",
+    "lol_gpu_multi_set_host_mode", "lol_gpu_multi_set_pixel_format",
 ]
 
 
@@ -182,6 +234,30 @@ def compile_offline(program: S.Program, out_base: str, arch: str = "gfx950", ass
 
 def part_rows(h: int, rows: Rows | None) -> int:
     return gpu_lib().lol_gpu_part_rows(h, C.byref(rows) if rows is not None else None)
+
+
+def deal_parts(n_devices: int, per_dev: int, root_parts: int) -> list:
+    """owner[p] of lol_gpu_deal_parts (pure host logic, no device needed)."""
+    owner = (C.c_int * 64)()
+    n = gpu_lib().lol_gpu_deal_parts(n_devices, per_dev, root_parts, owner, 64)
+    if n < 0:
+        raise GpuError(n, f"lol_gpu_deal_parts({n_devices}, {per_dev}, {root_parts})")
+    return list(owner[:n])
+
+
+def choose_band_rows_for(h: int, owner: list, n_devices: int) -> int:
+    arr = (C.c_int * len(owner))(*owner)
+    return int(gpu_lib().lol_gpu_choose_band_rows_for(h, arr, len(owner), n_devices))
+
+
+def assemble_parts_at(ctx_renderer, parts_ptr: int, part_row0: list, band_rows: int, w: int, h: int, dst_ptr: int,
+                      pitch_bytes: int, stream: int | None):
+    """lol_gpu_assemble_parts_at on the renderer's device: un-interleave gathered parts (device pointers)."""
+    arr = (C.c_uint32 * len(part_row0))(*part_row0)
+    st = gpu_lib().lol_gpu_assemble_parts_at(ctx_renderer._ctx, C.c_void_p(parts_ptr), arr, len(part_row0), band_rows, w, h,
+                                             C.c_void_p(dst_ptr), pitch_bytes, _stream_arg(stream))
+    if st != LOL_GPU_OK:
+        raise GpuError(st, "lol_gpu_assemble_parts_at")
 
 
 class Renderer:
@@ -234,11 +310,35 @@ class Renderer:
         fc = self.scene.frame_camera(w, h, camera)
         self._check(self._lib.lol_gpu_render_host_begin(self._ctx, C.byref(fc), w, h, max_steps))
 
-    def render_host_end(self, host_ptr: int, pitch_bytes: int):
-        self._check(self._lib.lol_gpu_render_host_end(self._ctx, C.c_void_p(host_ptr), pitch_bytes))
+    def render_host_end(self, host_ptr: int, pitch_bytes: int, w: int, h: int):
+        """Deliver the oldest queued frame into a surface of w x h (refused when the frame has another size)."""
+        self._check(self._lib.lol_gpu_render_host_end(self._ctx, C.c_void_p(host_ptr), pitch_bytes, w, h))
 
     def render_host_pending(self) -> int:
         return int(self._lib.lol_gpu_render_host_pending(self._ctx))
+
+    def render_host_pending_size(self):
+        w, h = C.c_int(), C.c_int()
+        self._check(self._lib.lol_gpu_render_host_pending_size(self._ctx, C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    def render_host_discard(self):
+        self._check(self._lib.lol_gpu_render_host_discard(self._ctx))
+
+    def set_pixel_format(self, fmt: "PixelFormat | str | None"):
+        """The surface's SDL_PixelFormat (None = XRGB8888); raises for palettised / non-32-bit formats."""
+        if isinstance(fmt, str):
+            fmt = PIXEL_FORMATS[fmt]
+        self._check(self._lib.lol_gpu_set_pixel_format(self._ctx, C.byref(fmt) if fmt is not None else None))
+
+    def set_host_mode(self, mode: int):
+        self._check(self._lib.lol_gpu_set_host_mode(self._ctx, mode))
+
+    def host_mode_used(self) -> int:
+        return int(self._lib.lol_gpu_host_mode_used(self._ctx))
+
+    def kernel_key(self) -> str:
+        return self._lib.lol_gpu_kernel_key(self._ctx).decode()
 
     def sync(self):
         self._check(self._lib.lol_gpu_sync(self._ctx))
@@ -323,6 +423,17 @@ class MultiRenderer:
 
     def set_host_via_root(self, enable: bool):
         self._check(self._lib.lol_gpu_multi_set_host_via_root(self._m, 1 if enable else 0))
+
+    def set_root_parts(self, root_parts: int):
+        self._check(self._lib.lol_gpu_multi_set_root_parts(self._m, root_parts))
+
+    def set_host_mode(self, mode: int):
+        self._check(self._lib.lol_gpu_multi_set_host_mode(self._m, mode))
+
+    def set_pixel_format(self, fmt):
+        if isinstance(fmt, str):
+            fmt = PIXEL_FORMATS[fmt]
+        self._check(self._lib.lol_gpu_multi_set_pixel_format(self._m, C.byref(fmt) if fmt is not None else None))
 
     def render_into(self, dst_ptr: int, w: int, h: int, max_steps: int = 256, camera: S.Camera | None = None,
                     pitch_bytes: int | None = None, frame_camera: S.FrameCamera | None = None):

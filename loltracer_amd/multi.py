@@ -3,18 +3,27 @@
 The reference parallelises a frame by letting workers claim scan-lines from an
 atomic counter (naive_renderer.c:216, main.c:189-194): every pixel is
 independent.  Across GPUs the same independence is used statically: the frame's
-rows are cut into bands of `band_rows`, band b goes to rank b % world (fine
-interleave, so sky rows and blob rows are spread evenly), each rank renders its
-bands compactly (include/lol_gpu.h, lol_gpu_rows) and one gather over
-RCCL/xGMI brings the parts to rank 0, which un-interleaves them.  One process
-per GPU; torch.distributed is only the transport.
+rows are cut into bands of `band_rows`, band b goes to part b % n_parts (fine
+interleave, so sky rows and blob rows are spread evenly), every part belongs to
+one rank, each rank renders its parts compactly (include/lol_gpu.h,
+lol_gpu_rows) and one gather over RCCL/xGMI brings them to rank 0, which
+un-interleaves them.  One process per GPU; torch.distributed is only the
+transport.
+
+Cost-weighted split (`Partition`): rank 0 also receives and un-interleaves the
+whole frame, so with an equal share it is the straggler.  The parts are dealt
+round-robin over the ranks, `per_rank` rounds of one part each, and the root
+sits out the last `per_rank - root_parts` rounds — the same dealing as
+lol_gpu_deal_parts behind the C ABI, so both hosts cut a frame identically.
 
 Everything here is device-agnostic (tensors in, tensors out) so the same code
-runs under gloo on CPU in the tests and under nccl (= RCCL) on MI355X.
+runs under gloo on CPU in the tests and under nccl (= RCCL) on MI355X; on a GPU
+the un-interleave is the library's uint4 kernel (lol_gpu_assemble_parts_at,
+injected as `assembler`), on the CPU an index_select.
 """
 from __future__ import annotations
 
-from typing import Callable, Optional
+from typing import Callable, List, Optional
 
 import torch
 import torch.distributed as dist
@@ -61,6 +70,84 @@ def assemble(parts: torch.Tensor, h: int, band_rows: int) -> torch.Tensor:
     return parts.view(world, nb, band_rows, w).permute(1, 0, 2, 3).reshape(h, w)
 
 
+def deal_parts(world: int, per_rank: int, root_parts: Optional[int] = None) -> List[int]:
+    """owner[p] = rank of part p: per_rank rounds of one part per rank, the root (rank 0) sitting out the last
+    per_rank - root_parts rounds.  Mirrors lol_gpu_deal_parts (include/lol_gpu.h)."""
+    if root_parts is None or world == 1:
+        root_parts = per_rank
+    if world < 1 or per_rank < 1 or not 0 <= root_parts <= per_rank:
+        raise ValueError(f"deal_parts({world}, {per_rank}, {root_parts})")
+    return [r for rnd in range(per_rank) for r in range(world) if not (r == 0 and rnd >= root_parts)]
+
+
+def choose_band_rows_for(h: int, owner: List[int], world: int) -> int:
+    """Band height for a deal: the multiple of 4 up to 16 that leaves the busiest rank the fewest rows (ties: the
+    taller band).  Mirrors lol_gpu_choose_band_rows_for."""
+    n_parts = len(owner)
+    if n_parts == 1:
+        return h
+    best, best_rows = 0, -1
+    for band in (16, 12, 8, 4):
+        rows = [0] * world
+        for p, r in enumerate(owner):
+            rows[r] += part_rows(h, band, n_parts, p)
+        if best_rows < 0 or max(rows) < best_rows:
+            best, best_rows = band, max(rows)
+    return best
+
+
+class Partition:
+    """How one frame of `h` rows is cut over `world` ranks: the same on every rank.
+
+    band          band height
+    owner[p]      rank of part p;  parts_of[r] = the parts of rank r, ascending
+    rows_of[p]    rows part p holds;  rank_rows[r] = rows rank r renders
+    max_rows      rows of every rank's local buffer (padded to the largest, so one gather of equal tensors serves)
+    local_row0[p] first row of part p inside its owner's local buffer (parts back to back)
+    part_row0[p]  first row of part p inside the gathered [world * max_rows, w] staging buffer
+    """
+
+    def __init__(self, h: int, world: int, per_rank: int = 1, root_parts: Optional[int] = None, band_rows: int = 0):
+        self.h, self.world, self.per_rank = h, world, per_rank
+        self.owner = deal_parts(world, per_rank, root_parts)
+        self.root_parts = per_rank if (root_parts is None or world == 1) else root_parts
+        self.n_parts = len(self.owner)
+        equal = self.root_parts == per_rank
+        self.band = band_rows or ((choose_band_rows(h, self.n_parts) if equal else 0)
+                                  or choose_band_rows_for(h, self.owner, world))
+        if self.band <= 0:
+            raise ValueError(f"cannot cut {h} rows into bands for {self.n_parts} parts")
+        self.parts_of = [[p for p in range(self.n_parts) if self.owner[p] == r] for r in range(world)]
+        self.rows_of = [part_rows(h, self.band, self.n_parts, p) for p in range(self.n_parts)]
+        self.rank_rows = [sum(self.rows_of[p] for p in ps) for ps in self.parts_of]
+        assert sum(self.rank_rows) == h
+        self.max_rows = max(self.rank_rows)
+        self.local_row0, self.part_row0 = [0] * self.n_parts, [0] * self.n_parts
+        for r, ps in enumerate(self.parts_of):
+            row = 0
+            for p in ps:
+                self.local_row0[p] = row
+                self.part_row0[p] = r * self.max_rows + row
+                row += self.rows_of[p]
+
+    def frame_rows_of_rank(self, rank: int) -> torch.Tensor:
+        """Frame row of every (used) local row of `rank`, parts back to back."""
+        ys = [frame_rows_of_part(self.h, self.band, self.n_parts, p) for p in self.parts_of[rank]]
+        return torch.cat(ys) if ys else torch.zeros(0, dtype=torch.long)
+
+    def staging_index(self) -> torch.Tensor:
+        """index[y] = row of the gathered staging buffer that holds frame row y."""
+        idx = torch.empty(self.h, dtype=torch.long)
+        for p in range(self.n_parts):
+            ys = frame_rows_of_part(self.h, self.band, self.n_parts, p)
+            idx[ys] = self.part_row0[p] + torch.arange(len(ys))
+        return idx
+
+    def describe(self) -> dict:
+        return {"band_rows": self.band, "n_parts": self.n_parts, "parts_per_rank": self.per_rank,
+                "root_parts": self.root_parts, "rows_per_rank": self.rank_rows}
+
+
 def gather_frame(local: torch.Tensor, h: int, band_rows: int, group=None, dst: int = 0,
                  out: Optional[torch.Tensor] = None, staging: Optional[torch.Tensor] = None
                  ) -> Optional[torch.Tensor]:
@@ -90,39 +177,57 @@ def gather_frame(local: torch.Tensor, h: int, band_rows: int, group=None, dst: i
 class GatherPipeline:
     """Frames in flight: while frame i's parts travel to `dst`, frame i+1 is already rendering.
 
-    Each rank owns `depth` local part buffers.  submit(render) renders the next frame's part into
-    the next buffer (after making sure the gather that last read that buffer has finished) and
-    starts an asynchronous gather of it; on `dst` the gathered parts are un-interleaved into
-    `frame` when their gather is waited for.  drain() completes everything in flight.  A renderer
-    that produces a stream of frames (the reference's frame loop, main.c:163-211) loses nothing by
-    this: every frame still ends up assembled on `dst`, in order.
+    Each rank owns `depth` local buffers of partition.max_rows rows.  submit(render) renders the next frame's parts
+    into the next buffer (after making sure the gather that last read that buffer has finished) and starts an
+    asynchronous gather of it; on `dst` the gathered parts are un-interleaved into `frame` when their gather is waited
+    for.  drain() completes everything in flight.  A renderer that produces a stream of frames (the reference's frame
+    loop, main.c:163-211) loses nothing by this: every frame still ends up assembled on `dst`, in order.
+
+    `assembler(staging, frame, partition, stream_handle)`: the un-interleave on a GPU (bench.py passes the library's
+    lol_gpu_assemble_parts_at); None = index_select (CPU tensors, tests).
     """
 
     def __init__(self, w: int, h: int, band_rows: int, device, group=None, dst: int = 0, depth: int = 2,
-                 dtype=torch.int32, force_collective: bool = False):
-        self.group, self.dst, self.h, self.w, self.band = group, dst, h, w, band_rows
+                 dtype=torch.int32, force_collective: bool = False, partition: Optional[Partition] = None,
+                 assembler: Optional[Callable] = None):
+        self.group, self.dst, self.h, self.w = group, dst, h, w
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         # force_collective: run the gather even in a 1-rank group (exercises the backend's gather on one device)
         self.single = self.world == 1 and not (force_collective and dist.is_initialized())
-        if self.world > 1 and h % (band_rows * self.world) != 0:
-            raise ValueError(f"h={h} must be a multiple of band_rows*world={band_rows * self.world}")
-        self.rows = part_rows(h, band_rows, self.world, self.rank) if self.world > 1 else h
+        if dst != 0:
+            raise ValueError("the root of the partition is rank 0")
+        self.partition = partition if partition is not None else Partition(h, self.world, 1, None, band_rows if self.world > 1 else h)
+        P = self.partition
+        if P.h != h:
+            raise ValueError("partition is for another frame height")
+        self.band = P.band
+        # a partition cut for MORE ranks than the group has (bench.py's one-GPU rehearsal of rank 0's cadence):
+        # this rank renders its share, the gather moves what the group has, the assembly covers the whole frame
+        self.rows = P.rank_rows[self.rank]
         self.depth = depth if not self.single else 1
-        self.local = [torch.zeros((self.rows, w), dtype=dtype, device=device) for _ in range(self.depth)]
+        self.local = [torch.zeros((P.max_rows, w), dtype=dtype, device=device) for _ in range(self.depth)]
         self.is_dst = self.rank == dst
-        self.staging = ([torch.empty((self.world, self.rows, w), dtype=dtype, device=device) for _ in range(self.depth)]
+        self.staging = ([torch.zeros((P.world, P.max_rows, w), dtype=dtype, device=device) for _ in range(self.depth)]
                         if not self.single and self.is_dst else None)
         self.frame = torch.empty((h, w), dtype=dtype, device=device) if not self.single and self.is_dst else None
+        self.assembler = assembler
+        self._index = P.staging_index().to(device) if (self.frame is not None and assembler is None) else None
         self.work = [None] * self.depth
         self.n = 0
         self.frames_done = 0
         # On a GPU the root un-interleaves on a stream of its own, so that neither the wait for the parts nor the
-        # 4 B/pixel permuted copy sits in the render stream between two frame kernels; `assembled[slot]` orders the
+        # 4 B/pixel un-interleave sits in the render stream between two frame kernels; `assembled[slot]` orders the
         # next gather into staging[slot] (and the caller's reads of `frame`) after it.
         self.cuda = torch.device(device).type == "cuda"
         self.asm_stream = torch.cuda.Stream(device=device) if self.cuda and self.is_dst and not self.single else None
         self.assembled = [None] * self.depth
+
+    def _assemble(self, slot: int, stream_handle):
+        if self.assembler is not None:
+            self.assembler(self.staging[slot], self.frame, self.partition, stream_handle)
+        else:
+            torch.index_select(self.staging[slot].view(-1, self.w), 0, self._index, out=self.frame)
 
     def _finish(self, slot: int):
         w = self.work[slot]
@@ -134,18 +239,19 @@ class GatherPipeline:
                                                        # collective that reads it (two frames of slack at depth 2)
             with torch.cuda.stream(self.asm_stream):
                 w.wait()                               # orders the assembly stream after the collective
-                self.frame.copy_(assemble(self.staging[slot], self.h, self.band))
+                self._assemble(slot, self.asm_stream.cuda_stream)
                 ev = torch.cuda.Event()
                 ev.record()
             self.assembled[slot] = ev
         else:
             w.wait()                                   # orders the current stream after the collective
             if self.is_dst:
-                self.frame.copy_(assemble(self.staging[slot], self.h, self.band))
+                self._assemble(slot, torch.cuda.current_stream().cuda_stream if self.cuda else None)
         self.frames_done += 1
 
     def submit(self, render):
-        """render(local_part_tensor): enqueue the rendering of this rank's part into the tensor."""
+        """render(local_buffer): enqueue the rendering of this rank's parts into the [max_rows, w] tensor
+        (part p at rows partition.local_row0[p] …)."""
         slot = self.n % self.depth
         self.n += 1
         if self.single:

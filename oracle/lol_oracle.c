@@ -225,12 +225,23 @@ static v3 get_camera_ray(const lol_camera* cam, float vx, float vy, float aspect
 	return v3normalize(v3add(r, cdir));
 }
 
-/* colorf_to_pixfmt with SDL_MapRGB on XRGB8888, renderer.h:17-22 */
+/* colorf_to_pixfmt, renderer.h:17-22: Uint8 channels, then SDL_MapRGB(fmt, r, g, b).  SDL2 is a third-party
+ * dependency of the reference (Makefile:3-4, `sdl2-config`, no version pinned; absent from this image); for a
+ * non-palettised format its SDL_MapRGB is (SDL 2.0.x src/video/SDL_pixels.c)
+ *     (r >> Rloss) << Rshift | (g >> Gloss) << Gshift | (b >> Bloss) << Bshift | Amask
+ * — restated here over the SDL_PixelFormat fields of the surface.  Default XRGB8888 (shifts 16/8/0, no loss, Amask 0),
+ * i.e. r << 16 | g << 8 | b.  Process-wide; set by the tests that check other formats. */
+static lol_oracle_pixel_format g_fmt = { 16, 8, 0, 0, 0, 0, 0 };
+void lol_oracle_set_pixel_format(const lol_oracle_pixel_format* f) {
+	static const lol_oracle_pixel_format xrgb = { 16, 8, 0, 0, 0, 0, 0 };
+	g_fmt = f ? *f : xrgb;
+}
 static uint32_t pack_xrgb(v3 c) {
 	uint8_t r = (uint8_t)(c.x * 255);
 	uint8_t g = (uint8_t)(c.y * 255);
 	uint8_t b = (uint8_t)(c.z * 255);
-	return (uint32_t)r << 16 | (uint32_t)g << 8 | (uint32_t)b;
+	return (uint32_t)(r >> g_fmt.r_loss) << g_fmt.r_shift | (uint32_t)(g >> g_fmt.g_loss) << g_fmt.g_shift |
+	       (uint32_t)(b >> g_fmt.b_loss) << g_fmt.b_shift | g_fmt.a_mask;
 }
 
 /* the pixel body of render_thread, naive_renderer.c:217-235 */

@@ -44,6 +44,14 @@ typedef struct lol_oracle_counters {
 	uint64_t miss_pixels;      /* id == 0 after the march */
 } lol_oracle_counters;
 
+/* The surface's SDL_PixelFormat fields that SDL_MapRGB reads (renderer.h:17-22); NULL / default = XRGB8888.
+ * Process-wide state of the checker (tests only). */
+typedef struct lol_oracle_pixel_format {
+	uint8_t  r_shift, g_shift, b_shift, r_loss, g_loss, b_loss;
+	uint32_t a_mask;
+} lol_oracle_pixel_format;
+void lol_oracle_set_pixel_format(const lol_oracle_pixel_format* f);
+
 /* Per-pixel probe of the intermediate values (for debugging parity failures). */
 typedef struct lol_oracle_probe {
 	float    rd[3];

@@ -24,6 +24,11 @@ class Probe(C.Structure):
                 ("rgb_linear", C.c_float * 3), ("rgb", C.c_float * 3), ("xrgb", C.c_uint32)]
 
 
+class PixelFormat(C.Structure):
+    _fields_ = [("r_shift", C.c_uint8), ("g_shift", C.c_uint8), ("b_shift", C.c_uint8),
+                ("r_loss", C.c_uint8), ("g_loss", C.c_uint8), ("b_loss", C.c_uint8), ("a_mask", C.c_uint32)]
+
+
 _lib = None
 
 
@@ -52,6 +57,8 @@ def lib() -> C.CDLL:
         l.lol_oracle_powf_batch.restype = None
         l.lol_oracle_hash_xrgb.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t]
         l.lol_oracle_hash_xrgb.restype = C.c_uint64
+        l.lol_oracle_set_pixel_format.argtypes = [P(PixelFormat)]
+        l.lol_oracle_set_pixel_format.restype = None
         f3 = P(C.c_float)
         for name, args, res in [
             ("lol_oracle_minf", [C.c_float] * 2, C.c_float), ("lol_oracle_maxf", [C.c_float] * 2, C.c_float),
@@ -118,3 +125,13 @@ def hash_xrgb(xrgb: np.ndarray) -> int:
     a = np.ascontiguousarray(xrgb, dtype=np.uint32)
     h, w = a.shape
     return int(lib().lol_oracle_hash_xrgb(a.ctypes.data, w, h, w * 4))
+
+
+def set_pixel_format(fmt=None):
+    """The checker's surface format (None = XRGB8888): shifts, losses, Amask of an SDL_PixelFormat, or a
+    loltracer_amd.gpu.PixelFormat.  Process-wide: reset it (None) when done."""
+    if fmt is None:
+        lib().lol_oracle_set_pixel_format(None)
+        return
+    f = PixelFormat(fmt.r_shift, fmt.g_shift, fmt.b_shift, fmt.r_loss, fmt.g_loss, fmt.b_loss, fmt.a_mask)
+    lib().lol_oracle_set_pixel_format(C.byref(f))

@@ -1,0 +1,291 @@
+"""The boundary the reference's host sees: surf->pixels is HOST memory of whatever size and pixel
+format the window has this frame (main.c:157,182-187; renderer.h:17-22).
+
+  - colorf_to_pixfmt maps through the SURFACE's format: the kernel's pack equals SDL_MapRGB's definition, computed
+    here in numpy from the float colours, for XRGB / ARGB / BGRX / RGBA / ABGR; palettised and 16-bit are refused;
+  - pixels reach the surface directly from the kernel (pinned + mapped), by an asynchronous copy, or pageable: same bits;
+  - the surface may change size between frames, with frames in flight: nothing is ever written beyond a surface;
+  - a rejected scene upload leaves the previous scene rendering.
+"""
+import ctypes as C
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from loltracer_amd import gpu, scene as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "loltracer_amd", "lib", "lol_headless")
+SCENE4 = os.path.join(ROOT, "tests", "golden", "scenes", "scene4.lol")
+SCENE = os.path.join(ROOT, "tests", "golden", "scenes", "scene.lol")
+
+
+def sdl_map_rgb(rgb: np.ndarray, f: gpu.PixelFormat) -> np.ndarray:
+    """colorf_to_pixfmt (renderer.h:17-22): Uint8 channel = colorf * 255 (float multiply, truncation), then
+    SDL_MapRGB for a non-palettised format: (r >> Rloss) << Rshift | (g >> Gloss) << Gshift | (b >> Bloss) << Bshift | Amask."""
+    ch = (rgb.astype(np.float32) * np.float32(255.0)).astype(np.uint32) & 0xFF
+    r, g, b = ch[..., 0], ch[..., 1], ch[..., 2]
+    return ((r >> f.r_loss) << f.r_shift | (g >> f.g_loss) << f.g_shift | (b >> f.b_loss) << f.b_shift | f.a_mask).astype(np.uint32)
+
+
+def test_pixel_format_struct_matches_the_header():
+    assert C.sizeof(gpu.PixelFormat) == 12 and C.sizeof(gpu.Rows) == 16
+
+
+def test_oracle_packs_through_the_surface_format(scenes):
+    """The checker's own pack against SDL_MapRGB's definition (CPU only)."""
+    sc = scenes["scene4"]
+    try:
+        for name in ("xrgb8888", "argb8888", "bgrx8888", "rgba8888", "abgr8888"):
+            f = gpu.PIXEL_FORMATS[name]
+            O.set_pixel_format(f)
+            px, rgb, _ = O.render_rows(sc, 48, 32, 0, 32)
+            assert np.array_equal(px, sdl_map_rgb(rgb, f)), name
+    finally:
+        O.set_pixel_format(None)
+    px, rgb, _ = O.render_rows(sc, 48, 32, 0, 32)
+    ch = (rgb * np.float32(255)).astype(np.uint32)
+    assert np.array_equal(px, ch[..., 0] << 16 | ch[..., 1] << 8 | ch[..., 2])
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("specialize", [1, 0])
+def test_device_packs_like_sdl_map_rgb(torch_cuda, scenes, specialize):
+    torch = torch_cuda
+    w, h = 96, 64
+    for scene_name in ("scene4", "scene"):
+        sc = scenes[scene_name]
+        r = gpu.Renderer(0, specialize=specialize)
+        r.prepare(sc)
+        _, orgb, _ = O.render_rows(sc, w, h, 0, h)
+        for name in ("xrgb8888", "argb8888", "bgrx8888", "rgba8888", "abgr8888"):
+            f = gpu.PIXEL_FORMATS[name]
+            r.set_pixel_format(name)
+            frame = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+            rgb = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+            r.render_into(frame.data_ptr(), w, h, debug=gpu.Debug(rgb.data_ptr(), None, None, None))
+            r.sync()
+            got = frame.cpu().numpy().view(np.uint32)
+            # integer-exact against the definition applied to the device's own float colours ...
+            assert np.array_equal(got, sdl_map_rgb(rgb.cpu().numpy(), f)), (scene_name, name)
+            # ... and against the oracle packing through the same format
+            O.set_pixel_format(f)
+            try:
+                want, _, _ = O.render_rows(sc, w, h, 0, h)
+            finally:
+                O.set_pixel_format(None)
+            assert np.array_equal(got, want), (scene_name, name)
+            if f.a_mask:
+                assert np.all(got & f.a_mask == f.a_mask)
+        # formats the reference's Uint32 store cannot express are refused, loudly, and change nothing
+        for bad in ("rgb565", "index8"):
+            with pytest.raises(gpu.GpuError) as e:
+                r.set_pixel_format(bad)
+            assert e.value.status == -5
+        frame = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+        r.render_into(frame.data_ptr(), w, h)
+        r.sync()
+        assert np.array_equal(frame.cpu().numpy().view(np.uint32), want)         # still ABGR, the last accepted format
+        r.set_pixel_format(None)
+        r.close()
+
+
+@pytest.mark.gpu
+def test_host_surface_modes_agree(torch_cuda, scenes):
+    """direct (kernel stores into the pinned, mapped surface) == copy (async pitched DMA) == pageable, padding untouched."""
+    sc = scenes["scene4"]
+    r = gpu.Renderer(0)
+    r.prepare(sc)
+    for (w, h, pitch) in ((200, 120, 203 * 4), (97, 61, 97 * 4), (640, 360, 700 * 4), (33, 7, 33 * 4 + 2)):
+        want, _, _ = O.render(sc, w, h, threads=4)
+        for mode in (gpu.HOST_DIRECT, gpu.HOST_COPY, gpu.HOST_PAGEABLE):
+            r.set_host_mode(mode)
+            buf = np.full(h * pitch + 64, 0xA5, dtype=np.uint8)
+            base = buf.ctypes.data
+            r.render_host(base, w, h, pitch_bytes=pitch)
+            rows = np.stack([buf[y * pitch:y * pitch + w * 4].view(np.uint32) for y in range(h)])
+            assert np.array_equal(rows, want), (w, h, mode)
+            for y in range(h):                                   # row padding and the tail are untouched
+                assert np.all(buf[y * pitch + w * 4:(y + 1) * pitch] == 0xA5)
+            assert np.all(buf[h * pitch:] == 0xA5)
+            used = r.host_mode_used()
+            if mode == gpu.HOST_PAGEABLE:
+                assert used == gpu.HOST_PAGEABLE
+            elif pitch % 4:
+                assert used != gpu.HOST_DIRECT                   # a pitch that is no multiple of 4: copied
+            else:
+                assert used in (mode, gpu.HOST_PAGEABLE)         # (pageable only if this box cannot pin)
+    # the same memory again, a sub-range of it, and a grown surface at a new address: all re-pinned as needed
+    big = np.zeros(1 << 22, dtype=np.uint8)
+    r.set_host_mode(gpu.HOST_DIRECT)
+    for (w, h) in ((64, 64), (128, 128), (640, 360), (64, 64)):
+        want, _, _ = O.render(sc, w, h, threads=4)
+        r.render_host(big.ctypes.data, w, h, pitch_bytes=w * 4)
+        assert np.array_equal(big[:w * h * 4].view(np.uint32).reshape(h, w), want)
+    assert gpu.gpu_lib().lol_gpu_unpin_host(None) == 0
+    r.render_host(big.ctypes.data, 64, 64, pitch_bytes=256)     # pinned again on demand
+    r.close()
+
+
+@pytest.mark.gpu
+def test_frames_in_flight_survive_a_resize(torch_cuda, scenes):
+    """a frame queued at one size must never be copied into a surface of another size."""
+    sc = scenes["scene4"]
+    r = gpu.Renderer(0)
+    r.prepare(sc)
+    sizes = [(200, 120), (96, 54), (320, 200), (320, 200), (64, 40)]
+    want = {s: O.render(sc, s[0], s[1], threads=4)[0] for s in set(sizes)}
+    # two frames of DIFFERENT sizes in flight, each ended into a surface of its own size
+    r.render_host_begin(*sizes[0])
+    for i in range(len(sizes)):
+        if i + 1 < len(sizes):
+            r.render_host_begin(*sizes[i + 1])
+        w, h = sizes[i]
+        assert r.render_host_pending_size() == (w, h)
+        # a surface of the NEXT size is refused and stays untouched, the frame stays queued
+        other = sizes[(i + 1) % len(sizes)]
+        if other != (w, h):
+            guard = np.full((other[1], other[0]), 0x5A5A5A5A, dtype=np.uint32)
+            pending = r.render_host_pending()
+            with pytest.raises(gpu.GpuError):
+                r.render_host_end(guard.ctypes.data, other[0] * 4, other[0], other[1])
+            assert np.all(guard == 0x5A5A5A5A) and r.render_host_pending() == pending
+        surf = np.zeros((h, w), dtype=np.uint32)
+        r.render_host_end(surf.ctypes.data, w * 4, w, h)
+        assert np.array_equal(surf, want[(w, h)]), sizes[i]
+    assert r.render_host_pending() == 0 and r.render_host_pending_size() == (0, 0)
+    # discard drops what is queued; the pipeline works again afterwards
+    r.render_host_begin(200, 120); r.render_host_begin(96, 54)
+    r.render_host_discard()
+    assert r.render_host_pending() == 0
+    r.render_host_begin(64, 40)
+    surf = np.zeros((40, 64), dtype=np.uint32)
+    r.render_host_end(surf.ctypes.data, 256, 64, 40)
+    assert np.array_equal(surf, want[(64, 40)])
+    r.close()
+
+
+def read_frames(prefix, n):
+    out = []
+    for i in range(n):
+        data = open(f"{prefix}{i:04d}.raw", "rb").read()
+        assert data[:4] == b"LOLF"
+        w, h = struct.unpack("<ii", data[4:12])
+        out.append(np.frombuffer(data[12:], dtype=np.uint32).reshape(h, w))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [[], ["--pipeline"], ["--host-mode", "copy"], ["--host-mode", "pageable"],
+                                   ["--devices", "0", "--parts-per-device", "3"],
+                                   ["--devices", "0", "--parts-per-device", "3", "--host-mode", "copy"]])
+def test_c_host_resizes_between_frames(tmp_path, scenes, flags):
+    """main.c:182-187 through render_thread: grow, shrink, grow again on ONE context; every surface the host sees equals
+    the oracle's frame of that size (static camera, so the pipelined mode's one-frame lag shows the same picture)."""
+    script = "320x180,320x180,1280x720,97x61,97x61,640x480,33x7,320x180"
+    sizes = [tuple(int(v) for v in s.split("x")) for s in script.split(",")]
+    prefix = str(tmp_path / "f")
+    p = subprocess.run([HOST, "3", SCENE4, "--resize-script", script, "--dump-frames", prefix] + flags,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "hip_renderer" not in p.stderr, p.stderr
+    n = len(sizes) + (1 if "--pipeline" in flags else 0)
+    frames = read_frames(prefix, n)
+    want = {s: O.render(scenes["scene4"], s[0], s[1], threads=4)[0] for s in set(sizes)}
+    for i, f in enumerate(frames):
+        s = sizes[min(i, len(sizes) - 1)]
+        assert f.shape == (s[1], s[0])
+        assert np.array_equal(f, want[s]), (i, s, flags)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["argb8888", "bgrx8888", "rgba8888", "abgr8888"])
+def test_c_host_honours_the_surface_format(tmp_path, scenes, name):
+    prefix = str(tmp_path / "f")
+    w, h = 160, 90
+    p = subprocess.run([HOST, "2", SCENE4, "--size", f"{w}x{h}", "--format", name, "--dump-frames", prefix],
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "hip_renderer" not in p.stderr, p.stderr
+    _, rgb, _ = O.render_rows(scenes["scene4"], w, h, 0, h)
+    assert np.array_equal(read_frames(prefix, 1)[0], sdl_map_rgb(rgb, gpu.PIXEL_FORMATS[name]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["rgb565", "index8"])
+def test_c_host_refuses_other_surface_formats(tmp_path, name):
+    prefix = str(tmp_path / "f")
+    p = subprocess.run([HOST, "2", SCENE4, "--size", "64x36", "--frames", "2", "--format", name, "--dump-frames", prefix],
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0
+    assert p.stderr.count("hip_renderer:") == 1 and "supported" in p.stderr      # reported once, not per frame
+    assert not np.any(read_frames(prefix, 2)[1])                                  # nothing was written
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("specialize", [1, 0])
+def test_rejected_upload_leaves_the_previous_scene_rendering(torch_cuda, scenes, specialize, monkeypatch):
+    """lol_gpu_upload_program is all-or-nothing."""
+    torch = torch_cuda
+    w, h = 128, 72
+    a, b = scenes["scene4"], scenes["scene"]
+    want_a, want_b = O.render(a, w, h, threads=4)[0], O.render(b, w, h, threads=4)[0]
+    r = gpu.Renderer(0, specialize=specialize)
+    r.prepare(a)
+
+    def frame():
+        t = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+        r.render_into(t.data_ptr(), w, h, camera=cam)
+        r.sync()
+        return t.cpu().numpy().view(np.uint32)
+    cam = a.c.camera
+    assert np.array_equal(frame(), want_a)
+    # 1. malformed programs (stack underflow, bad material index, too many ops)
+    for breaker in ("smin", "material", "n_ops"):
+        bad = b.flatten()
+        if breaker == "smin":
+            bad.ops[0].op = S.OP_SMIN
+        elif breaker == "material":
+            bad.root_material[0] = 9999
+        else:
+            bad.n_ops = S.LOL_MAX_OPS + 1
+        with pytest.raises(gpu.GpuError):
+            r._check(r._lib.lol_gpu_upload_program(r._ctx, C.byref(bad)))
+        assert np.array_equal(frame(), want_a), breaker
+    # 2. a device-side failure in the middle of the upload (injected)
+    monkeypatch.setenv("LOL_GPU_TEST_FAIL_UPLOAD", "1")
+    with pytest.raises(gpu.GpuError):
+        r._check(r._lib.lol_gpu_upload_program(r._ctx, C.byref(b.flatten())))
+    monkeypatch.delenv("LOL_GPU_TEST_FAIL_UPLOAD")
+    assert np.array_equal(frame(), want_a)
+    assert r.kernel_name() == ("lol_render_spec" if specialize else "render_interp")
+    # 3. a good upload switches over
+    r.prepare(b)
+    cam = b.c.camera
+    assert np.array_equal(frame(), want_b)
+    r.close()
+
+
+@pytest.mark.gpu
+def test_kernel_key_names_the_code(torch_cuda, scenes):
+    r = gpu.Renderer(0)
+    r.prepare(scenes["scene4"])
+    k4 = r.kernel_key()
+    r.prepare(scenes["scene"])
+    k1 = r.kernel_key()
+    r.prepare(scenes["scene4"])
+    assert len(k4) == 16 and k4 != k1 and r.kernel_key() == k4
+    ri = gpu.Renderer(0, specialize=0)
+    ri.prepare(scenes["scene4"])
+    assert len(ri.kernel_key()) == 16 and ri.kernel_key() != k4
+    r.close(); ri.close()

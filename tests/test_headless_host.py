@@ -113,17 +113,17 @@ def test_pipelined_host_path_delivers_the_same_frames(tmp_path, scenes):
             r.render_host_begin(w, h, camera=cams[i + 1])
             assert r.render_host_pending() == 2
         surf = np.zeros((h, pitch // 4), dtype=np.uint32)
-        r.render_host_end(surf.ctypes.data, pitch)
+        r.render_host_end(surf.ctypes.data, pitch, w, h)
         got.append(surf)
     assert r.render_host_pending() == 0
     for a, b in zip(got, want):
         assert np.array_equal(a, b)
     with pytest.raises(gpu.GpuError):
-        r.render_host_end(got[0].ctypes.data, pitch)           # nothing in flight
+        r.render_host_end(got[0].ctypes.data, pitch, w, h)     # nothing in flight
     r.render_host_begin(w, h); r.render_host_begin(w, h)
     with pytest.raises(gpu.GpuError):
         r.render_host_begin(w, h)                              # a third frame is refused
-    r.render_host_end(got[0].ctypes.data, pitch); r.render_host_end(got[0].ctypes.data, pitch)
+    r.render_host_end(got[0].ctypes.data, pitch, w, h); r.render_host_end(got[0].ctypes.data, pitch, w, h)
     r.close()
 
     outs = []

@@ -106,6 +106,36 @@ def test_parts_assembled_by_the_library_equal_the_whole_frame(scenes, w, h, band
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("w,h,world,per,k", [(640, 360, 8, 8, 7), (333, 181, 3, 4, 2), (512, 432, 8, 8, 5), (256, 97, 2, 3, 0)])
+def test_weighted_parts_padded_per_rank_assemble_to_the_whole_frame(scenes, w, h, world, per, k):
+    """What rank 0 of the one-process-per-GPU host does with unequal parts (the root owns fewer bands): every rank's
+    parts back to back in a buffer padded to the largest rank, the buffers gathered rank by rank, then
+    lol_gpu_assemble_parts_at with the table of where each part starts.  One device renders every rank's parts here,
+    and the in-place form (lol_gpu_rows.in_place) writes the same parts straight into a whole frame."""
+    import torch
+    from loltracer_amd import multi
+    r = gpu.Renderer(0)
+    r.prepare(scenes["scene4"])
+    whole = _frame(r, torch, w, h)
+    P = multi.Partition(h, world, per, k)
+    staging = torch.full((world * P.max_rows, w), -1, dtype=torch.int32, device="cuda")
+    pitch_px = w + 3
+    direct = torch.zeros((h, pitch_px), dtype=torch.int32, device="cuda")
+    for p in range(P.n_parts):
+        if not P.rows_of[p]:
+            continue
+        r.render_into(staging[P.part_row0[p]:].data_ptr(), w, h, 256, rows=gpu.Rows(P.band, P.n_parts, p))
+        r.render_into(direct.data_ptr(), w, h, 256, rows=gpu.Rows(P.band, P.n_parts, p, 1), pitch_bytes=pitch_px * 4)
+    r.sync()
+    out = torch.zeros((h, pitch_px), dtype=torch.int32, device="cuda")
+    gpu.assemble_parts_at(r, staging.data_ptr(), P.part_row0, P.band, w, h, out.data_ptr(), pitch_px * 4, None)
+    torch.cuda.synchronize()
+    assert torch.equal(out[:, :w], whole) and int(out[:, w:].abs().sum()) == 0
+    assert torch.equal(direct[:, :w], whole) and int(direct[:, w:].abs().sum()) == 0
+    r.close()
+
+
+@pytest.mark.gpu
 def test_multi_path_on_one_device_equals_the_single_device_frame(scenes):
     import torch
     single = gpu.Renderer(0)
