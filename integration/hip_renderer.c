@@ -17,8 +17,11 @@
  *                   these GPUs, each writing its bands into the surface,
  *                   include/lol_gpu.h lol_gpu_multi_*), --parts-per-device N,
  *                   --root-parts N (the first device's smaller share),
- *                   --host-mode direct|copy|pageable (how pixels reach
- *                   surf->pixels, lol_gpu_render_host), --max-steps N, and
+ *                   --host-mode copy|direct (how pixels reach surf->pixels,
+ *                   lol_gpu_render_host: copy is the default and safe for any
+ *                   surface; direct has the kernel store into the pinned surface
+ *                   and is for hosts whose surface memory stays put),
+ *                   --max-steps N, and
  *                   --dump-kernel BASE, the counterpart of the JIT renderer's
  *                   -j/--jitdump (tracing_jit_renderer.dasc:424-433): writes the
  *                   scene-specialised kernel as BASE.hip (generated source) and
@@ -97,9 +100,8 @@ void render_prepare(struct render_data* data, int argc, const char* argv[]) {
 		else if (is_ppd) parts_per_device = atoi(v);
 		else if (is_root) root_parts = atoi(v);
 		else if (is_mode) {
-			host_mode = !strcmp(v, "direct") ? LOL_GPU_HOST_DIRECT : !strcmp(v, "copy") ? LOL_GPU_HOST_COPY :
-			            !strcmp(v, "pageable") ? LOL_GPU_HOST_PAGEABLE : -1;
-			if (host_mode < 0) fprintf(stderr, "hip_renderer: --host-mode wants direct, copy or pageable\n");
+			host_mode = !strcmp(v, "direct") ? LOL_GPU_HOST_DIRECT : !strcmp(v, "copy") ? LOL_GPU_HOST_COPY : -1;
+			if (host_mode < 0) fprintf(stderr, "hip_renderer: --host-mode wants copy or direct\n");
 		} else {
 			n_devices = 0;
 			for (const char* p = v; *p && n_devices < LOL_GPU_MULTI_MAX_DEVICES;) {

@@ -168,6 +168,9 @@ int main(int argc, const char* argv[]) {
 		if (n_sizes) {                                           /* SDL_GetWindowSurface after a resize: a new surface */
 			const int k = f < n_sizes ? f : n_sizes - 1;
 			if (sizes[k][0] != surf.w || sizes[k][1] != surf.h) {
+				/* a host that lets the renderer store straight into its surface (--host-mode direct) owes it this
+				 * call before the memory goes away (include/lol_gpu.h); a no-op for the default copy route */
+				lol_gpu_unpin_host(surf.pixels);
 				free(surf.pixels);
 				w = surf.w = sizes[k][0]; h = surf.h = sizes[k][1];
 				surf.pitch = (w + 13) * 4;
@@ -221,6 +224,7 @@ int main(int argc, const char* argv[]) {
 	render_destroy(&data);
 
 	free(tid);
+	lol_gpu_unpin_host(surf.pixels);
 	free(surf.pixels);
 	lol_scene_free(scene);
 	sem_destroy(&entry);

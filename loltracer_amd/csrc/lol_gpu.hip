@@ -61,7 +61,7 @@ struct lol_gpu {
 	/* the surface's pixel format (lol_gpu_set_pixel_format), packed as lol::Launch wants it; default XRGB8888 */
 	uint32_t     fmt_shift = 16u | 8u << 8 | 0u << 16, fmt_loss = 0, fmt_amask = 0;
 	/* host-surface path */
-	int          host_mode = LOL_GPU_HOST_DIRECT, host_mode_used = -1;
+	int          host_mode = LOL_GPU_HOST_COPY, host_mode_used = -1;
 	uint32_t*    d_frame = nullptr;      /* framebuffer for lol_gpu_render_host in the copy modes */
 	size_t       frame_bytes = 0;
 	/* lol_gpu_render_host_begin / _end: two frames in flight, one device framebuffer each (sized per slot, so frames of
@@ -111,11 +111,14 @@ int fail(lol_gpu* ctx, int status, const char* what, hipError_t e = hipSuccess) 
 
 /* ------------------------------------------------------------- pinned host surfaces
  * The reference's renderer writes into surf->pixels, host memory the HOST owns (SDL's window surface, main.c:182).
- * Copies into pageable memory are staged by the HIP runtime through its own pinned buffers, synchronously on the
- * calling thread: half the frame time of the boundary path in round 2.  So the surface itself is page-locked and
- * mapped for the devices (hipHostRegister; the kernel driver keeps such a range coherent through unmap / remap with
- * MMU notifiers), once per (address, size) — the host re-fetches the surface every frame and it only changes when
- * the window is resized.  Process-wide, because every device of a multi-device host writes the same surface. */
+ * The default route copies into it and lets the HIP runtime pin the pages for the duration of each copy (measured:
+ * PCIe line rate, tools/d2h_bench.hip).  The DIRECT route (opt-in, include/lol_gpu.h) has the kernel store into the
+ * surface itself, which needs the surface page-locked and mapped for the devices (hipHostRegister) — remembered here
+ * by address, because registering per frame would cost more than the copy it saves.  That memory is only as good as
+ * the host's promise to keep it mapped: a range unmapped and mapped again behind the library's back is NOT followed
+ * (the device then writes to pages that are gone and the runtime aborts the process — seen once in
+ * tests/test_gpu_boundary.py before the route became opt-in).  Process-wide, because every device of a multi-device
+ * host writes the same surface. */
 struct HostPins {
 	struct Range { char* base; size_t bytes; unsigned long stamp; };
 	static constexpr int MAX = 4;
@@ -125,7 +128,9 @@ struct HostPins {
 	unsigned long clock = 0;
 	bool enabled() const { const char* e = getenv("LOL_GPU_PIN_HOST"); return !(e && e[0] == '0'); }
 	void drop(int i) {
-		(void)hipHostUnregister(r[i].base);
+		/* (the host may have freed — unmapped — the range already: then this fails, and the failure must not stay
+		 * behind as the thread's "last error" for the next hipGetLastError() of whoever shares the thread) */
+		if (hipHostUnregister(r[i].base) != hipSuccess) (void)hipGetLastError();
 		r[i] = r[--n];
 	}
 	/* true when [p, p + bytes) is registered afterwards */
@@ -1222,8 +1227,7 @@ int lol_gpu_create(int device, lol_gpu** out) {
 		/* macro-ops + test records <= 1.5 x ops */
 		if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_mops[i]), (size_t)(2 * LOL_MAX_OPS) * lol::MOP_DWORDS * 4);
 	}
-	if (const char* hm = getenv("LOL_GPU_HOST_MODE"))
-		ctx->host_mode = !strcmp(hm, "copy") ? LOL_GPU_HOST_COPY : !strcmp(hm, "pageable") ? LOL_GPU_HOST_PAGEABLE : LOL_GPU_HOST_DIRECT;
+	if (const char* hm = getenv("LOL_GPU_HOST_MODE")) ctx->host_mode = !strcmp(hm, "direct") ? LOL_GPU_HOST_DIRECT : LOL_GPU_HOST_COPY;
 	if (e != hipSuccess) {
 		fprintf(stderr, "lol_gpu_create: %s\n", hipGetErrorString(e));
 		lol_gpu_destroy(ctx);
@@ -1477,7 +1481,7 @@ int lol_gpu_set_pixel_format(lol_gpu* ctx, const lol_gpu_pixel_format* fmt) {
 }
 
 int lol_gpu_set_host_mode(lol_gpu* ctx, int mode) {
-	if (!ctx || mode < LOL_GPU_HOST_DIRECT || mode > LOL_GPU_HOST_PAGEABLE) return LOL_GPU_ERR_ARG;
+	if (!ctx || (mode != LOL_GPU_HOST_COPY && mode != LOL_GPU_HOST_DIRECT)) return LOL_GPU_ERR_ARG;
 	ctx->host_mode = mode;
 	return LOL_GPU_OK;
 }
@@ -1493,16 +1497,12 @@ int lol_gpu_pin_host(void* ptr, size_t bytes, void** dev_ptr) {
 
 int lol_gpu_unpin_host(void* ptr) { g_pins.unpin(ptr); return LOL_GPU_OK; }
 
-/* Pin the surface (unless the mode says not to) and say how the frame is to reach it:
- *   returns LOL_GPU_HOST_DIRECT with *direct = the device's address of the surface, or _COPY (pinned), or _PAGEABLE. */
-static int host_route(lol_gpu* ctx, void* host_pixels, size_t pitch_bytes, int w, int h, void** direct) {
-	*direct = nullptr;
-	if (ctx->host_mode == LOL_GPU_HOST_PAGEABLE) return LOL_GPU_HOST_PAGEABLE;
+/* The direct route's destination: the device's address of the (pinned, mapped) surface, nullptr = copy instead. */
+static void* direct_target(lol_gpu* ctx, void* host_pixels, size_t pitch_bytes, int w, int h) {
+	if (ctx->host_mode != LOL_GPU_HOST_DIRECT || pitch_bytes % 4 || reinterpret_cast<uintptr_t>(host_pixels) % 4) return nullptr;
 	/* the last row is w*4 bytes long, not a whole pitch: a surface need not own the padding behind it */
-	if (!g_pins.pin(host_pixels, pitch_bytes * (size_t)(h - 1) + (size_t)w * 4)) return LOL_GPU_HOST_PAGEABLE;
-	if (ctx->host_mode == LOL_GPU_HOST_DIRECT && pitch_bytes % 4 == 0 && reinterpret_cast<uintptr_t>(host_pixels) % 4 == 0)
-		if ((*direct = device_view(host_pixels)) != nullptr) return LOL_GPU_HOST_DIRECT;
-	return LOL_GPU_HOST_COPY;
+	if (!g_pins.pin(host_pixels, pitch_bytes * (size_t)(h - 1) + (size_t)w * 4)) return nullptr;
+	return device_view(host_pixels);
 }
 
 int lol_gpu_render_host(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h, int max_steps,
@@ -1510,10 +1510,9 @@ int lol_gpu_render_host(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h,
 	if (!ctx || !host_pixels) return LOL_GPU_ERR_ARG;
 	if (w <= 0 || h <= 0 || pitch_bytes < (size_t)w * 4) return fail(ctx, LOL_GPU_ERR_ARG, "bad frame geometry");
 	LOL_HIP(ctx, hipSetDevice(ctx->device));
-	void* direct = nullptr;
-	const int route = host_route(ctx, host_pixels, pitch_bytes, w, h, &direct);
-	ctx->host_mode_used = route;
-	if (route == LOL_GPU_HOST_DIRECT) {
+	void* direct = direct_target(ctx, host_pixels, pitch_bytes, w, h);
+	ctx->host_mode_used = direct ? LOL_GPU_HOST_DIRECT : LOL_GPU_HOST_COPY;
+	if (direct) {
 		/* the kernel's 64-byte row-segment stores go over the PCIe link into the mapped surface: nothing to copy */
 		int st = lol_gpu_render_device(ctx, cam, w, h, max_steps, nullptr, direct, pitch_bytes, nullptr, nullptr);
 		if (st != LOL_GPU_OK) return st;
@@ -1539,8 +1538,8 @@ int lol_gpu_render_host(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h,
  * The host-surface path with two frames in flight: begin() queues frame i+1's kernel while end() copies frame i
  * into the host's surface, so the 33 MB device-to-host copy of a 4K frame (0.6 ms at PCIe Gen5 rates) runs under
  * the next frame's kernel instead of after its own.  Kernels go to the context's stream, copies to a second
- * stream, two device framebuffers alternate.  The surface is pinned (host_route), so the copy is a real
- * asynchronous DMA; pageable it is staged by the runtime on the calling thread.
+ * stream, two device framebuffers alternate.  (Always the copy route: measured at the kernel's own rate on C3 — the
+ * copy hides completely — bench.py `host_surface`.)
  */
 int lol_gpu_render_host_begin(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h, int max_steps) {
 	if (!ctx || !cam) return LOL_GPU_ERR_ARG;
@@ -1587,9 +1586,7 @@ int lol_gpu_render_host_end(lol_gpu* ctx, void* host_pixels, size_t pitch_bytes,
 		return fail(ctx, LOL_GPU_ERR_ARG, "the queued frame's size differs from the surface's: lol_gpu_render_host_discard");
 	if (pitch_bytes < (size_t)w * 4) return fail(ctx, LOL_GPU_ERR_ARG, "bad frame geometry");
 	LOL_HIP(ctx, hipSetDevice(ctx->device));
-	void* unused = nullptr;
-	const int route = host_route(ctx, host_pixels, pitch_bytes, w, h, &unused);
-	ctx->host_mode_used = route == LOL_GPU_HOST_DIRECT ? LOL_GPU_HOST_COPY : route;
+	ctx->host_mode_used = LOL_GPU_HOST_COPY;
 	LOL_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->pipe_rendered[slot], 0));
 	LOL_HIP(ctx, hipMemcpy2DAsync(host_pixels, pitch_bytes, ctx->d_pipe[slot], (size_t)w * 4, (size_t)w * 4, h,
 	                              hipMemcpyDeviceToHost, ctx->copy_stream));

@@ -37,7 +37,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <new>
+#include <thread>
 
 namespace {
 
@@ -74,6 +78,53 @@ struct Rccl {
 
 constexpr int SLOTS = 2;
 
+/* One host thread per device for the copies into a HOST surface: a device-to-host copy into pageable memory (memory
+ * the host owns and the library must not keep pinned, include/lol_gpu.h) occupies the thread that issues it, so N
+ * devices only drive their N PCIe links at once when N threads issue.  Started by the first frame that needs it. */
+struct Worker {
+	std::thread th;
+	std::mutex mu;
+	std::condition_variable cv;
+	std::function<hipError_t()> job;
+	bool busy = false, quit = false;
+	hipError_t result = hipSuccess;
+	void start() {
+		if (th.joinable()) return;
+		th = std::thread([this] {
+			std::unique_lock<std::mutex> lock(mu);
+			for (;;) {
+				cv.wait(lock, [this] { return quit || (busy && job); });
+				if (quit) return;
+				std::function<hipError_t()> j = std::move(job);
+				job = nullptr;
+				lock.unlock();
+				const hipError_t r = j();
+				lock.lock();
+				result = r;
+				busy = false;
+				cv.notify_all();
+			}
+		});
+	}
+	void submit(std::function<hipError_t()> j) {
+		start();
+		std::lock_guard<std::mutex> lock(mu);
+		job = std::move(j);
+		busy = true;
+		cv.notify_all();
+	}
+	hipError_t wait() {
+		std::unique_lock<std::mutex> lock(mu);
+		cv.wait(lock, [this] { return !busy; });
+		return result;
+	}
+	void stop() {
+		if (!th.joinable()) return;
+		{ std::lock_guard<std::mutex> lock(mu); quit = true; cv.notify_all(); }
+		th.join();
+	}
+};
+
 struct Device {
 	int          id = -1;
 	lol_gpu*     ctx = nullptr;
@@ -82,6 +133,7 @@ struct Device {
 	uint32_t*    part[SLOTS] = { nullptr, nullptr };
 	size_t       part_bytes = 0;
 	hipEvent_t   rendered[SLOTS] = { nullptr, nullptr }, sent[SLOTS] = { nullptr, nullptr };
+	Worker       copier;
 };
 
 constexpr int MAX_PARTS = 64;      /* devices x parts_per_device */
@@ -166,7 +218,7 @@ struct lol_gpu_multi {
 	int       root_parts = 1;                          /* parts of the root (<= per_dev): its smaller share */
 	int       n_parts = 1;
 	int       owner[MAX_PARTS] = { 0 };                /* device index of every part (lol_gpu_deal_parts) */
-	int       host_mode = LOL_GPU_HOST_DIRECT;
+	int       host_mode = LOL_GPU_HOST_COPY;
 	int       host_via_root = 0;                       /* render_host: assemble on the root first (RCCL) instead of direct copies */
 	uint32_t* staging[SLOTS] = { nullptr, nullptr };   /* root: every part of a frame, back to back */
 	size_t    staging_bytes = 0;
@@ -364,7 +416,7 @@ int lol_gpu_multi_create(const int* devices, int n, lol_gpu_multi** out) {
 	}
 	if (const char* e = getenv("LOL_GPU_MULTI_HOST_VIA_ROOT")) m->host_via_root = e[0] == '1';
 	if (const char* hm = getenv("LOL_GPU_HOST_MODE"))
-		m->host_mode = !strcmp(hm, "copy") ? LOL_GPU_HOST_COPY : !strcmp(hm, "pageable") ? LOL_GPU_HOST_PAGEABLE : LOL_GPU_HOST_DIRECT;
+		m->host_mode = !strcmp(hm, "direct") ? LOL_GPU_HOST_DIRECT : LOL_GPU_HOST_COPY;
 	m->n_parts = lol_gpu_deal_parts(n, m->per_dev, m->root_parts, m->owner, MAX_PARTS);
 	*out = m;
 	return LOL_GPU_OK;
@@ -372,6 +424,7 @@ int lol_gpu_multi_create(const int* devices, int n, lol_gpu_multi** out) {
 
 void lol_gpu_multi_destroy(lol_gpu_multi* m) {
 	if (!m) return;
+	for (int i = 0; i < m->n; i++) m->dev[i].copier.stop();
 	for (int i = 0; i < m->n; i++) {
 		Device& D = m->dev[i];
 		if (D.id < 0) continue;
@@ -447,7 +500,7 @@ int lol_gpu_multi_set_root_parts(lol_gpu_multi* m, int root_parts) {
 }
 
 int lol_gpu_multi_set_host_mode(lol_gpu_multi* m, int mode) {
-	if (!m || mode < LOL_GPU_HOST_DIRECT || mode > LOL_GPU_HOST_PAGEABLE) return LOL_GPU_ERR_ARG;
+	if (!m || (mode != LOL_GPU_HOST_COPY && mode != LOL_GPU_HOST_DIRECT)) return LOL_GPU_ERR_ARG;
 	m->host_mode = mode;
 	return LOL_GPU_OK;
 }
@@ -570,8 +623,8 @@ int lol_gpu_multi_sync(lol_gpu_multi* m) {
 /* One part of the frame from its compact device copy into the host surface: the part's bands are band_rows rows each,
  * n_parts * band_rows rows apart in the frame — one strided 3-D copy (+ one 2-D copy if the part owns the frame's
  * partial last band). */
-static int copy_part_to_host(lol_gpu_multi* m, const uint32_t* part_dev, const lol_gpu_rows& R, int w, int h,
-                             char* host, size_t pitch, hipStream_t s) {
+static hipError_t copy_part_to_host(const uint32_t* part_dev, const lol_gpu_rows& R, int w, int h,
+                                    char* host, size_t pitch, hipStream_t s) {
 	const int rows = lol_gpu_part_rows(h, &R);
 	const int full = rows / R.band_rows, tail = rows - full * R.band_rows;
 	if (full > 0) {
@@ -582,14 +635,16 @@ static int copy_part_to_host(lol_gpu_multi* m, const uint32_t* part_dev, const l
 		                              (size_t)R.n_parts * R.band_rows);
 		p.extent = make_hipExtent((size_t)w * 4, (size_t)R.band_rows, (size_t)full);
 		p.kind = hipMemcpyDeviceToHost;
-		M_HIP(m, hipMemcpy3DAsync(&p, s));
+		const hipError_t e = hipMemcpy3DAsync(&p, s);
+		if (e != hipSuccess) return e;
 	}
 	if (tail > 0) {
 		const size_t y0 = ((size_t)full * R.n_parts + R.part) * R.band_rows;
-		M_HIP(m, hipMemcpy2DAsync(host + y0 * pitch, pitch, part_dev + (size_t)full * R.band_rows * w, (size_t)w * 4,
-		                          (size_t)w * 4, (size_t)tail, hipMemcpyDeviceToHost, s));
+		const hipError_t e = hipMemcpy2DAsync(host + y0 * pitch, pitch, part_dev + (size_t)full * R.band_rows * w, (size_t)w * 4,
+		                                      (size_t)w * 4, (size_t)tail, hipMemcpyDeviceToHost, s);
+		if (e != hipSuccess) return e;
 	}
-	return LOL_GPU_OK;
+	return hipSuccess;
 }
 
 int lol_gpu_multi_render_host(lol_gpu_multi* m, const lol_frame_camera* cam, int w, int h, int max_steps,
@@ -621,12 +676,11 @@ int lol_gpu_multi_render_host(lol_gpu_multi* m, const lol_frame_camera* cam, int
 	Split S;
 	int st = split_frame(m, h, S);
 	if (st != LOL_GPU_OK) return st;
-	/* pinned and mapped for every device, so that the copies are real asynchronous DMAs (pageable memory is staged by
-	 * the runtime on THIS thread, one device after the other) — or no copies at all */
-	const bool pinned = m->host_mode != LOL_GPU_HOST_PAGEABLE &&
-	                    lol_gpu_pin_host(host_pixels, pitch_bytes * (size_t)(h - 1) + (size_t)w * 4, nullptr) == LOL_GPU_OK;
+	/* direct (opt-in: the host vouches for the surface, include/lol_gpu.h): pinned and mapped for every device, the
+	 * kernels store straight into it */
 	void* view[LOL_GPU_MULTI_MAX_DEVICES] = { nullptr };
-	bool direct = pinned && m->host_mode == LOL_GPU_HOST_DIRECT && pitch_bytes % 4 == 0 && reinterpret_cast<uintptr_t>(host_pixels) % 4 == 0;
+	bool direct = m->host_mode == LOL_GPU_HOST_DIRECT && pitch_bytes % 4 == 0 && reinterpret_cast<uintptr_t>(host_pixels) % 4 == 0 &&
+	              lol_gpu_pin_host(host_pixels, pitch_bytes * (size_t)(h - 1) + (size_t)w * 4, nullptr) == LOL_GPU_OK;
 	for (int d = 0; d < m->n && direct; d++) {
 		M_HIP(m, hipSetDevice(m->dev[d].id));
 		if (hipHostGetDevicePointer(&view[d], host_pixels, 0) != hipSuccess || !view[d]) { (void)hipGetLastError(); direct = false; }
@@ -647,23 +701,32 @@ int lol_gpu_multi_render_host(lol_gpu_multi* m, const lol_frame_camera* cam, int
 	if (st != LOL_GPU_OK) return st;
 	st = render_parts(m, cam, w, h, max_steps, S, slot);
 	if (st != LOL_GPU_OK) return st;
-	for (int d = 0; d < m->n; d++) {
+	/* the copies: every device's by a thread of its own (one device: this thread), each waiting for its device */
+	auto copy_device = [m, &S, slot, w, h, host_pixels, pitch_bytes](int d) -> hipError_t {
 		Device& D = m->dev[d];
-		M_HIP(m, hipSetDevice(D.id));
-		for (int part = 0; part < m->n_parts; part++) {
+		hipError_t e = hipSetDevice(D.id);
+		for (int part = 0; part < m->n_parts && e == hipSuccess; part++) {
 			if (m->owner[part] != d) continue;
 			lol_gpu_rows R = { S.band, m->n_parts, part };
 			if (lol_gpu_part_rows(h, &R) <= 0) continue;
-			st = copy_part_to_host(m, D.part[slot] + (size_t)(S.tab.row0[part] - S.dev_row0[d]) * w, R, w, h,
-			                       static_cast<char*>(host_pixels), pitch_bytes, D.xchg);
-			if (st != LOL_GPU_OK) return st;
+			e = copy_part_to_host(D.part[slot] + (size_t)(S.tab.row0[part] - S.dev_row0[d]) * w, R, w, h,
+			                      static_cast<char*>(host_pixels), pitch_bytes, D.xchg);
 		}
-		M_HIP(m, hipEventRecord(D.sent[slot], D.xchg));
+		if (e == hipSuccess) e = hipEventRecord(D.sent[slot], D.xchg);
+		if (e == hipSuccess) e = hipStreamSynchronize(D.xchg);
+		return e;
+	};
+	hipError_t worst = hipSuccess;
+	if (m->n == 1) {
+		worst = copy_device(0);
+	} else {
+		for (int d = 0; d < m->n; d++) m->dev[d].copier.submit([copy_device, d] { return copy_device(d); });
+		for (int d = 0; d < m->n; d++) {
+			const hipError_t e = m->dev[d].copier.wait();
+			if (e != hipSuccess) worst = e;
+		}
 	}
-	for (int d = 0; d < m->n; d++) {
-		M_HIP(m, hipSetDevice(m->dev[d].id));
-		M_HIP(m, hipStreamSynchronize(m->dev[d].xchg));
-	}
+	if (worst != hipSuccess) return mfail(m, LOL_GPU_ERR_HIP, "copy into the host surface", hipGetErrorString(worst));
 	M_HIP(m, hipSetDevice(root.id));
 	return LOL_GPU_OK;
 }

@@ -42,7 +42,7 @@ PIXEL_FORMATS = {
     "rgb565": PixelFormat(11, 5, 0, 3, 2, 3, 2, 0, 0),
     "index8": PixelFormat(0, 0, 0, 8, 8, 8, 1, 1, 0),
 }
-HOST_DIRECT, HOST_COPY, HOST_PAGEABLE = 0, 1, 2
+HOST_COPY, HOST_DIRECT = 0, 1
 
 
 class Debug(C.Structure):

@@ -103,14 +103,17 @@ def test_device_packs_like_sdl_map_rgb(torch_cuda, scenes, specialize):
 
 
 @pytest.mark.gpu
-def test_host_surface_modes_agree(torch_cuda, scenes):
-    """direct (kernel stores into the pinned, mapped surface) == copy (async pitched DMA) == pageable, padding untouched."""
+def test_host_surface_routes_agree(torch_cuda, scenes):
+    """copy (device framebuffer + pitched copy: the default, safe for any host memory) == direct (the kernel stores into
+    the pinned, mapped surface: opt-in), padding untouched."""
     sc = scenes["scene4"]
     r = gpu.Renderer(0)
     r.prepare(sc)
+    r.render_host(np.zeros(64 * 64, dtype=np.uint32).ctypes.data, 64, 64)
+    assert r.host_mode_used() == gpu.HOST_COPY                # the default never pins what it does not own
     for (w, h, pitch) in ((200, 120, 203 * 4), (97, 61, 97 * 4), (640, 360, 700 * 4), (33, 7, 33 * 4 + 2)):
         want, _, _ = O.render(sc, w, h, threads=4)
-        for mode in (gpu.HOST_DIRECT, gpu.HOST_COPY, gpu.HOST_PAGEABLE):
+        for mode in (gpu.HOST_COPY, gpu.HOST_DIRECT):
             r.set_host_mode(mode)
             buf = np.full(h * pitch + 64, 0xA5, dtype=np.uint8)
             base = buf.ctypes.data
@@ -120,23 +123,66 @@ def test_host_surface_modes_agree(torch_cuda, scenes):
             for y in range(h):                                   # row padding and the tail are untouched
                 assert np.all(buf[y * pitch + w * 4:(y + 1) * pitch] == 0xA5)
             assert np.all(buf[h * pitch:] == 0xA5)
-            used = r.host_mode_used()
-            if mode == gpu.HOST_PAGEABLE:
-                assert used == gpu.HOST_PAGEABLE
-            elif pitch % 4:
-                assert used != gpu.HOST_DIRECT                   # a pitch that is no multiple of 4: copied
+            if mode == gpu.HOST_DIRECT and pitch % 4 == 0:
+                assert r.host_mode_used() == gpu.HOST_DIRECT
             else:
-                assert used in (mode, gpu.HOST_PAGEABLE)         # (pageable only if this box cannot pin)
-    # the same memory again, a sub-range of it, and a grown surface at a new address: all re-pinned as needed
+                assert r.host_mode_used() == gpu.HOST_COPY       # a pitch that is no multiple of 4 cannot be stored into
+            assert gpu.gpu_lib().lol_gpu_unpin_host(base) == 0   # the host vouched for `buf` only until here
+    # direct: the same memory again, a sub-range of it, a larger frame in it: re-pinned as needed
     big = np.zeros(1 << 22, dtype=np.uint8)
     r.set_host_mode(gpu.HOST_DIRECT)
     for (w, h) in ((64, 64), (128, 128), (640, 360), (64, 64)):
         want, _, _ = O.render(sc, w, h, threads=4)
         r.render_host(big.ctypes.data, w, h, pitch_bytes=w * 4)
+        assert r.host_mode_used() == gpu.HOST_DIRECT
         assert np.array_equal(big[:w * h * 4].view(np.uint32).reshape(h, w), want)
     assert gpu.gpu_lib().lol_gpu_unpin_host(None) == 0
     r.render_host(big.ctypes.data, 64, 64, pitch_bytes=256)     # pinned again on demand
+    assert gpu.gpu_lib().lol_gpu_unpin_host(None) == 0
     r.close()
+
+
+REMAP_SCRIPT = r"""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import oracle_lib as O
+from loltracer_amd import gpu, scene as S
+libc = C.CDLL(None, use_errno=True)
+libc.mmap.restype = C.c_void_p
+libc.mmap.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_long]
+libc.munmap.argtypes = [C.c_void_p, C.c_size_t]
+PROT_RW, MAP_PRIVATE, MAP_ANON, MAP_FIXED_NOREPLACE = 3, 2, 0x20, 0x100000
+sc = S.Scene.parse_file({scene!r})
+r = gpu.Renderer(0)
+r.prepare(sc)
+w, h = 512, 256
+size = w * h * 4
+addr = libc.mmap(None, size, PROT_RW, MAP_PRIVATE | MAP_ANON, -1, 0)
+for (ww, hh) in ((w, h), (w, h), (w // 2, h // 2), (w, h)):
+    r.render_host(addr, ww, hh, pitch_bytes=ww * 4)
+    assert r.host_mode_used() == gpu.HOST_COPY
+    got = np.ctypeslib.as_array(C.cast(addr, C.POINTER(C.c_uint32)), shape=(hh * ww,)).reshape(hh, ww).copy()
+    assert np.array_equal(got, O.render(sc, ww, hh, threads=4)[0]), (ww, hh)
+    assert libc.munmap(addr, size) == 0                      # the host drops the surface ...
+    again = libc.mmap(addr, size, PROT_RW, MAP_PRIVATE | MAP_ANON | MAP_FIXED_NOREPLACE, -1, 0)
+    assert again == addr, "could not map the same address again"      # ... and gets fresh zero pages at the same address
+    assert not np.ctypeslib.as_array(C.cast(addr, C.POINTER(C.c_uint32)), shape=(h * w,)).any()
+r.close()
+print("remap ok")
+"""
+
+
+@pytest.mark.gpu
+def test_surface_freed_and_mapped_again_at_the_same_address(tmp_path):
+    """SDL frees the window surface on a resize and allocates a new one (main.c:182); the allocator may hand out the
+    SAME address for new pages.  The default route remembers nothing about the surface between frames, so the new pages
+    get the frame: map, render, unmap, map again at that very address, render, for a same-size and a smaller surface.
+    (The opt-in direct route pins by address and must not be used by such a host — include/lol_gpu.h; when this case was
+    first run against it the runtime aborted the process.)  Runs in a process of its own."""
+    import sys
+    p = subprocess.run([sys.executable, "-c", REMAP_SCRIPT.format(root=ROOT, scene=SCENE4)], capture_output=True, text=True, timeout=180)
+    assert p.returncode == 0 and "remap ok" in p.stdout, p.stderr[-2000:]
 
 
 @pytest.mark.gpu
@@ -188,9 +234,9 @@ def read_frames(prefix, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("flags", [[], ["--pipeline"], ["--host-mode", "copy"], ["--host-mode", "pageable"],
+@pytest.mark.parametrize("flags", [[], ["--pipeline"], ["--host-mode", "direct"],
                                    ["--devices", "0", "--parts-per-device", "3"],
-                                   ["--devices", "0", "--parts-per-device", "3", "--host-mode", "copy"]])
+                                   ["--devices", "0", "--parts-per-device", "3", "--host-mode", "direct"]])
 def test_c_host_resizes_between_frames(tmp_path, scenes, flags):
     """main.c:182-187 through render_thread: grow, shrink, grow again on ONE context; every surface the host sees equals
     the oracle's frame of that size (static camera, so the pipelined mode's one-frame lag shows the same picture)."""
