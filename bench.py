@@ -220,17 +220,15 @@ def host_surface_rates(r, sc, cfg, cams, frames: int = 12):
     def rate(dt):
         return round(frames * w * h / dt / 1e6, 1)
 
-    for name, mode in (("copy", gpu.HOST_COPY), ("direct", gpu.HOST_DIRECT)):
-        r.set_host_mode(mode)
+    for chunks in (1, 4, 8):
+        r.set_host_chunks(chunks)
         for i in range(3):
             r.render_host(surf.ctypes.data, w, h, ms, camera=cam_list[i % len(cam_list)], pitch_bytes=pitch)
         t0 = time.perf_counter()
         for i in range(frames):
             r.render_host(surf.ctypes.data, w, h, ms, camera=cam_list[i % len(cam_list)], pitch_bytes=pitch)
-        out[f"sync_{name}_mpixels_per_s"] = rate(time.perf_counter() - t0)
-        out[f"sync_{name}_route_used"] = ("copy", "direct")[r.host_mode_used()]
-    r.set_host_mode(gpu.HOST_COPY)
-    gpu.gpu_lib().lol_gpu_unpin_host(None)             # this surface is about to be freed: the direct route's pin goes first
+        out[f"sync_{chunks}_chunks_mpixels_per_s"] = rate(time.perf_counter() - t0)
+    r.set_host_chunks(4)
     r.render_host_begin(w, h, ms, camera=cam_list[0])
     r.render_host_begin(w, h, ms, camera=cam_list[1 % len(cam_list)])
     r.render_host_end(surf.ctypes.data, pitch, w, h)
@@ -240,9 +238,8 @@ def host_surface_rates(r, sc, cfg, cams, frames: int = 12):
         r.render_host_end(surf.ctypes.data, pitch, w, h)
     out["pipelined_copy_mpixels_per_s"] = rate(time.perf_counter() - t0)
     r.render_host_end(surf.ctypes.data, pitch, w, h)
-    # the default route (safe for any host surface), synchronous per frame and with two frames in flight
-    out["host_surface_mpixels_per_s"] = {"sync": out["sync_copy_mpixels_per_s"], "pipelined": out["pipelined_copy_mpixels_per_s"],
-                                         "sync_direct_opt_in": out["sync_direct_mpixels_per_s"]}
+    # synchronous per frame (the default: 4 row chunks, copies under the next chunk's kernel) and with two frames in flight
+    out["host_surface_mpixels_per_s"] = {"sync": out["sync_4_chunks_mpixels_per_s"], "pipelined": out["pipelined_copy_mpixels_per_s"]}
     return out
 
 

@@ -125,37 +125,14 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
  * Whole frame into a HOST surface (what render_thread does with surf->pixels,
  * naive_renderer.c:233-235), honouring `pitch_bytes`; returns when the surface holds the frame.
  *
- * Two routes (lol_gpu_set_host_mode, LOL_GPU_HOST_MODE=copy|direct):
- *   LOL_GPU_HOST_COPY (default)  device framebuffer + one pitched device-to-host copy.  Safe for memory the library knows
- *                       nothing about: the HIP runtime pins the pages for the duration of the copy by itself (measured
- *                       on MI355X: 56 GB/s into plain malloc'd memory, the same as into registered memory —
- *                       profiles/r3_d2h_routes.jsonl), and nothing of the surface is remembered between calls.
- *   LOL_GPU_HOST_DIRECT the surface is page-locked and mapped for the device (lol_gpu_pin_host, remembered by address)
- *                       and the kernel stores its pixels straight into it: no device framebuffer, no copy, +27 % on C3.
- *                       ONLY for hosts that vouch for the surface: the memory must stay mapped, at that address, until
- *                       lol_gpu_unpin_host (or until it is handed over with another size, which re-pins).  A surface
- *                       that is unmapped and mapped again at the same address and size without the library noticing
- *                       leaves the device writing to pages that are gone (observed: the process is aborted by the
- *                       runtime) — SDL may do exactly that to a window surface on a resize (main.c:182), so the renderer.h
- *                       adapter uses this route only when asked to (--host-mode direct).
- *                       A surface that cannot be pinned or is not 4-byte aligned falls back to the copy.
+ * The surface is the host's memory: the library keeps nothing about it between calls and never registers it with the
+ * device (the HIP runtime pins a copy's destination for the duration of the copy: PCIe line rate, measured).  The frame
+ * is rendered as a few row chunks, each copied while the next one renders, so only the last chunk's copy adds to
+ * the frame time; lol_gpu_set_host_chunks(ctx, 1..16) / LOL_GPU_HOST_CHUNKS (default 4; 1 = one launch, one copy).
  */
 int lol_gpu_render_host(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h, int max_steps,
                         void* host_pixels, size_t pitch_bytes);
-enum { LOL_GPU_HOST_COPY = 0, LOL_GPU_HOST_DIRECT = 1 };
-int lol_gpu_set_host_mode(lol_gpu* ctx, int mode);
-/* the route the last host-surface frame really took */
-int lol_gpu_host_mode_used(const lol_gpu* ctx);
-
-/*
- * Page-lock [ptr, ptr + bytes) and map it for every device (hipHostRegister, portable + mapped); process-wide,
- * remembered by address range, at most four ranges (the oldest is released).  Returns 0 and the address the
- * CURRENT device uses for `ptr` in *dev_ptr (may be NULL), or LOL_GPU_ERR_HIP when the memory cannot be registered.
- * The caller vouches that the range stays mapped until lol_gpu_unpin_host(ptr) (ptr = NULL: every range; the last
- * context to be destroyed releases what is left).  Only the direct route above uses it.
- */
-int lol_gpu_pin_host(void* ptr, size_t bytes, void** dev_ptr);
-int lol_gpu_unpin_host(void* ptr);
+int lol_gpu_set_host_chunks(lol_gpu* ctx, int chunks);
 
 /*
  * The same with two frames in flight, for hosts that can give the next frame's camera before they consume the
@@ -300,16 +277,13 @@ int  lol_gpu_part_frame_row(int h, const lol_gpu_rows* rows, int local_row);
 int  lol_gpu_multi_render_device(lol_gpu_multi* m, const lol_frame_camera* cam, int w, int h, int max_steps,
                                  void* dst, size_t pitch_bytes);
 /* What render_thread does with surf->pixels: one frame over all devices into a HOST surface; waits.  No exchange is
- * needed for this: every device writes its own bands into the surface over its own PCIe link, all devices at once —
- * one host thread per device issues that device's strided copies (one per part; host mode "copy", the default: a copy
- * into pageable memory occupies the thread that issues it, so N threads are what makes N links run in parallel), or
- * the devices' kernels store straight into the pinned, mapped surface (host mode "direct", opt-in as for one device).
- * set_host_via_root(m, 1) (or LOL_GPU_MULTI_HOST_VIA_ROOT=1) instead assembles on the root with the RCCL exchange and
- * copies from there. */
+ * needed for this: every device copies its own bands into the surface over its own PCIe link, all devices at once —
+ * one host thread per device issues that device's strided copies (one per part): a copy into pageable memory occupies
+ * the thread that issues it, so N threads are what makes N links run in parallel.  set_host_via_root(m, 1) (or
+ * LOL_GPU_MULTI_HOST_VIA_ROOT=1) instead assembles on the root with the RCCL exchange and copies from there. */
 int  lol_gpu_multi_render_host(lol_gpu_multi* m, const lol_frame_camera* cam, int w, int h, int max_steps,
                                void* host_pixels, size_t pitch_bytes);
 int  lol_gpu_multi_set_host_via_root(lol_gpu_multi* m, int enable);
-int  lol_gpu_multi_set_host_mode(lol_gpu_multi* m, int mode);          /* LOL_GPU_HOST_* for every device */
 int  lol_gpu_multi_set_pixel_format(lol_gpu_multi* m, const lol_gpu_pixel_format* fmt);
 /* Parts per device (default 1): the frame's bands are dealt over n_parts parts and the parts over the devices, `parts`
  * rounds of one part per device (lol_gpu_deal_parts).  Finer interleaving of the rows, the unit of the root's smaller

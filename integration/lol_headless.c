@@ -6,7 +6,7 @@
  *   lol_headless <threads> <scene.lol> [--size WxH] [--frames N] [--out frame.ppm]
  *                [--orbit] [--keys SCRIPT] [--dump-camera FILE] [--pipeline]
  *                [--format NAME] [--resize-script WxH,WxH,..] [--dump-frames PREFIX]
- *                [renderer flags: --device N | --devices A,B,.. --max-steps N --host-mode M ...]
+ *                [renderer flags: --device N | --devices A,B,.. --max-steps N --host-chunks N ...]
  *   --format NAME            pixel format of the surface, as SDL names it: xrgb8888 (default), argb8888, bgrx8888,
  *                            rgba8888, abgr8888; rgb565 and index8 exist to see the plug-in refuse them
  *   --resize-script LIST     the window is resizable (main.c:157) and its surface re-fetched every frame (main.c:182):
@@ -168,9 +168,6 @@ int main(int argc, const char* argv[]) {
 		if (n_sizes) {                                           /* SDL_GetWindowSurface after a resize: a new surface */
 			const int k = f < n_sizes ? f : n_sizes - 1;
 			if (sizes[k][0] != surf.w || sizes[k][1] != surf.h) {
-				/* a host that lets the renderer store straight into its surface (--host-mode direct) owes it this
-				 * call before the memory goes away (include/lol_gpu.h); a no-op for the default copy route */
-				lol_gpu_unpin_host(surf.pixels);
 				free(surf.pixels);
 				w = surf.w = sizes[k][0]; h = surf.h = sizes[k][1];
 				surf.pitch = (w + 13) * 4;
@@ -224,7 +221,6 @@ int main(int argc, const char* argv[]) {
 	render_destroy(&data);
 
 	free(tid);
-	lol_gpu_unpin_host(surf.pixels);
 	free(surf.pixels);
 	lol_scene_free(scene);
 	sem_destroy(&entry);

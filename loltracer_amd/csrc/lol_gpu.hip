@@ -25,7 +25,6 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <algorithm>
-#include <atomic>
 #include <cmath>
 #include <functional>
 #include <cstddef>
@@ -61,9 +60,10 @@ struct lol_gpu {
 	/* the surface's pixel format (lol_gpu_set_pixel_format), packed as lol::Launch wants it; default XRGB8888 */
 	uint32_t     fmt_shift = 16u | 8u << 8 | 0u << 16, fmt_loss = 0, fmt_amask = 0;
 	/* host-surface path */
-	int          host_mode = LOL_GPU_HOST_COPY, host_mode_used = -1;
-	uint32_t*    d_frame = nullptr;      /* framebuffer for lol_gpu_render_host in the copy modes */
+	int          host_chunks = 4;        /* lol_gpu_render_host: row chunks per frame (copy of chunk i under the kernel of chunk i+1) */
+	uint32_t*    d_frame = nullptr;      /* framebuffer for lol_gpu_render_host */
 	size_t       frame_bytes = 0;
+	hipEvent_t   chunk_rendered[16] = { nullptr };
 	/* lol_gpu_render_host_begin / _end: two frames in flight, one device framebuffer each (sized per slot, so frames of
 	 * different sizes can be in flight while the host's window is being resized) */
 	uint32_t*    d_pipe[2] = { nullptr, nullptr };
@@ -108,69 +108,6 @@ int fail(lol_gpu* ctx, int status, const char* what, hipError_t e = hipSuccess) 
 		hipError_t e_ = (call);                                                   \
 		if (e_ != hipSuccess) return fail((ctx), LOL_GPU_ERR_HIP, #call, e_);     \
 	} while (0)
-
-/* ------------------------------------------------------------- pinned host surfaces
- * The reference's renderer writes into surf->pixels, host memory the HOST owns (SDL's window surface, main.c:182).
- * The default route copies into it and lets the HIP runtime pin the pages for the duration of each copy (measured:
- * PCIe line rate, tools/d2h_bench.hip).  The DIRECT route (opt-in, include/lol_gpu.h) has the kernel store into the
- * surface itself, which needs the surface page-locked and mapped for the devices (hipHostRegister) — remembered here
- * by address, because registering per frame would cost more than the copy it saves.  That memory is only as good as
- * the host's promise to keep it mapped: a range unmapped and mapped again behind the library's back is NOT followed
- * (the device then writes to pages that are gone and the runtime aborts the process — seen once in
- * tests/test_gpu_boundary.py before the route became opt-in).  Process-wide, because every device of a multi-device
- * host writes the same surface. */
-struct HostPins {
-	struct Range { char* base; size_t bytes; unsigned long stamp; };
-	static constexpr int MAX = 4;
-	std::mutex mu;
-	Range r[MAX] = {};
-	int n = 0;
-	unsigned long clock = 0;
-	bool enabled() const { const char* e = getenv("LOL_GPU_PIN_HOST"); return !(e && e[0] == '0'); }
-	void drop(int i) {
-		/* (the host may have freed — unmapped — the range already: then this fails, and the failure must not stay
-		 * behind as the thread's "last error" for the next hipGetLastError() of whoever shares the thread) */
-		if (hipHostUnregister(r[i].base) != hipSuccess) (void)hipGetLastError();
-		r[i] = r[--n];
-	}
-	/* true when [p, p + bytes) is registered afterwards */
-	bool pin(void* ptr, size_t bytes) {
-		if (!ptr || !bytes || !enabled()) return false;
-		std::lock_guard<std::mutex> lock(mu);
-		const size_t page = (size_t)sysconf(_SC_PAGESIZE);
-		char* lo = reinterpret_cast<char*>(reinterpret_cast<uintptr_t>(ptr) & ~(uintptr_t)(page - 1));
-		char* hi = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(ptr) + bytes + page - 1) & ~(uintptr_t)(page - 1));
-		for (int i = 0; i < n; i++)
-			if (r[i].base <= lo && hi <= r[i].base + r[i].bytes) { r[i].stamp = ++clock; return true; }
-		/* a range that overlaps without covering is the old surface at (partly) the same address: release it */
-		for (int i = n - 1; i >= 0; i--)
-			if (r[i].base < hi && lo < r[i].base + r[i].bytes) drop(i);
-		if (n == MAX) {
-			int oldest = 0;
-			for (int i = 1; i < n; i++) if (r[i].stamp < r[oldest].stamp) oldest = i;
-			drop(oldest);
-		}
-		if (hipHostRegister(lo, (size_t)(hi - lo), hipHostRegisterPortable | hipHostRegisterMapped) != hipSuccess) {
-			(void)hipGetLastError();
-			return false;
-		}
-		r[n++] = { lo, (size_t)(hi - lo), ++clock };
-		return true;
-	}
-	void unpin(void* ptr) {
-		std::lock_guard<std::mutex> lock(mu);
-		for (int i = n - 1; i >= 0; i--)
-			if (!ptr || (r[i].base <= static_cast<char*>(ptr) && static_cast<char*>(ptr) < r[i].base + r[i].bytes)) drop(i);
-	}
-} g_pins;
-std::atomic<int> g_live_contexts{0};     /* the last context to go releases the pinned ranges */
-
-/* the device's address of pinned host memory, nullptr when it has none */
-void* device_view(void* host_ptr) {
-	void* d = nullptr;
-	if (hipHostGetDevicePointer(&d, host_ptr, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-	return d;
-}
 
 template <int SSIZE>
 hipError_t launch_sdf_interp(const uint32_t* mops, uint32_t n_mops, const float* pts, float* dist, uint32_t* id, uint32_t n,
@@ -1227,13 +1164,12 @@ int lol_gpu_create(int device, lol_gpu** out) {
 		/* macro-ops + test records <= 1.5 x ops */
 		if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_mops[i]), (size_t)(2 * LOL_MAX_OPS) * lol::MOP_DWORDS * 4);
 	}
-	if (const char* hm = getenv("LOL_GPU_HOST_MODE")) ctx->host_mode = !strcmp(hm, "direct") ? LOL_GPU_HOST_DIRECT : LOL_GPU_HOST_COPY;
+	if (const char* hc = getenv("LOL_GPU_HOST_CHUNKS")) ctx->host_chunks = std::max(1, std::min(atoi(hc), 16));
 	if (e != hipSuccess) {
 		fprintf(stderr, "lol_gpu_create: %s\n", hipGetErrorString(e));
 		lol_gpu_destroy(ctx);
 		return LOL_GPU_ERR_HIP;
 	}
-	g_live_contexts++;
 	*out = ctx;
 	return LOL_GPU_OK;
 }
@@ -1254,10 +1190,9 @@ void lol_gpu_destroy(lol_gpu* ctx) {
 		if (ctx->pipe_rendered[i]) (void)hipEventDestroy(ctx->pipe_rendered[i]);
 		if (ctx->pipe_copied[i]) (void)hipEventDestroy(ctx->pipe_copied[i]);
 	}
+	for (auto& e : ctx->chunk_rendered) if (e) (void)hipEventDestroy(e);
 	if (ctx->d_bad) (void)hipFree(ctx->d_bad);
-	const bool counted = ctx->stream != nullptr && ctx->d_mops[1] != nullptr;     /* lol_gpu_create got to the end */
 	delete ctx;
-	if (counted && --g_live_contexts == 0) g_pins.unpin(nullptr);
 }
 
 const char* lol_gpu_error(const lol_gpu* ctx) { return ctx ? ctx->err : "null context"; }
@@ -1480,45 +1415,41 @@ int lol_gpu_set_pixel_format(lol_gpu* ctx, const lol_gpu_pixel_format* fmt) {
 	return LOL_GPU_OK;
 }
 
-int lol_gpu_set_host_mode(lol_gpu* ctx, int mode) {
-	if (!ctx || (mode != LOL_GPU_HOST_COPY && mode != LOL_GPU_HOST_DIRECT)) return LOL_GPU_ERR_ARG;
-	ctx->host_mode = mode;
+int lol_gpu_set_host_chunks(lol_gpu* ctx, int chunks) {
+	if (!ctx || chunks < 1 || chunks > 16) return LOL_GPU_ERR_ARG;
+	ctx->host_chunks = chunks;
 	return LOL_GPU_OK;
 }
 
-int lol_gpu_host_mode_used(const lol_gpu* ctx) { return ctx ? ctx->host_mode_used : -1; }
-
-int lol_gpu_pin_host(void* ptr, size_t bytes, void** dev_ptr) {
-	if (!ptr || !bytes) return LOL_GPU_ERR_ARG;
-	if (!g_pins.pin(ptr, bytes)) return LOL_GPU_ERR_HIP;
-	if (dev_ptr) *dev_ptr = device_view(ptr);
+static int ensure_copy_stream(lol_gpu* ctx) {
+	if (ctx->copy_stream) return LOL_GPU_OK;
+	LOL_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+	for (int i = 0; i < 2; i++) {
+		LOL_HIP(ctx, hipEventCreateWithFlags(&ctx->pipe_rendered[i], hipEventDisableTiming));
+		LOL_HIP(ctx, hipEventCreateWithFlags(&ctx->pipe_copied[i], hipEventDisableTiming));
+	}
+	for (auto& e : ctx->chunk_rendered) LOL_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
 	return LOL_GPU_OK;
 }
 
-int lol_gpu_unpin_host(void* ptr) { g_pins.unpin(ptr); return LOL_GPU_OK; }
-
-/* The direct route's destination: the device's address of the (pinned, mapped) surface, nullptr = copy instead. */
-static void* direct_target(lol_gpu* ctx, void* host_pixels, size_t pitch_bytes, int w, int h) {
-	if (ctx->host_mode != LOL_GPU_HOST_DIRECT || pitch_bytes % 4 || reinterpret_cast<uintptr_t>(host_pixels) % 4) return nullptr;
-	/* the last row is w*4 bytes long, not a whole pitch: a surface need not own the padding behind it */
-	if (!g_pins.pin(host_pixels, pitch_bytes * (size_t)(h - 1) + (size_t)w * 4)) return nullptr;
-	return device_view(host_pixels);
-}
-
+/*
+ * The surface is memory the HOST owns (SDL's window surface, main.c:182): nothing about it is remembered between
+ * calls, and it is never registered with the device by this library — the HIP runtime pins the pages of a copy's
+ * destination for the duration of that copy by itself and reaches PCIe line rate that way (56 GB/s into plain malloc'd
+ * memory on MI355X, the same as into hipHostRegister'd memory: tools/d2h_bench.hip, profiles/r3_d2h_routes.jsonl).
+ * (Round 3 also built the other way — the surface registered once by address, the kernel storing straight into it:
+ * +27 % per frame, but a host that unmaps and re-maps its surface behind the library's back, as SDL may on a resize,
+ * left the device writing into pages that were gone and the runtime aborted the process.  Dropped.)
+ *
+ * What the copy costs is latency — 0.6 ms behind a 1.45 ms kernel for a 4K frame — so the frame is rendered as
+ * `host_chunks` row chunks (one launch each, same pixels: rows are independent) and chunk i is copied while chunk i+1
+ * renders: only the last chunk's copy is left uncovered.
+ */
 int lol_gpu_render_host(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h, int max_steps,
                         void* host_pixels, size_t pitch_bytes) {
 	if (!ctx || !host_pixels) return LOL_GPU_ERR_ARG;
 	if (w <= 0 || h <= 0 || pitch_bytes < (size_t)w * 4) return fail(ctx, LOL_GPU_ERR_ARG, "bad frame geometry");
 	LOL_HIP(ctx, hipSetDevice(ctx->device));
-	void* direct = direct_target(ctx, host_pixels, pitch_bytes, w, h);
-	ctx->host_mode_used = direct ? LOL_GPU_HOST_DIRECT : LOL_GPU_HOST_COPY;
-	if (direct) {
-		/* the kernel's 64-byte row-segment stores go over the PCIe link into the mapped surface: nothing to copy */
-		int st = lol_gpu_render_device(ctx, cam, w, h, max_steps, nullptr, direct, pitch_bytes, nullptr, nullptr);
-		if (st != LOL_GPU_OK) return st;
-		LOL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-		return LOL_GPU_OK;
-	}
 	size_t need = (size_t)w * h * 4;
 	if (need > ctx->frame_bytes) {          /* the surface may be resized between frames (main.c:182-187) */
 		if (ctx->d_frame) { LOL_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_frame); }
@@ -1526,11 +1457,34 @@ int lol_gpu_render_host(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h,
 		LOL_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_frame), need));
 		ctx->frame_bytes = need;
 	}
-	int st = lol_gpu_render_device(ctx, cam, w, h, max_steps, nullptr, ctx->d_frame, (size_t)w * 4, nullptr, nullptr);
+	/* chunks of whole 4-row wave patches, at least 64 rows each: small frames are one launch and one copy */
+	int chunks = std::min(ctx->host_chunks, std::max(1, h / 64));
+	const int rows_per = ((h + chunks - 1) / chunks + 3) & ~3;
+	chunks = (h + rows_per - 1) / rows_per;
+	if (chunks <= 1) {
+		int st = lol_gpu_render_device(ctx, cam, w, h, max_steps, nullptr, ctx->d_frame, (size_t)w * 4, nullptr, nullptr);
+		if (st != LOL_GPU_OK) return st;
+		LOL_HIP(ctx, hipMemcpy2DAsync(host_pixels, pitch_bytes, ctx->d_frame, (size_t)w * 4, (size_t)w * 4, h,
+		                              hipMemcpyDeviceToHost, ctx->stream));
+		LOL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		return LOL_GPU_OK;
+	}
+	int st = ensure_copy_stream(ctx);
 	if (st != LOL_GPU_OK) return st;
-	LOL_HIP(ctx, hipMemcpy2DAsync(host_pixels, pitch_bytes, ctx->d_frame, (size_t)w * 4, (size_t)w * 4, h,
-	                              hipMemcpyDeviceToHost, ctx->stream));
-	LOL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	for (int c = 0; c < chunks; c++) {          /* every launch first: the device never waits for the host */
+		const lol_gpu_rows R = { rows_per, chunks, c, 0 };      /* band c = rows [c * rows_per, …): a contiguous chunk */
+		st = lol_gpu_render_device(ctx, cam, w, h, max_steps, &R, ctx->d_frame + (size_t)c * rows_per * w, (size_t)w * 4, nullptr, nullptr);
+		if (st != LOL_GPU_OK) return st;
+		LOL_HIP(ctx, hipEventRecord(ctx->chunk_rendered[c], ctx->stream));
+	}
+	for (int c = 0; c < chunks; c++) {
+		const int y0 = c * rows_per, rows = std::min(rows_per, h - y0);
+		LOL_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->chunk_rendered[c], 0));
+		LOL_HIP(ctx, hipMemcpy2DAsync(static_cast<char*>(host_pixels) + (size_t)y0 * pitch_bytes, pitch_bytes,
+		                              ctx->d_frame + (size_t)y0 * w, (size_t)w * 4, (size_t)w * 4, rows,
+		                              hipMemcpyDeviceToHost, ctx->copy_stream));
+	}
+	LOL_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
 	return LOL_GPU_OK;
 }
 
@@ -1538,20 +1492,17 @@ int lol_gpu_render_host(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h,
  * The host-surface path with two frames in flight: begin() queues frame i+1's kernel while end() copies frame i
  * into the host's surface, so the 33 MB device-to-host copy of a 4K frame (0.6 ms at PCIe Gen5 rates) runs under
  * the next frame's kernel instead of after its own.  Kernels go to the context's stream, copies to a second
- * stream, two device framebuffers alternate.  (Always the copy route: measured at the kernel's own rate on C3 — the
- * copy hides completely — bench.py `host_surface`.)
+ * stream, two device framebuffers alternate.  Measured at the kernel's own rate on C3: the copy hides completely
+ * (bench.py `host_surface`).
  */
 int lol_gpu_render_host_begin(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h, int max_steps) {
 	if (!ctx || !cam) return LOL_GPU_ERR_ARG;
 	if (w <= 0 || h <= 0) return fail(ctx, LOL_GPU_ERR_ARG, "bad frame geometry");
 	if (ctx->pipe_begun - ctx->pipe_ended >= 2) return fail(ctx, LOL_GPU_ERR_ARG, "two frames already in flight: call lol_gpu_render_host_end first");
 	LOL_HIP(ctx, hipSetDevice(ctx->device));
-	if (!ctx->copy_stream) {
-		LOL_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-		for (int i = 0; i < 2; i++) {
-			LOL_HIP(ctx, hipEventCreateWithFlags(&ctx->pipe_rendered[i], hipEventDisableTiming));
-			LOL_HIP(ctx, hipEventCreateWithFlags(&ctx->pipe_copied[i], hipEventDisableTiming));
-		}
+	{
+		const int st = ensure_copy_stream(ctx);
+		if (st != LOL_GPU_OK) return st;
 	}
 	const int slot = (int)(ctx->pipe_begun & 1u);
 	const size_t need = (size_t)w * h * 4;
@@ -1586,7 +1537,6 @@ int lol_gpu_render_host_end(lol_gpu* ctx, void* host_pixels, size_t pitch_bytes,
 		return fail(ctx, LOL_GPU_ERR_ARG, "the queued frame's size differs from the surface's: lol_gpu_render_host_discard");
 	if (pitch_bytes < (size_t)w * 4) return fail(ctx, LOL_GPU_ERR_ARG, "bad frame geometry");
 	LOL_HIP(ctx, hipSetDevice(ctx->device));
-	ctx->host_mode_used = LOL_GPU_HOST_COPY;
 	LOL_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->pipe_rendered[slot], 0));
 	LOL_HIP(ctx, hipMemcpy2DAsync(host_pixels, pitch_bytes, ctx->d_pipe[slot], (size_t)w * 4, (size_t)w * 4, h,
 	                              hipMemcpyDeviceToHost, ctx->copy_stream));

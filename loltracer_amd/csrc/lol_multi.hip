@@ -17,11 +17,10 @@
  * RCCL itself is resolved with dlopen, and the communicators are created, on the first frame that needs the
  * exchange: librccl is a 570 MB library that a host which never assembles on a device should not have to map.
  *
- * A HOST surface (what render_thread fills, naive_renderer.c:233-235) needs no exchange at all: the surface is pinned
- * and mapped for every device (lol_gpu_pin_host) and every device writes its own bands into it over its own PCIe link —
- * its kernels store straight into the surface (lol_gpu_rows.in_place, host mode "direct") or its exchange stream copies
- * its parts there (one strided asynchronous hipMemcpy3DAsync per part, host mode "copy") — instead of funnelling 4 B per
- * pixel through the root's single link (132 MB = 2.4 ms for a C4 frame).
+ * A HOST surface (what render_thread fills, naive_renderer.c:233-235) needs no exchange at all: every device copies its
+ * own bands into it over its own PCIe link (one strided hipMemcpy3DAsync per part, issued by a host thread per device so
+ * that the links run at once) instead of funnelling 4 B per pixel through the root's single link (132 MB = 2.4 ms for a
+ * C4 frame).  The surface is the host's memory and is never registered with the devices (lol_gpu.hip, lol_gpu_render_host).
  *
  * Parts and their owners.  A frame's bands are dealt round-robin over n_parts PARTS, and the parts round-robin over
  * the devices: parts_per_device rounds, every device taking one part per round — except that the root sits out the
@@ -218,7 +217,6 @@ struct lol_gpu_multi {
 	int       root_parts = 1;                          /* parts of the root (<= per_dev): its smaller share */
 	int       n_parts = 1;
 	int       owner[MAX_PARTS] = { 0 };                /* device index of every part (lol_gpu_deal_parts) */
-	int       host_mode = LOL_GPU_HOST_COPY;
 	int       host_via_root = 0;                       /* render_host: assemble on the root first (RCCL) instead of direct copies */
 	uint32_t* staging[SLOTS] = { nullptr, nullptr };   /* root: every part of a frame, back to back */
 	size_t    staging_bytes = 0;
@@ -415,8 +413,6 @@ int lol_gpu_multi_create(const int* devices, int n, lol_gpu_multi** out) {
 		if (e != hipSuccess) return bail("event setup", hipGetErrorString(e));
 	}
 	if (const char* e = getenv("LOL_GPU_MULTI_HOST_VIA_ROOT")) m->host_via_root = e[0] == '1';
-	if (const char* hm = getenv("LOL_GPU_HOST_MODE"))
-		m->host_mode = !strcmp(hm, "direct") ? LOL_GPU_HOST_DIRECT : LOL_GPU_HOST_COPY;
 	m->n_parts = lol_gpu_deal_parts(n, m->per_dev, m->root_parts, m->owner, MAX_PARTS);
 	*out = m;
 	return LOL_GPU_OK;
@@ -496,12 +492,6 @@ int lol_gpu_multi_set_root_parts(lol_gpu_multi* m, int root_parts) {
 	if (st != LOL_GPU_OK) return st;
 	m->root_parts = root_parts;
 	m->n_parts = lol_gpu_deal_parts(m->n, m->per_dev, m->root_parts, m->owner, MAX_PARTS);
-	return LOL_GPU_OK;
-}
-
-int lol_gpu_multi_set_host_mode(lol_gpu_multi* m, int mode) {
-	if (!m || (mode != LOL_GPU_HOST_COPY && mode != LOL_GPU_HOST_DIRECT)) return LOL_GPU_ERR_ARG;
-	m->host_mode = mode;
 	return LOL_GPU_OK;
 }
 
@@ -676,27 +666,8 @@ int lol_gpu_multi_render_host(lol_gpu_multi* m, const lol_frame_camera* cam, int
 	Split S;
 	int st = split_frame(m, h, S);
 	if (st != LOL_GPU_OK) return st;
-	/* direct (opt-in: the host vouches for the surface, include/lol_gpu.h): pinned and mapped for every device, the
-	 * kernels store straight into it */
-	void* view[LOL_GPU_MULTI_MAX_DEVICES] = { nullptr };
-	bool direct = m->host_mode == LOL_GPU_HOST_DIRECT && pitch_bytes % 4 == 0 && reinterpret_cast<uintptr_t>(host_pixels) % 4 == 0 &&
-	              lol_gpu_pin_host(host_pixels, pitch_bytes * (size_t)(h - 1) + (size_t)w * 4, nullptr) == LOL_GPU_OK;
-	for (int d = 0; d < m->n && direct; d++) {
-		M_HIP(m, hipSetDevice(m->dev[d].id));
-		if (hipHostGetDevicePointer(&view[d], host_pixels, 0) != hipSuccess || !view[d]) { (void)hipGetLastError(); direct = false; }
-	}
 	const int slot = (int)(m->frames % SLOTS);
 	m->frames++;
-	if (direct) {
-		st = render_parts(m, cam, w, h, max_steps, S, slot, view, pitch_bytes);
-		if (st != LOL_GPU_OK) return st;
-		for (int d = 0; d < m->n; d++) {
-			M_HIP(m, hipSetDevice(m->dev[d].id));
-			M_HIP(m, hipStreamSynchronize(m->dev[d].render));
-		}
-		M_HIP(m, hipSetDevice(root.id));
-		return LOL_GPU_OK;
-	}
 	st = ensure_buffers(m, w, h, S.dev_rows, false);
 	if (st != LOL_GPU_OK) return st;
 	st = render_parts(m, cam, w, h, max_steps, S, slot);

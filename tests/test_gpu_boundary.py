@@ -3,7 +3,7 @@ format the window has this frame (main.c:157,182-187; renderer.h:17-22).
 
   - colorf_to_pixfmt maps through the SURFACE's format: the kernel's pack equals SDL_MapRGB's definition, computed
     here in numpy from the float colours, for XRGB / ARGB / BGRX / RGBA / ABGR; palettised and 16-bit are refused;
-  - pixels reach the surface directly from the kernel (pinned + mapped), by an asynchronous copy, or pageable: same bits;
+  - pixels reach the surface in row chunks copied under the next chunk's kernel: same bits for any chunk count;
   - the surface may change size between frames, with frames in flight: nothing is ever written beyond a surface;
   - a rejected scene upload leaves the previous scene rendering.
 """
@@ -103,42 +103,27 @@ def test_device_packs_like_sdl_map_rgb(torch_cuda, scenes, specialize):
 
 
 @pytest.mark.gpu
-def test_host_surface_routes_agree(torch_cuda, scenes):
-    """copy (device framebuffer + pitched copy: the default, safe for any host memory) == direct (the kernel stores into
-    the pinned, mapped surface: opt-in), padding untouched."""
+def test_host_surface_in_row_chunks(torch_cuda, scenes):
+    """lol_gpu_render_host renders a frame as row chunks and copies chunk i while chunk i+1 renders: the same surface
+    for every chunk count, odd sizes, padded and unaligned pitches; padding untouched."""
     sc = scenes["scene4"]
     r = gpu.Renderer(0)
     r.prepare(sc)
-    r.render_host(np.zeros(64 * 64, dtype=np.uint32).ctypes.data, 64, 64)
-    assert r.host_mode_used() == gpu.HOST_COPY                # the default never pins what it does not own
-    for (w, h, pitch) in ((200, 120, 203 * 4), (97, 61, 97 * 4), (640, 360, 700 * 4), (33, 7, 33 * 4 + 2)):
+    for (w, h, pitch) in ((200, 120, 203 * 4), (97, 61, 97 * 4), (640, 360, 700 * 4), (33, 7, 33 * 4 + 2), (320, 517, 320 * 4),
+                          (1280, 720, 1280 * 4 + 6)):
         want, _, _ = O.render(sc, w, h, threads=4)
-        for mode in (gpu.HOST_COPY, gpu.HOST_DIRECT):
-            r.set_host_mode(mode)
+        for chunks in (1, 2, 4, 7, 16):
+            r.set_host_chunks(chunks)
             buf = np.full(h * pitch + 64, 0xA5, dtype=np.uint8)
-            base = buf.ctypes.data
-            r.render_host(base, w, h, pitch_bytes=pitch)
+            r.render_host(buf.ctypes.data, w, h, pitch_bytes=pitch)
             rows = np.stack([buf[y * pitch:y * pitch + w * 4].view(np.uint32) for y in range(h)])
-            assert np.array_equal(rows, want), (w, h, mode)
+            assert np.array_equal(rows, want), (w, h, chunks)
             for y in range(h):                                   # row padding and the tail are untouched
                 assert np.all(buf[y * pitch + w * 4:(y + 1) * pitch] == 0xA5)
             assert np.all(buf[h * pitch:] == 0xA5)
-            if mode == gpu.HOST_DIRECT and pitch % 4 == 0:
-                assert r.host_mode_used() == gpu.HOST_DIRECT
-            else:
-                assert r.host_mode_used() == gpu.HOST_COPY       # a pitch that is no multiple of 4 cannot be stored into
-            assert gpu.gpu_lib().lol_gpu_unpin_host(base) == 0   # the host vouched for `buf` only until here
-    # direct: the same memory again, a sub-range of it, a larger frame in it: re-pinned as needed
-    big = np.zeros(1 << 22, dtype=np.uint8)
-    r.set_host_mode(gpu.HOST_DIRECT)
-    for (w, h) in ((64, 64), (128, 128), (640, 360), (64, 64)):
-        want, _, _ = O.render(sc, w, h, threads=4)
-        r.render_host(big.ctypes.data, w, h, pitch_bytes=w * 4)
-        assert r.host_mode_used() == gpu.HOST_DIRECT
-        assert np.array_equal(big[:w * h * 4].view(np.uint32).reshape(h, w), want)
-    assert gpu.gpu_lib().lol_gpu_unpin_host(None) == 0
-    r.render_host(big.ctypes.data, 64, 64, pitch_bytes=256)     # pinned again on demand
-    assert gpu.gpu_lib().lol_gpu_unpin_host(None) == 0
+    for bad in (0, 17):
+        with pytest.raises(gpu.GpuError):
+            r.set_host_chunks(bad)
     r.close()
 
 
@@ -161,7 +146,6 @@ size = w * h * 4
 addr = libc.mmap(None, size, PROT_RW, MAP_PRIVATE | MAP_ANON, -1, 0)
 for (ww, hh) in ((w, h), (w, h), (w // 2, h // 2), (w, h)):
     r.render_host(addr, ww, hh, pitch_bytes=ww * 4)
-    assert r.host_mode_used() == gpu.HOST_COPY
     got = np.ctypeslib.as_array(C.cast(addr, C.POINTER(C.c_uint32)), shape=(hh * ww,)).reshape(hh, ww).copy()
     assert np.array_equal(got, O.render(sc, ww, hh, threads=4)[0]), (ww, hh)
     assert libc.munmap(addr, size) == 0                      # the host drops the surface ...
@@ -176,10 +160,11 @@ print("remap ok")
 @pytest.mark.gpu
 def test_surface_freed_and_mapped_again_at_the_same_address(tmp_path):
     """SDL frees the window surface on a resize and allocates a new one (main.c:182); the allocator may hand out the
-    SAME address for new pages.  The default route remembers nothing about the surface between frames, so the new pages
-    get the frame: map, render, unmap, map again at that very address, render, for a same-size and a smaller surface.
-    (The opt-in direct route pins by address and must not be used by such a host — include/lol_gpu.h; when this case was
-    first run against it the runtime aborted the process.)  Runs in a process of its own."""
+    SAME address for new pages.  The library remembers nothing about the surface between frames and never registers it
+    with the device, so the new pages get the frame: map, render, unmap, map again at that very address, render, for a
+    same-size and a smaller surface.  (Round 3 first pinned surfaces by address and had the kernel store into them: this
+    very case aborted the process, which is why that route is gone — lol_gpu.hip, lol_gpu_render_host.)  Runs in a process
+    of its own."""
     import sys
     p = subprocess.run([sys.executable, "-c", REMAP_SCRIPT.format(root=ROOT, scene=SCENE4)], capture_output=True, text=True, timeout=180)
     assert p.returncode == 0 and "remap ok" in p.stdout, p.stderr[-2000:]
@@ -234,9 +219,8 @@ def read_frames(prefix, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("flags", [[], ["--pipeline"], ["--host-mode", "direct"],
-                                   ["--devices", "0", "--parts-per-device", "3"],
-                                   ["--devices", "0", "--parts-per-device", "3", "--host-mode", "direct"]])
+@pytest.mark.parametrize("flags", [[], ["--pipeline"], ["--host-chunks", "1"], ["--host-chunks", "9"],
+                                   ["--devices", "0", "--parts-per-device", "3"]])
 def test_c_host_resizes_between_frames(tmp_path, scenes, flags):
     """main.c:182-187 through render_thread: grow, shrink, grow again on ONE context; every surface the host sees equals
     the oracle's frame of that size (static camera, so the pipelined mode's one-frame lag shows the same picture)."""
