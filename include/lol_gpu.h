@@ -123,16 +123,15 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 
 /*
  * Whole frame into a HOST surface (what render_thread does with surf->pixels,
- * naive_renderer.c:233-235), honouring `pitch_bytes`; returns when the surface holds the frame.
+ * naive_renderer.c:233-235): renders into the context's device framebuffer,
+ * copies `h` rows of w*4 bytes honouring `pitch_bytes`, and waits.
  *
  * The surface is the host's memory: the library keeps nothing about it between calls and never registers it with the
- * device (the HIP runtime pins a copy's destination for the duration of the copy: PCIe line rate, measured).  The frame
- * is rendered as a few row chunks, each copied while the next one renders, so only the last chunk's copy adds to
- * the frame time; lol_gpu_set_host_chunks(ctx, 1..16) / LOL_GPU_HOST_CHUNKS (default 4; 1 = one launch, one copy).
+ * device (the HIP runtime pins a copy's destination for the duration of the copy: PCIe line rate, measured), so a host
+ * may free, move or resize its surface between any two frames (main.c:182-187).
  */
 int lol_gpu_render_host(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h, int max_steps,
                         void* host_pixels, size_t pitch_bytes);
-int lol_gpu_set_host_chunks(lol_gpu* ctx, int chunks);
 
 /*
  * The same with two frames in flight, for hosts that can give the next frame's camera before they consume the

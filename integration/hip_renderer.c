@@ -17,9 +17,7 @@
  *                   these GPUs, each writing its bands into the surface,
  *                   include/lol_gpu.h lol_gpu_multi_*), --parts-per-device N,
  *                   --root-parts N (the first device's smaller share),
- *                   --host-chunks N (row chunks per frame whose copies into
- *                   surf->pixels overlap the rendering of the next chunk,
- *                   lol_gpu_render_host; default 4), --max-steps N, and
+ *                   --max-steps N, and
  *                   --dump-kernel BASE, the counterpart of the JIT renderer's
  *                   -j/--jitdump (tracing_jit_renderer.dasc:424-433): writes the
  *                   scene-specialised kernel as BASE.hip (generated source) and
@@ -78,7 +76,7 @@ void render_prepare(struct render_data* data, int argc, const char* argv[]) {
 	struct hip_renderer* r = calloc(1, sizeof *r);
 	int device = 0;
 	int devices[LOL_GPU_MULTI_MAX_DEVICES], n_devices = 0;
-	int parts_per_device = 0, root_parts = -1, host_chunks = 0;
+	int parts_per_device = 0, root_parts = -1;
 	const char* dump = NULL;
 	HOST_PRIVATE(data) = r;
 	if (!r) { fprintf(stderr, "hip_renderer: out of memory\n"); return; }
@@ -87,9 +85,8 @@ void render_prepare(struct render_data* data, int argc, const char* argv[]) {
 		const int is_device = !strcmp(argv[i], "--device"), is_devices = !strcmp(argv[i], "--devices");
 		const int is_steps = !strcmp(argv[i], "--max-steps"), is_dump = !strcmp(argv[i], "--dump-kernel");
 		const int is_ppd = !strcmp(argv[i], "--parts-per-device"), is_root = !strcmp(argv[i], "--root-parts");
-		const int is_chunks = !strcmp(argv[i], "--host-chunks");
 		if (!strcmp(argv[i], "--pipeline")) { r->pipeline = 1; continue; }
-		if (!(is_device || is_devices || is_steps || is_dump || is_ppd || is_root || is_chunks)) continue;      /* the host's own flags */
+		if (!(is_device || is_devices || is_steps || is_dump || is_ppd || is_root)) continue;      /* the host's own flags */
 		if (i + 1 >= argc) { fprintf(stderr, "hip_renderer: %s needs a value, ignored\n", argv[i]); break; }
 		const char* v = argv[++i];
 		if (is_device) device = atoi(v);
@@ -97,7 +94,6 @@ void render_prepare(struct render_data* data, int argc, const char* argv[]) {
 		else if (is_dump) dump = v;
 		else if (is_ppd) parts_per_device = atoi(v);
 		else if (is_root) root_parts = atoi(v);
-		else if (is_chunks) host_chunks = atoi(v);
 		else {
 			n_devices = 0;
 			for (const char* p = v; *p && n_devices < LOL_GPU_MULTI_MAX_DEVICES;) {
@@ -137,8 +133,6 @@ void render_prepare(struct render_data* data, int argc, const char* argv[]) {
 	} else {
 		st = lol_gpu_create(device, &r->gpu);
 		if (st != LOL_GPU_OK) { fprintf(stderr, "hip_renderer: no usable HIP device %d (status %d)\n", device, st); return; }
-		if (host_chunks > 0 && lol_gpu_set_host_chunks(r->gpu, host_chunks) != LOL_GPU_OK)
-			fprintf(stderr, "hip_renderer: --host-chunks %d refused (1..16)\n", host_chunks);
 		st = lol_gpu_upload_program(r->gpu, &r->program);
 		if (st != LOL_GPU_OK) { fprintf(stderr, "hip_renderer: %s\n", lol_gpu_error(r->gpu)); return; }
 	}

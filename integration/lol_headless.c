@@ -6,7 +6,7 @@
  *   lol_headless <threads> <scene.lol> [--size WxH] [--frames N] [--out frame.ppm]
  *                [--orbit] [--keys SCRIPT] [--dump-camera FILE] [--pipeline]
  *                [--format NAME] [--resize-script WxH,WxH,..] [--dump-frames PREFIX]
- *                [renderer flags: --device N | --devices A,B,.. --max-steps N --host-chunks N ...]
+ *                [renderer flags: --device N | --devices A,B,.. --max-steps N ...]
  *   --format NAME            pixel format of the surface, as SDL names it: xrgb8888 (default), argb8888, bgrx8888,
  *                            rgba8888, abgr8888; rgb565 and index8 exist to see the plug-in refuse them
  *   --resize-script LIST     the window is resizable (main.c:157) and its surface re-fetched every frame (main.c:182):

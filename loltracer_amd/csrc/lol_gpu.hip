@@ -60,10 +60,8 @@ struct lol_gpu {
 	/* the surface's pixel format (lol_gpu_set_pixel_format), packed as lol::Launch wants it; default XRGB8888 */
 	uint32_t     fmt_shift = 16u | 8u << 8 | 0u << 16, fmt_loss = 0, fmt_amask = 0;
 	/* host-surface path */
-	int          host_chunks = 4;        /* lol_gpu_render_host: row chunks per frame (copy of chunk i under the kernel of chunk i+1) */
 	uint32_t*    d_frame = nullptr;      /* framebuffer for lol_gpu_render_host */
 	size_t       frame_bytes = 0;
-	hipEvent_t   chunk_rendered[16] = { nullptr };
 	/* lol_gpu_render_host_begin / _end: two frames in flight, one device framebuffer each (sized per slot, so frames of
 	 * different sizes can be in flight while the host's window is being resized) */
 	uint32_t*    d_pipe[2] = { nullptr, nullptr };
@@ -1164,7 +1162,6 @@ int lol_gpu_create(int device, lol_gpu** out) {
 		/* macro-ops + test records <= 1.5 x ops */
 		if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_mops[i]), (size_t)(2 * LOL_MAX_OPS) * lol::MOP_DWORDS * 4);
 	}
-	if (const char* hc = getenv("LOL_GPU_HOST_CHUNKS")) ctx->host_chunks = std::max(1, std::min(atoi(hc), 16));
 	if (e != hipSuccess) {
 		fprintf(stderr, "lol_gpu_create: %s\n", hipGetErrorString(e));
 		lol_gpu_destroy(ctx);
@@ -1190,7 +1187,7 @@ void lol_gpu_destroy(lol_gpu* ctx) {
 		if (ctx->pipe_rendered[i]) (void)hipEventDestroy(ctx->pipe_rendered[i]);
 		if (ctx->pipe_copied[i]) (void)hipEventDestroy(ctx->pipe_copied[i]);
 	}
-	for (auto& e : ctx->chunk_rendered) if (e) (void)hipEventDestroy(e);
+
 	if (ctx->d_bad) (void)hipFree(ctx->d_bad);
 	delete ctx;
 }
@@ -1415,12 +1412,6 @@ int lol_gpu_set_pixel_format(lol_gpu* ctx, const lol_gpu_pixel_format* fmt) {
 	return LOL_GPU_OK;
 }
 
-int lol_gpu_set_host_chunks(lol_gpu* ctx, int chunks) {
-	if (!ctx || chunks < 1 || chunks > 16) return LOL_GPU_ERR_ARG;
-	ctx->host_chunks = chunks;
-	return LOL_GPU_OK;
-}
-
 static int ensure_copy_stream(lol_gpu* ctx) {
 	if (ctx->copy_stream) return LOL_GPU_OK;
 	LOL_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
@@ -1428,7 +1419,6 @@ static int ensure_copy_stream(lol_gpu* ctx) {
 		LOL_HIP(ctx, hipEventCreateWithFlags(&ctx->pipe_rendered[i], hipEventDisableTiming));
 		LOL_HIP(ctx, hipEventCreateWithFlags(&ctx->pipe_copied[i], hipEventDisableTiming));
 	}
-	for (auto& e : ctx->chunk_rendered) LOL_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
 	return LOL_GPU_OK;
 }
 
@@ -1437,13 +1427,14 @@ static int ensure_copy_stream(lol_gpu* ctx) {
  * calls, and it is never registered with the device by this library — the HIP runtime pins the pages of a copy's
  * destination for the duration of that copy by itself and reaches PCIe line rate that way (56 GB/s into plain malloc'd
  * memory on MI355X, the same as into hipHostRegister'd memory: tools/d2h_bench.hip, profiles/r3_d2h_routes.jsonl).
- * (Round 3 also built the other way — the surface registered once by address, the kernel storing straight into it:
- * +27 % per frame, but a host that unmaps and re-maps its surface behind the library's back, as SDL may on a resize,
- * left the device writing into pages that were gone and the runtime aborted the process.  Dropped.)
- *
- * What the copy costs is latency — 0.6 ms behind a 1.45 ms kernel for a 4K frame — so the frame is rendered as
- * `host_chunks` row chunks (one launch each, same pixels: rows are independent) and chunk i is copied while chunk i+1
- * renders: only the last chunk's copy is left uncovered.
+ * So one frame costs kernel + copy here (C3: 1.45 + 0.59 + 0.1 ms); a host that can give the next camera early hides the
+ * copy completely with lol_gpu_render_host_begin / _end below.  Two ways to hide it inside ONE call were built in round 3,
+ * measured and removed (profiles/r3_host_surface_routes.md):
+ *  - the surface registered once by address (hipHostRegister) and the kernel storing straight into it: +27 % per frame,
+ *    but a host that unmaps and re-maps its surface at the same address behind the library's back — what SDL may do to a
+ *    window surface on a resize — left the device writing into pages that were gone: the runtime aborted the process;
+ *  - the frame as row chunks, chunk i copied while chunk i+1 renders: no gain — a copy into unregistered memory costs
+ *    ~0.1 ms of pinning per call and did not run under the following kernels (4 chunks 3840 vs 3880 Mpixels/s, 8: 3020).
  */
 int lol_gpu_render_host(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h, int max_steps,
                         void* host_pixels, size_t pitch_bytes) {
@@ -1457,34 +1448,11 @@ int lol_gpu_render_host(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h,
 		LOL_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_frame), need));
 		ctx->frame_bytes = need;
 	}
-	/* chunks of whole 4-row wave patches, at least 64 rows each: small frames are one launch and one copy */
-	int chunks = std::min(ctx->host_chunks, std::max(1, h / 64));
-	const int rows_per = ((h + chunks - 1) / chunks + 3) & ~3;
-	chunks = (h + rows_per - 1) / rows_per;
-	if (chunks <= 1) {
-		int st = lol_gpu_render_device(ctx, cam, w, h, max_steps, nullptr, ctx->d_frame, (size_t)w * 4, nullptr, nullptr);
-		if (st != LOL_GPU_OK) return st;
-		LOL_HIP(ctx, hipMemcpy2DAsync(host_pixels, pitch_bytes, ctx->d_frame, (size_t)w * 4, (size_t)w * 4, h,
-		                              hipMemcpyDeviceToHost, ctx->stream));
-		LOL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-		return LOL_GPU_OK;
-	}
-	int st = ensure_copy_stream(ctx);
+	int st = lol_gpu_render_device(ctx, cam, w, h, max_steps, nullptr, ctx->d_frame, (size_t)w * 4, nullptr, nullptr);
 	if (st != LOL_GPU_OK) return st;
-	for (int c = 0; c < chunks; c++) {          /* every launch first: the device never waits for the host */
-		const lol_gpu_rows R = { rows_per, chunks, c, 0 };      /* band c = rows [c * rows_per, …): a contiguous chunk */
-		st = lol_gpu_render_device(ctx, cam, w, h, max_steps, &R, ctx->d_frame + (size_t)c * rows_per * w, (size_t)w * 4, nullptr, nullptr);
-		if (st != LOL_GPU_OK) return st;
-		LOL_HIP(ctx, hipEventRecord(ctx->chunk_rendered[c], ctx->stream));
-	}
-	for (int c = 0; c < chunks; c++) {
-		const int y0 = c * rows_per, rows = std::min(rows_per, h - y0);
-		LOL_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->chunk_rendered[c], 0));
-		LOL_HIP(ctx, hipMemcpy2DAsync(static_cast<char*>(host_pixels) + (size_t)y0 * pitch_bytes, pitch_bytes,
-		                              ctx->d_frame + (size_t)y0 * w, (size_t)w * 4, (size_t)w * 4, rows,
-		                              hipMemcpyDeviceToHost, ctx->copy_stream));
-	}
-	LOL_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+	LOL_HIP(ctx, hipMemcpy2DAsync(host_pixels, pitch_bytes, ctx->d_frame, (size_t)w * 4, (size_t)w * 4, h,
+	                              hipMemcpyDeviceToHost, ctx->stream));
+	LOL_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	return LOL_GPU_OK;
 }
 

@@ -107,8 +107,6 @@ def gpu_lib() -> C.CDLL:
         lib.lol_gpu_render_host_discard.restype = C.c_int
         lib.lol_gpu_set_pixel_format.argtypes = [vp, P(PixelFormat)]
         lib.lol_gpu_set_pixel_format.restype = C.c_int
-        lib.lol_gpu_set_host_chunks.argtypes = [vp, C.c_int]
-        lib.lol_gpu_set_host_chunks.restype = C.c_int
         lib.lol_gpu_kernel_key.argtypes = [vp]
         lib.lol_gpu_kernel_key.restype = C.c_char_p
         lib.lol_gpu_sync.argtypes = [vp]
@@ -206,7 +204,7 @@ EXPORTED_SYMBOLS = [
     "lol_gpu_part_frame_row", "lol_gpu_multi_render_device", "lol_gpu_multi_render_host", "lol_gpu_multi_sync",
     "lol_gpu_multi_malloc", "lol_gpu_multi_free", "lol_gpu_multi_memcpy_d2h", "lol_gpu_assemble_parts",
     "lol_gpu_multi_set_parts_per_device", "lol_gpu_multi_set_host_via_root",
-    "lol_gpu_set_pixel_format", "lol_gpu_set_host_chunks",
+    "lol_gpu_set_pixel_format",
     "lol_gpu_render_host_pending_size", "lol_gpu_render_host_discard", "lol_gpu_kernel_key",
     "lol_gpu_assemble_parts_at", "lol_gpu_deal_parts", "lol_gpu_choose_band_rows_for", "lol_gpu_multi_set_root_parts",
     "lol_gpu_multi_set_pixel_format",
@@ -322,9 +320,6 @@ class Renderer:
             fmt = PIXEL_FORMATS[fmt]
         self._check(self._lib.lol_gpu_set_pixel_format(self._ctx, C.byref(fmt) if fmt is not None else None))
 
-    def set_host_chunks(self, chunks: int):
-        """Row chunks per host-surface frame (chunk i is copied while chunk i+1 renders); 1 = one launch, one copy."""
-        self._check(self._lib.lol_gpu_set_host_chunks(self._ctx, chunks))
 
     def kernel_key(self) -> str:
         return self._lib.lol_gpu_kernel_key(self._ctx).decode()

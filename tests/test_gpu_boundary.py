@@ -3,7 +3,7 @@ format the window has this frame (main.c:157,182-187; renderer.h:17-22).
 
   - colorf_to_pixfmt maps through the SURFACE's format: the kernel's pack equals SDL_MapRGB's definition, computed
     here in numpy from the float colours, for XRGB / ARGB / BGRX / RGBA / ABGR; palettised and 16-bit are refused;
-  - pixels reach the surface in row chunks copied under the next chunk's kernel: same bits for any chunk count;
+  - the surface is never registered with the device: it may be freed and mapped again at the same address;
   - the surface may change size between frames, with frames in flight: nothing is ever written beyond a surface;
   - a rejected scene upload leaves the previous scene rendering.
 """
@@ -75,6 +75,7 @@ def test_device_packs_like_sdl_map_rgb(torch_cuda, scenes, specialize):
             r.set_pixel_format(name)
             frame = torch.zeros((h, w), dtype=torch.int32, device="cuda")
             rgb = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()                 # torch's fills run on ITS stream; the frame on the renderer's own
             r.render_into(frame.data_ptr(), w, h, debug=gpu.Debug(rgb.data_ptr(), None, None, None))
             r.sync()
             got = frame.cpu().numpy().view(np.uint32)
@@ -95,6 +96,7 @@ def test_device_packs_like_sdl_map_rgb(torch_cuda, scenes, specialize):
                 r.set_pixel_format(bad)
             assert e.value.status == -5
         frame = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
         r.render_into(frame.data_ptr(), w, h)
         r.sync()
         assert np.array_equal(frame.cpu().numpy().view(np.uint32), want)         # still ABGR, the last accepted format
@@ -103,27 +105,21 @@ def test_device_packs_like_sdl_map_rgb(torch_cuda, scenes, specialize):
 
 
 @pytest.mark.gpu
-def test_host_surface_in_row_chunks(torch_cuda, scenes):
-    """lol_gpu_render_host renders a frame as row chunks and copies chunk i while chunk i+1 renders: the same surface
-    for every chunk count, odd sizes, padded and unaligned pitches; padding untouched."""
+def test_host_surface_pitches_and_padding(torch_cuda, scenes):
+    """lol_gpu_render_host: odd sizes, padded and unaligned pitches; padding untouched; one context, sizes going up and down."""
     sc = scenes["scene4"]
     r = gpu.Renderer(0)
     r.prepare(sc)
     for (w, h, pitch) in ((200, 120, 203 * 4), (97, 61, 97 * 4), (640, 360, 700 * 4), (33, 7, 33 * 4 + 2), (320, 517, 320 * 4),
-                          (1280, 720, 1280 * 4 + 6)):
+                          (1280, 720, 1280 * 4 + 6), (64, 40, 256)):
         want, _, _ = O.render(sc, w, h, threads=4)
-        for chunks in (1, 2, 4, 7, 16):
-            r.set_host_chunks(chunks)
-            buf = np.full(h * pitch + 64, 0xA5, dtype=np.uint8)
-            r.render_host(buf.ctypes.data, w, h, pitch_bytes=pitch)
-            rows = np.stack([buf[y * pitch:y * pitch + w * 4].view(np.uint32) for y in range(h)])
-            assert np.array_equal(rows, want), (w, h, chunks)
-            for y in range(h):                                   # row padding and the tail are untouched
-                assert np.all(buf[y * pitch + w * 4:(y + 1) * pitch] == 0xA5)
-            assert np.all(buf[h * pitch:] == 0xA5)
-    for bad in (0, 17):
-        with pytest.raises(gpu.GpuError):
-            r.set_host_chunks(bad)
+        buf = np.full(h * pitch + 64, 0xA5, dtype=np.uint8)
+        r.render_host(buf.ctypes.data, w, h, pitch_bytes=pitch)
+        rows = np.stack([buf[y * pitch:y * pitch + w * 4].view(np.uint32) for y in range(h)])
+        assert np.array_equal(rows, want), (w, h)
+        for y in range(h):                                   # row padding and the tail are untouched
+            assert np.all(buf[y * pitch + w * 4:(y + 1) * pitch] == 0xA5)
+        assert np.all(buf[h * pitch:] == 0xA5)
     r.close()
 
 
@@ -219,8 +215,7 @@ def read_frames(prefix, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("flags", [[], ["--pipeline"], ["--host-chunks", "1"], ["--host-chunks", "9"],
-                                   ["--devices", "0", "--parts-per-device", "3"]])
+@pytest.mark.parametrize("flags", [[], ["--pipeline"], ["--devices", "0", "--parts-per-device", "3"]])
 def test_c_host_resizes_between_frames(tmp_path, scenes, flags):
     """main.c:182-187 through render_thread: grow, shrink, grow again on ONE context; every surface the host sees equals
     the oracle's frame of that size (static camera, so the pipelined mode's one-frame lag shows the same picture)."""
@@ -275,6 +270,7 @@ def test_rejected_upload_leaves_the_previous_scene_rendering(torch_cuda, scenes,
 
     def frame():
         t = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
         r.render_into(t.data_ptr(), w, h, camera=cam)
         r.sync()
         return t.cpu().numpy().view(np.uint32)
