@@ -50,6 +50,7 @@ struct hip_renderer {
 	lol_program    program;
 	int         max_steps;      /* MAX_STEPS, naive_renderer.c:49 */
 	int         pipeline;       /* --pipeline: frame i's copy into the surface overlaps frame i+1's kernel (one frame of latency) */
+	int         shown_w, shown_h;/* --pipeline: size of the surface that last received a frame */
 	int         ready;
 	int         have_format;    /* the surface's pixel format has been handed to the library ... */
 	lol_gpu_pixel_format format;/* ... and was this */
@@ -172,11 +173,13 @@ int render_thread(void* ptr) {
 					 * dropped, and this call's frame is delivered at once instead (so is the very first frame). */
 					int pw = 0, ph = 0;
 					lol_gpu_render_host_pending_size(r->gpu, &pw, &ph);
-					const int fresh = pw != width || ph != height;          /* nothing queued, or queued for another size */
-					if (fresh) lol_gpu_render_host_discard(r->gpu);
+					if ((pw || ph) && (pw != width || ph != height))       /* queued for a surface that no longer exists */
+						lol_gpu_render_host_discard(r->gpu);
+					const int first = r->shown_w != width || r->shown_h != height;   /* this surface has not been given a frame yet */
 					st = lol_gpu_render_host_begin(r->gpu, &fc, width, height, r->max_steps);
-					if (st == LOL_GPU_OK && (fresh || lol_gpu_render_host_pending(r->gpu) == 2))
+					if (st == LOL_GPU_OK && (first || lol_gpu_render_host_pending(r->gpu) == 2))
 						st = lol_gpu_render_host_end(r->gpu, surf->pixels, (size_t)surf->pitch, width, height);
+					if (st == LOL_GPU_OK) { r->shown_w = width; r->shown_h = height; }
 				} else {
 					st = lol_gpu_render_host(r->gpu, &fc, width, height, r->max_steps, surf->pixels, (size_t)surf->pitch);
 				}

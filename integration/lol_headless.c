@@ -151,6 +151,7 @@ int main(int argc, const char* argv[]) {
 	FILE* cam_fp = dump_camera ? fopen(dump_camera, "w") : NULL;
 	const char* key_at = keys;
 	double tmin = 1e30, tmax = 0, tsum = 0;
+	double* times = calloc((size_t)(frames + pipeline), sizeof *times);
 	/* with --pipeline the plug-in delivers frame i-1 on round i: one extra round (same camera) brings the last frame in */
 	for (int f = 0; f < frames + pipeline; f++) {
 		if (orbit) orbit_camera(&scene->camera, f < frames ? f : frames - 1, frames);
@@ -182,6 +183,7 @@ int main(int argc, const char* argv[]) {
 		if (dt < tmin) tmin = dt;
 		if (dt > tmax) tmax = dt;
 		tsum += dt;
+		if (times) times[f] = dt;
 		LOG("Frame %d: %.3fms (min: %.3f max: %.3f avg: %.3f) %.1f Mpixels/s", f + 1, dt, tmin, tmax,
 		    tsum / (f + 1), w * (double)h / dt / 1e3);
 		if (dump_frames) {
@@ -214,6 +216,13 @@ int main(int argc, const char* argv[]) {
 	}
 
 	if (cam_fp) fclose(cam_fp);
+	if (times && frames + pipeline >= 8) {               /* steady state: the median is not moved by the first frames' set-up */
+		const int n = frames + pipeline;
+		for (int i = 1; i < n; i++)                      /* insertion sort: a few hundred frames at most */
+			for (int j = i; j > 0 && times[j] < times[j - 1]; j--) { double t = times[j]; times[j] = times[j - 1]; times[j - 1] = t; }
+		LOG("Median: %.3fms %.1f Mpixels/s", times[n / 2], w * (double)h / times[n / 2] / 1e3);
+	}
+	free(times);
 	LOG("Cerrando");
 	atomic_store(&exiting, 1);
 	for (int i = 0; i < threads; i++) sem_post(&entry);
