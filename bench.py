@@ -12,9 +12,9 @@ XRGB8888) rendered from the scene already resident on the device, into a device 
   N > 1   workload "c4": scene4.lol, 7680x4320, rows band-interleaved over the N ranks (one process
           per GPU), each rank renders its bands, then ONE RCCL gather to rank 0 which un-interleaves
           them into the final framebuffer.  Total work is fixed as N grows → "scaling": "strong".
-          The root also receives and un-interleaves the whole frame, so its share of the rows is smaller
-          (loltracer_amd.multi.Partition; LOL_BENCH_ROOT_SHARE = auto | equal | k: `auto` times a few frames
-          of each candidate split during set-up and keeps the fastest).
+          The root also receives and un-interleaves the whole frame, so its bands may be less tall than the
+          others' (loltracer_amd.multi.Partition; LOL_BENCH_ROOT_SHARE = auto | equal | BAND,ROOT_BAND: `auto`
+          times a few frames of each candidate split during set-up and keeps the fastest).
   orbit   256-frame camera orbit of scene4 at 3840x2160, frames striped over ranks, no collective.
   --transport cabi       ONE process drives all N devices through lol_gpu_multi_* (the in-process path the
                          reference's C host calls: band partition + RCCL send/recv group + assembly kernel).
@@ -240,20 +240,36 @@ def host_surface_rates(r, sc, cfg, cams, frames: int = 12):
     return out
 
 
-def root_share_candidates(world: int):
-    """(parts_per_rank, root_parts) splits to try, by LOL_BENCH_ROOT_SHARE: `equal` = one part per rank;
-    `k` = the root takes part in k of LOL_BENCH_PARTS_PER_RANK (default 8) rounds; `auto` (default) = the equal split
-    and a few weighted ones, timed during set-up (main)."""
+def root_share_candidates(world: int, h: int):
+    """(band_rows, root_band_rows) splits to try, by LOL_BENCH_ROOT_SHARE: `equal` = the root like everyone else;
+    `B,R` = bands of B rows, the root's R rows; `auto` (default) = the equal split and a few with a lighter root, timed
+    during set-up (main).  One launch per rank in every case: only the heights of the bands differ."""
     mode = os.environ.get("LOL_BENCH_ROOT_SHARE", "auto")
-    per = max(1, min(int(os.environ.get("LOL_BENCH_PARTS_PER_RANK", "8")), 64 // world))
+    equal = multi.choose_band_rows(h, world) or 4
     if world == 1 or mode == "equal":
-        return [(1, 1)]
+        return [(equal, 0)]
     if mode != "auto":
-        k = int(mode)
-        if not 0 <= k <= per:
-            raise SystemExit(f"LOL_BENCH_ROOT_SHARE={mode}: want auto, equal or 0..{per}")
-        return [(per, k)]
-    return [(1, 1)] + [(per, k) for k in range(per - 1, max(per - 4, 0), -1)]
+        try:
+            b, r = (int(v) for v in mode.split(","))
+        except ValueError:
+            raise SystemExit(f"LOL_BENCH_ROOT_SHARE={mode}: want auto, equal or BAND,ROOT_BAND")
+        return [(b, r)]
+    # the root's share relative to an equal one: 1, then ~15/16 … 3/4; for every ratio the band height (16 / 12 / 8 rows)
+    # whose last, partial cycle leaves the busiest of the OTHER ranks the fewest rows
+    cands = [(equal, 0)]
+    for ratio in (15 / 16, 7 / 8, 13 / 16, 3 / 4):
+        best = None
+        for band in (16, 12, 8):
+            root = max(1, int(ratio * band + 0.5))
+            if root >= band:
+                continue
+            P = multi.Partition(h, world, band, root)
+            key = (max(P.rank_rows[1:]), -band)
+            if best is None or key < best[0]:
+                best = (key, (band, root))
+        if best and best[1] not in cands:
+            cands.append(best[1])
+    return cands
 
 
 def run_cabi(args, record_fd):
@@ -283,18 +299,20 @@ def run_cabi(args, record_fd):
             m.render_into(frames[i % 2].data_ptr(), w, h, max_steps, frame_camera=fc)
         m.sync()
 
-    per_env = os.environ.get("LOL_BENCH_PARTS_PER_DEVICE")
+    per_dev = int(os.environ.get("LOL_BENCH_PARTS_PER_DEVICE", "1"))
+    m.set_parts_per_device(per_dev)
     trials = []
-    cands = root_share_candidates(n) if per_env is None else [(int(per_env), int(per_env))]
+    cands = root_share_candidates(n, h)
     best = cands[0]
     if len(cands) > 1:
-        for per, k in cands:
-            m.set_parts_per_device(per); m.set_root_parts(k)
+        for band, root_band in cands:
+            m.set_band_rows(band); m.set_root_band_rows(root_band)
             run(4)
             t0 = time.perf_counter(); run(12); dt = time.perf_counter() - t0
-            trials.append({"parts_per_device": per, "root_parts": k, "ms_per_frame": round(dt / 12 * 1e3, 4)})
+            trials.append({"band_rows": band, "root_band_rows": root_band or band, "ms_per_frame": round(dt / 12 * 1e3, 4)})
         best = min(zip(cands, trials), key=lambda ct: ct[1]["ms_per_frame"])[0]
-    m.set_parts_per_device(best[0]); m.set_root_parts(best[1])
+    if n > 1:
+        m.set_band_rows(best[0]); m.set_root_band_rows(best[1])
     run({"c2": 400, "c3": 100, "c4": 32}[name])
     run(args.warmup)
     t0 = time.perf_counter()
@@ -319,7 +337,8 @@ def run_cabi(args, record_fd):
         "config": {"workload": f"{name}: tests/golden/scenes/{cfg['scene']}.lol {w}x{h}, {max_steps} march steps, rows in bands "
                                f"over {n} device(s) of ONE process (lol_gpu_multi_*: RCCL send/recv group to device 0 + assembly kernel)",
                    "width": w, "height": h, "max_steps": max_steps, "transport": "cabi",
-                   "parts_per_device": best[0], "root_parts": best[1], "kernel": m.kernel_name()},
+                   "parts_per_device": per_dev, "band_rows": best[0] if n > 1 else h, "root_band_rows": (best[1] or best[0]) if n > 1 else h,
+                   "kernel": m.kernel_name()},
         "root_share_trials": trials or None, "frame_equal_to_single_launch": check,
     }
     os.write(record_fd, (json.dumps(out) + "\n").encode())
@@ -418,7 +437,8 @@ def main():
 
     def assembler(staging, frame, P, stream_handle):
         """the root's un-interleave: the library's uint4 kernel on the assembly stream (lol_gpu_assemble_parts_at)"""
-        gpu.assemble_parts_at(r, staging.data_ptr(), P.part_row0, P.band, w, h, frame.data_ptr(), w * 4, stream_handle)
+        gpu.assemble_parts_at(r, staging.data_ptr(), [gpu.Rows(*g, 0) for g in P.geometry], P.part_row0, w, h,
+                              frame.data_ptr(), w * 4, stream_handle)
 
     if os.environ.get("LOL_BENCH_ASSEMBLE") == "torch":     # A/B: the round-2 torch index copy instead
         assembler = None
@@ -426,8 +446,8 @@ def main():
     kernel_ms = []
     state = {"P": None, "pipe": None}
 
-    def make_pipeline(per_rank, root_parts):
-        P = multi.Partition(h, emulate or world, per_rank, root_parts, args.band_rows)
+    def make_pipeline(band_rows, root_band_rows):
+        P = multi.Partition(h, emulate or world, args.band_rows or band_rows, root_band_rows)
         state["P"] = P
         state["pipe"] = multi.GatherPipeline(w, h, P.band, dev, depth=depth, force_collective=force_pipe, partition=P,
                                              assembler=assembler)
@@ -447,11 +467,9 @@ def main():
             e0.record()
         if P is None:
             r.render_into(dst_tensor.data_ptr(), w, h, max_steps, stream=stream, frame_camera=fc)
-        else:
-            for p in P.parts_of[rank]:               # one launch per part this rank owns, back to back in its buffer
-                if P.rows_of[p]:
-                    r.render_into(dst_tensor.data_ptr() + P.local_row0[p] * w * 4, w, h, max_steps,
-                                  rows=gpu.Rows(P.band, P.n_parts, p), stream=stream, frame_camera=fc)
+        elif P.rank_rows[rank]:                      # ONE launch: this rank's band of every cycle, compactly
+            r.render_into(dst_tensor.data_ptr(), w, h, max_steps, rows=gpu.Rows(*P.geometry[rank], 0), stream=stream,
+                          frame_camera=fc)
         if timed:
             e1.record()
             kernel_ms.append((e0, e1))
@@ -475,14 +493,13 @@ def main():
     # machine, so `auto` measures instead of guessing: a few frames of each candidate, slowest rank's time, keep the best.
     trials = []
     if piped:
-        cands = root_share_candidates(emulate or world)
+        cands = root_share_candidates(emulate or world, h)
         if emulate and len(cands) > 1:
-            cands = cands[:2]                         # one GPU cannot rank the splits: the equal one and the first weighted
-            cands = [cands[1]] if os.environ.get("LOL_BENCH_ROOT_SHARE", "auto") == "auto" else cands[:1]
+            cands = cands[:1]                         # one GPU cannot rank the splits: the equal one unless told otherwise
         best = cands[0]
         if len(cands) > 1:
-            for per, k in cands:
-                make_pipeline(per, k)
+            for band_c, root_c in cands:
+                make_pipeline(band_c, root_c)
                 for i in range(4):
                     step(i, False)
                 fence()
@@ -493,7 +510,7 @@ def main():
                 t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
                 if world > 1:
                     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                trials.append({"parts_per_rank": per, "root_parts": k, "ms_per_frame": round(float(t.item()) / 16 * 1e3, 4)})
+                trials.append({"band_rows": band_c, "root_band_rows": root_c or band_c, "ms_per_frame": round(float(t.item()) / 16 * 1e3, 4)})
                 state["pipe"] = None
             # every rank holds the same all-reduced times, so every rank picks the same split
             best = min(zip(cands, trials), key=lambda ct: ct[1]["ms_per_frame"])[0]
@@ -554,7 +571,6 @@ def main():
     k_ms = [a.elapsed_time(b) for a, b in kernel_ms]
     k_avg = sum(k_ms) / max(len(k_ms), 1)
     px_per_launch = (P.rank_rows[rank] if P is not None else h) * w      # pixels this rank renders per frame
-    launches_per_frame = len([p for p in P.parts_of[rank] if P.rows_of[p]]) if P is not None else 1
     if orbit:
         total_px = cfg["frames"] * w * h              # all ranks together render each frame once
         steps_reported = cfg["frames"]
@@ -574,7 +590,7 @@ def main():
             "scaling": "weak" if orbit else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{name}: tests/golden/scenes/{cfg['scene']}.lol {w}x{h}, {max_steps} march steps"
                                    + (f", {cfg['frames']}-frame orbit striped over ranks" if orbit else
-                                      (f", rows in bands of {band} dealt over {P.n_parts} parts / {P.world} ranks + RCCL gather to rank 0"
+                                      (f", rows in bands of {band} ({P.root_band or band} for rank 0) over {P.world} ranks + RCCL gather to rank 0"
                                        if P is not None else ", one kernel launch per frame")),
                        "width": w, "height": h, "max_steps": max_steps, "band_rows": band,
                        "kernel": r.kernel_name(), "kernel_key": r.kernel_key(), "transport": "dist"},
@@ -593,7 +609,6 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes": px_per_launch * BYTES_PER_PIXEL,
                          "kernel_ms_avg": round(k_avg, 4), "pixels_per_launch": px_per_launch,
-                         "launches_per_frame": launches_per_frame,
                          "bytes_per_pixel": BYTES_PER_PIXEL,
                          "note": "north_star names the HBM-write roofline; the path is FP32-VALU-bound, see `valu`"},
         }

@@ -45,19 +45,20 @@ enum lol_gpu_status {
 /*
  * Which rows of the frame one call renders, and where they land.
  *
- * The frame's rows are cut into bands of `band_rows`; band b belongs to part
- * (b % n_parts).  A call renders the bands of `part` and writes them
- * compactly: local row r = (b / n_parts) * band_rows + (y % band_rows) of the
- * destination holds frame row y.  {band_rows = h, n_parts = 1, part = 0}
- * is the whole frame in place.  This is the multi-GPU row-tile partition
- * (SURVEY.md §8e): every rank renders its part and the parts are gathered.
+ * The frame's rows are cut into cycles of `cycle_rows` rows; inside every cycle a part owns the `band_rows` rows that
+ * start at `offset_rows`.  A call renders the bands of one part and writes them compactly: local row
+ * r = c * band_rows + i of the destination holds frame row c * cycle_rows + offset_rows + i (i < band_rows).
+ * {band_rows = cycle_rows = h, offset_rows = 0} is the whole frame in place.  This is the multi-GPU row-tile partition
+ * (SURVEY.md §8e): every rank renders its part with ONE launch and the parts are gathered.  Equal shares of n parts with
+ * bands of b rows are {b, n * b, part * b}; the parts of one split may also differ in band height — how the root, which
+ * also receives and un-interleaves the whole frame, gets a smaller share (lol_gpu_multi_set_root_band_rows).
  */
 typedef struct lol_gpu_rows {
 	int32_t band_rows;
-	int32_t n_parts;
-	int32_t part;
+	int32_t cycle_rows;
+	int32_t offset_rows;
 	int32_t in_place;   /* 0: the part is stored compactly (above); 1: `dst` is the whole frame and every row of the part
-	                     * lands at its frame position — what a part written straight into a shared surface needs */
+	                     * lands at its frame position — what a part written straight into a shared frame needs */
 } lol_gpu_rows;
 
 /*
@@ -262,9 +263,10 @@ int  lol_gpu_multi_device_count(const lol_gpu_multi* m);
 lol_gpu* lol_gpu_multi_context(lol_gpu_multi* m, int i);
 /* render_prepare: the flattened scene goes to every device (14 KB each; the specialised kernel is compiled once) */
 int  lol_gpu_multi_upload_program(lol_gpu_multi* m, const lol_program* prog);
-/* Band height used for frames of height h over n devices: the largest multiple of the 4-row wave patch <= 16
- * that still gives every device at least four bands, else 4.  lol_gpu_multi_set_band_rows(m, b > 0) overrides. */
-int  lol_gpu_choose_band_rows(int h, int n_devices);
+/* Band height used for frames of height h over n parts: the largest multiple of the 4-row wave patch <= 16
+ * that gives equal parts, else the tallest one that still gives every part at least eight bands, else 4.
+ * lol_gpu_multi_set_band_rows(m, b > 0) overrides. */
+int  lol_gpu_choose_band_rows(int h, int n_parts);
 int  lol_gpu_multi_set_band_rows(lol_gpu_multi* m, int band_rows);
 /* Frame row shown by local row `local_row` of a part (the inverse of the kernel's mapping); -1 if out of range. */
 int  lol_gpu_part_frame_row(int h, const lol_gpu_rows* rows, int local_row);
@@ -284,19 +286,19 @@ int  lol_gpu_multi_render_host(lol_gpu_multi* m, const lol_frame_camera* cam, in
                                void* host_pixels, size_t pitch_bytes);
 int  lol_gpu_multi_set_host_via_root(lol_gpu_multi* m, int enable);
 int  lol_gpu_multi_set_pixel_format(lol_gpu_multi* m, const lol_gpu_pixel_format* fmt);
-/* Parts per device (default 1): the frame's bands are dealt over n_parts parts and the parts over the devices, `parts`
- * rounds of one part per device (lol_gpu_deal_parts).  Finer interleaving of the rows, the unit of the root's smaller
- * share below, and the way a single-GPU machine exercises the multi-part code paths.  n * parts <= 64. */
+/* Parts per device (default 1): the frame is cut into n * parts parts, part p belonging to device p % n, each part one
+ * launch.  Finer interleaving of the rows, and the way a single-GPU machine exercises the multi-part code paths.
+ * n * parts <= 64. */
 int  lol_gpu_multi_set_parts_per_device(lol_gpu_multi* m, int parts);
 /* The cost-weighted split: the root (devices[0]) also receives and un-interleaves the whole frame, so with an equal
- * share it finishes last.  root_parts in [0, parts_per_device] (default = parts_per_device, equal shares) is how many
- * of the rounds the root takes part in: its share of the rows is root_parts / ((n - 1) * parts + root_parts). */
-int  lol_gpu_multi_set_root_parts(lol_gpu_multi* m, int root_parts);
-/* The dealing itself, pure host logic: owner[p] = device index (0 = root) of part p; returns the number of parts
- * (n_devices - 1) * per_dev + root_parts (one device: per_dev), or a negative status.  owner may be NULL. */
-int  lol_gpu_deal_parts(int n_devices, int per_dev, int root_parts, int* owner, int cap);
-/* Band height for such a deal: the multiple of 4 up to 16 that leaves the busiest device the fewest rows. */
-int  lol_gpu_choose_band_rows_for(int h, const int* owner, int n_parts, int n_devices);
+ * share it finishes last.  root_band_rows > 0 makes the bands of the root's parts that tall instead of band_rows
+ * (0 = like the others): its share of the rows is root_band_rows / (root_band_rows + (n - 1) * band_rows).  Still one
+ * launch per part: only the geometry changes (lol_gpu_rows). */
+int  lol_gpu_multi_set_root_band_rows(lol_gpu_multi* m, int root_band_rows);
+/* The geometry itself, pure host logic: out[p] for p in [0, n_parts) = the lol_gpu_rows of part p when every part's
+ * bands are band_rows tall except those of parts p % root_stride == 0, which are root_band_rows tall (0 = band_rows too;
+ * root_stride = number of devices).  The bands tile a cycle in part order. */
+int  lol_gpu_split_rows(int n_parts, int band_rows, int root_band_rows, int root_stride, lol_gpu_rows* out);
 int  lol_gpu_multi_sync(lol_gpu_multi* m);
 /* Memory on the root device (for destinations of lol_gpu_multi_render_device). */
 int  lol_gpu_multi_malloc(lol_gpu_multi* m, size_t bytes, void** out);
@@ -310,10 +312,11 @@ int  lol_gpu_multi_memcpy_d2h(lol_gpu_multi* m, void* host, const void* dev, siz
  */
 int  lol_gpu_assemble_parts(lol_gpu* ctx, const void* parts, int n_parts, int band_rows, int w, int h,
                             void* dst, size_t pitch_bytes, void* stream);
-/* The same for parts that do not lie back to back in part order (gathered per rank, padded to a common size, several
- * parts per rank): part_row0[p] = the row of `parts` (w pixels per row) where part p starts. */
-int  lol_gpu_assemble_parts_at(lol_gpu* ctx, const void* parts, const uint32_t* part_row0, int n_parts, int band_rows,
-                               int w, int h, void* dst, size_t pitch_bytes, void* stream);
+/* The same for any split and any placement (parts gathered per rank and padded to a common size, bands of different
+ * heights): part_rows[p] = the geometry of part p (the bands of all parts must tile one cycle, in order),
+ * part_row0[p] = the row of `parts` (w pixels per row) where part p's compact copy starts. */
+int  lol_gpu_assemble_parts_at(lol_gpu* ctx, const void* parts, const lol_gpu_rows* part_rows, const uint32_t* part_row0,
+                               int n_parts, int w, int h, void* dst, size_t pitch_bytes, void* stream);
 
 #ifdef __cplusplus
 }

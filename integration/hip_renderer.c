@@ -16,7 +16,7 @@
  *                   --devices A,B,... (the frame's rows are dealt in bands over
  *                   these GPUs, each writing its bands into the surface,
  *                   include/lol_gpu.h lol_gpu_multi_*), --parts-per-device N,
- *                   --root-parts N (the first device's smaller share),
+ *                   --root-band-rows N (the first device's smaller share),
  *                   --max-steps N, and
  *                   --dump-kernel BASE, the counterpart of the JIT renderer's
  *                   -j/--jitdump (tracing_jit_renderer.dasc:424-433): writes the
@@ -77,7 +77,7 @@ void render_prepare(struct render_data* data, int argc, const char* argv[]) {
 	struct hip_renderer* r = calloc(1, sizeof *r);
 	int device = 0;
 	int devices[LOL_GPU_MULTI_MAX_DEVICES], n_devices = 0;
-	int parts_per_device = 0, root_parts = -1;
+	int parts_per_device = 0, root_band = -1;
 	const char* dump = NULL;
 	HOST_PRIVATE(data) = r;
 	if (!r) { fprintf(stderr, "hip_renderer: out of memory\n"); return; }
@@ -85,7 +85,7 @@ void render_prepare(struct render_data* data, int argc, const char* argv[]) {
 	for (int i = 3; i < argc; i++) {
 		const int is_device = !strcmp(argv[i], "--device"), is_devices = !strcmp(argv[i], "--devices");
 		const int is_steps = !strcmp(argv[i], "--max-steps"), is_dump = !strcmp(argv[i], "--dump-kernel");
-		const int is_ppd = !strcmp(argv[i], "--parts-per-device"), is_root = !strcmp(argv[i], "--root-parts");
+		const int is_ppd = !strcmp(argv[i], "--parts-per-device"), is_root = !strcmp(argv[i], "--root-band-rows");
 		if (!strcmp(argv[i], "--pipeline")) { r->pipeline = 1; continue; }
 		if (!(is_device || is_devices || is_steps || is_dump || is_ppd || is_root)) continue;      /* the host's own flags */
 		if (i + 1 >= argc) { fprintf(stderr, "hip_renderer: %s needs a value, ignored\n", argv[i]); break; }
@@ -94,7 +94,7 @@ void render_prepare(struct render_data* data, int argc, const char* argv[]) {
 		else if (is_steps) r->max_steps = atoi(v);
 		else if (is_dump) dump = v;
 		else if (is_ppd) parts_per_device = atoi(v);
-		else if (is_root) root_parts = atoi(v);
+		else if (is_root) root_band = atoi(v);
 		else {
 			n_devices = 0;
 			for (const char* p = v; *p && n_devices < LOL_GPU_MULTI_MAX_DEVICES;) {
@@ -127,8 +127,8 @@ void render_prepare(struct render_data* data, int argc, const char* argv[]) {
 		if (st != LOL_GPU_OK) { fprintf(stderr, "hip_renderer: cannot set up %d device(s) (status %d)\n", n_devices, st); return; }
 		if (parts_per_device > 0 && lol_gpu_multi_set_parts_per_device(r->multi, parts_per_device) != LOL_GPU_OK)
 			fprintf(stderr, "hip_renderer: --parts-per-device %d refused\n", parts_per_device);
-		if (root_parts >= 0 && lol_gpu_multi_set_root_parts(r->multi, root_parts) != LOL_GPU_OK)
-			fprintf(stderr, "hip_renderer: --root-parts %d refused\n", root_parts);
+		if (root_band >= 0 && lol_gpu_multi_set_root_band_rows(r->multi, root_band) != LOL_GPU_OK)
+			fprintf(stderr, "hip_renderer: --root-band-rows %d refused\n", root_band);
 		st = lol_gpu_multi_upload_program(r->multi, &r->program);
 		if (st != LOL_GPU_OK) { fprintf(stderr, "hip_renderer: %s\n", lol_gpu_multi_error(r->multi)); return; }
 	} else {

@@ -1315,11 +1315,12 @@ int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog) {
 int lol_gpu_part_rows(int h, const lol_gpu_rows* rows) {
 	if (h <= 0) return 0;
 	if (!rows) return h;
-	if (rows->band_rows <= 0 || rows->n_parts <= 0 || rows->part < 0 || rows->part >= rows->n_parts) return -1;
-	long bands = ((long)h + rows->band_rows - 1) / rows->band_rows;
+	if (rows->band_rows <= 0 || rows->cycle_rows < rows->band_rows || rows->offset_rows < 0 ||
+	    rows->offset_rows > rows->cycle_rows - rows->band_rows)
+		return -1;
 	long n = 0;
-	for (long b = rows->part; b < bands; b += rows->n_parts) {
-		long y0 = b * rows->band_rows, y1 = y0 + rows->band_rows;
+	for (long y0 = rows->offset_rows; y0 < h; y0 += rows->cycle_rows) {
+		long y1 = y0 + rows->band_rows;
 		if (y1 > h) y1 = h;
 		n += y1 - y0;
 	}
@@ -1333,13 +1334,13 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	if (!ctx->have_prog) return fail(ctx, LOL_GPU_ERR_NO_PROGRAM, "no scene program uploaded");
 	if (w <= 0 || h <= 0 || max_steps < 0 || pitch_bytes % 4 || pitch_bytes < (size_t)w * 4)
 		return fail(ctx, LOL_GPU_ERR_ARG, "bad frame geometry");
-	lol_gpu_rows whole = { h, 1, 0 };
+	lol_gpu_rows whole = { h, h, 0, 0 };
 	const lol_gpu_rows* R = rows ? rows : &whole;
 	int n_rows = lol_gpu_part_rows(h, R);
 	if (n_rows < 0) return fail(ctx, LOL_GPU_ERR_ARG, "bad row partition");
 	if (n_rows == 0) return LOL_GPU_OK;
-	/* h need not be a multiple of band_rows: the one partial band is the frame's last, hence also the last of
-	 * the part that owns it, so every part's local rows stay dense (lol_gpu_part_frame_row is the mapping) */
+	/* h need not be a multiple of cycle_rows: a part's band in the last, partial cycle is cut or absent, and it is the
+	 * part's last, so every part's local rows stay dense (lol_gpu_part_frame_row is the mapping) */
 
 	lol::Launch L;
 	memset(&L, 0, sizeof L);
@@ -1347,7 +1348,7 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	L.fw = (float)w; L.fh = (float)h;
 	L.w = w; L.h = h; L.max_steps = max_steps;
 	L.n_rows = n_rows;
-	L.band_rows = R->band_rows; L.n_parts = R->n_parts; L.part = R->part;
+	L.band_rows = R->band_rows; L.cycle_rows = R->cycle_rows; L.offset_rows = R->offset_rows;
 	const lol_program& P = ctx->h_prog;
 	L.n_ops = ctx->n_mops; L.n_lights = P.n_lights; L.n_materials = P.n_materials; L.n_roots = P.n_roots;
 	const char* base = reinterpret_cast<const char*>(ctx->d_prog[ctx->cur]);
@@ -1377,7 +1378,7 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	g_roctx.init();
 	if (g_roctx.push) {
 		char label[96];
-		snprintf(label, sizeof label, "lol frame %dx%d rows=%d part=%d/%d %s", w, h, n_rows, R->part, R->n_parts, ctx->kernel_name);
+		snprintf(label, sizeof label, "lol frame %dx%d rows=%d band=%d@%d/%d %s", w, h, n_rows, R->band_rows, R->offset_rows, R->cycle_rows, ctx->kernel_name);
 		g_roctx.push(label);
 	}
 	if (ctx->spec_fn) {

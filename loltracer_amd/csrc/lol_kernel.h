@@ -78,7 +78,7 @@ struct Launch {
 	i32    w, h;
 	i32    max_steps;
 	i32    n_rows;               /* local rows this launch renders */
-	i32    band_rows, n_parts, part;
+	i32    band_rows, cycle_rows, offset_rows;   /* lol_gpu_rows: local row r is frame row (r / band_rows) * cycle_rows + offset_rows + r % band_rows */
 	u32    n_ops, n_lights, n_materials, n_roots;   /* n_ops: macro-ops in `ops` (interpreter kernel only) */
 	const u32* ops;              /* device copies of the flattened scene's tables (ops: the macro-op list) */
 	const u32* lights;
@@ -705,7 +705,7 @@ struct Pixel { u32 px; V3 rgb; Hit hit; u32 shadow_steps; };
 /* frame row of local row r of this launch's part (the inverse: lol_gpu_part_frame_row) */
 __device__ __forceinline__ int frame_row(const Launch& L, int r) {
 	const int band = r / L.band_rows;
-	return (band * L.n_parts + L.part) * L.band_rows + (r - band * L.band_rows);
+	return band * L.cycle_rows + L.offset_rows + (r - band * L.band_rows);
 }
 
 /*

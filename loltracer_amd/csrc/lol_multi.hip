@@ -22,11 +22,13 @@
  * that the links run at once) instead of funnelling 4 B per pixel through the root's single link (132 MB = 2.4 ms for a
  * C4 frame).  The surface is the host's memory and is never registered with the devices (lol_gpu.hip, lol_gpu_render_host).
  *
- * Parts and their owners.  A frame's bands are dealt round-robin over n_parts PARTS, and the parts round-robin over
- * the devices: parts_per_device rounds, every device taking one part per round — except that the root sits out the
- * last (parts_per_device - root_parts) rounds (lol_gpu_deal_parts).  The root also receives, and un-interleaves, the
- * whole frame, so an equal share makes it the straggler; owning fewer parts is the cost-weighted split.  Several parts
- * per device are also how a single-GPU box exercises every multi-part code path — tests/test_multi_device.py.
+ * Parts.  The frame's rows are cut into cycles; inside a cycle every part owns one band (lol_gpu_rows: band_rows rows at
+ * offset_rows of every cycle_rows), and a part is ONE launch — measured on MI355X, a device that rendered its share as
+ * eight small launches took 2.7 times as long as with one (every launch ends in its own tail of half-empty SIMDs).  The
+ * parts' bands need not be equally tall: the root also receives and un-interleaves the whole frame, so with an equal
+ * share it finishes last; lol_gpu_multi_set_root_band_rows gives its bands fewer rows — the cost-weighted split.
+ * parts_per_device > 1 (part p belongs to device p % n) exists for finer interleaving experiments and so that a
+ * single-GPU box exercises every multi-part code path — tests/test_multi_device.py.
  */
 #include "lol_gpu.h"
 
@@ -137,17 +139,23 @@ struct Device {
 
 constexpr int MAX_PARTS = 64;      /* devices x parts_per_device */
 
-/* Offsets (in rows) of the parts inside the staging buffer, by value in the kernel arguments. */
-struct PartTable { uint32_t row0[MAX_PARTS]; };
+/* The parts of one frame, by value in the kernel arguments: where each part's band sits inside a cycle, and the row of
+ * the source buffer (w pixels per row) where the part's compact copy starts. */
+struct PartTable {
+	uint32_t row0[MAX_PARTS];
+	uint16_t band[MAX_PARTS], offset[MAX_PARTS];
+	int32_t  n_parts, cycle;
+};
 
 /* dst row y ← the row of the part that rendered it.  One thread per 4 pixels (uint4) when VEC, else per pixel. */
 template <bool VEC>
-__global__ __launch_bounds__(256) void assemble_kernel(const uint32_t* __restrict__ parts, PartTable tab, int n_parts,
-                                                        int band_rows, int w, int h, uint32_t* __restrict__ dst,
-                                                        uint32_t pitch_px) {
+__global__ __launch_bounds__(256) void assemble_kernel(const uint32_t* __restrict__ parts, PartTable tab, int w, int h,
+                                                        uint32_t* __restrict__ dst, uint32_t pitch_px) {
 	const int y = blockIdx.y;
-	const int band = y / band_rows, part = band % n_parts;
-	const int local = (band / n_parts) * band_rows + (y - band * band_rows);
+	const int c = y / tab.cycle, o = y - c * tab.cycle;
+	int part = 0;
+	for (int p = 1; p < tab.n_parts; p++) part = o >= (int)tab.offset[p] ? p : part;      /* offsets ascend: the last one not above o */
+	const int local = c * (int)tab.band[part] + (o - (int)tab.offset[part]);
 	const uint32_t* src = parts + ((size_t)tab.row0[part] + local) * w;
 	uint32_t* out = dst + (size_t)y * pitch_px;
 	const int i = blockIdx.x * 256 + threadIdx.x;
@@ -158,51 +166,32 @@ __global__ __launch_bounds__(256) void assemble_kernel(const uint32_t* __restric
 	}
 }
 
-hipError_t launch_assemble(const void* parts, const PartTable& tab, int n_parts, int band_rows, int w, int h, void* dst,
-                           size_t pitch_bytes, hipStream_t s) {
+hipError_t launch_assemble(const void* parts, const PartTable& tab, int w, int h, void* dst, size_t pitch_bytes, hipStream_t s) {
 	const bool vec = w % 4 == 0 && pitch_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(parts) % 16) == 0 &&
 	                 (reinterpret_cast<uintptr_t>(dst) % 16) == 0;
 	const int per_row = vec ? w / 4 : w;
 	dim3 grid((per_row + 255) / 256, h);
-	if (vec) hipLaunchKernelGGL(assemble_kernel<true>, grid, dim3(256), 0, s, static_cast<const uint32_t*>(parts), tab, n_parts,
-	                            band_rows, w, h, static_cast<uint32_t*>(dst), (uint32_t)(pitch_bytes / 4));
-	else     hipLaunchKernelGGL(assemble_kernel<false>, grid, dim3(256), 0, s, static_cast<const uint32_t*>(parts), tab, n_parts,
-	                            band_rows, w, h, static_cast<uint32_t*>(dst), (uint32_t)(pitch_bytes / 4));
+	if (vec) hipLaunchKernelGGL(assemble_kernel<true>, grid, dim3(256), 0, s, static_cast<const uint32_t*>(parts), tab, w, h,
+	                            static_cast<uint32_t*>(dst), (uint32_t)(pitch_bytes / 4));
+	else     hipLaunchKernelGGL(assemble_kernel<false>, grid, dim3(256), 0, s, static_cast<const uint32_t*>(parts), tab, w, h,
+	                            static_cast<uint32_t*>(dst), (uint32_t)(pitch_bytes / 4));
 	return hipGetLastError();
 }
 
-/* parts stored back to back in part order (lol_gpu_assemble_parts) */
-bool fill_table(PartTable& tab, int n_parts, int band_rows, int h) {
-	uint32_t row = 0;
-	for (int r = 0; r < n_parts; r++) {
-		lol_gpu_rows R = { band_rows, n_parts, r };
-		int n = lol_gpu_part_rows(h, &R);
-		if (n < 0) return false;
-		tab.row0[r] = row;
-		row += (uint32_t)n;
+/* A valid split: the parts' bands tile one cycle exactly, in order.  Fills band / offset / cycle of the table. */
+bool table_from_rows(PartTable& tab, const lol_gpu_rows* rows, int n_parts) {
+	if (!rows || n_parts < 1 || n_parts > MAX_PARTS) return false;
+	int at = 0;
+	for (int p = 0; p < n_parts; p++) {
+		if (rows[p].band_rows < 1 || rows[p].band_rows > 0xFFFF || rows[p].offset_rows != at || rows[p].cycle_rows != rows[0].cycle_rows) return false;
+		tab.band[p] = (uint16_t)rows[p].band_rows;
+		tab.offset[p] = (uint16_t)at;
+		at += rows[p].band_rows;
 	}
-	return row == (uint32_t)h;
-}
-
-/* parts stored device by device (a device's parts back to back, in part order): the layout of the per-device buffers
- * and, concatenated in device order, of the root's staging buffer.  dev_row0[d] = first staging row of device d,
- * dev_rows[d] = rows device d owns, tab.row0[part] = staging row where that part starts. */
-bool fill_device_major(PartTable& tab, uint32_t* dev_row0, uint32_t* dev_rows, const int* owner, int n_parts, int n_dev,
-                       int band_rows, int h) {
-	uint32_t row = 0;
-	for (int d = 0; d < n_dev; d++) {
-		dev_row0[d] = row;
-		for (int part = 0; part < n_parts; part++) {
-			if (owner[part] != d) continue;
-			lol_gpu_rows R = { band_rows, n_parts, part };
-			int n = lol_gpu_part_rows(h, &R);
-			if (n < 0) return false;
-			tab.row0[part] = row;
-			row += (uint32_t)n;
-		}
-		dev_rows[d] = row - dev_row0[d];
-	}
-	return row == (uint32_t)h;
+	if (at != rows[0].cycle_rows || at > 0xFFFF) return false;
+	tab.n_parts = n_parts;
+	tab.cycle = at;
+	return true;
 }
 
 }  // namespace
@@ -212,13 +201,11 @@ struct lol_gpu_multi {
 	Device    dev[LOL_GPU_MULTI_MAX_DEVICES];
 	Rccl      rccl;
 	bool      comms_up = false;
-	int       band_override = 0;
-	int       per_dev = 1;                             /* parts per device */
-	int       root_parts = 1;                          /* parts of the root (<= per_dev): its smaller share */
-	int       n_parts = 1;
-	int       owner[MAX_PARTS] = { 0 };                /* device index of every part (lol_gpu_deal_parts) */
+	int       band_override = 0;                       /* band height of every part (0 = chosen per frame height) */
+	int       root_band = 0;                           /* band height of the root's parts (0 = like the others) */
+	int       per_dev = 1;                             /* parts per device: part p belongs to device p % n */
 	int       host_via_root = 0;                       /* render_host: assemble on the root first (RCCL) instead of direct copies */
-	uint32_t* staging[SLOTS] = { nullptr, nullptr };   /* root: every part of a frame, back to back */
+	uint32_t* staging[SLOTS] = { nullptr, nullptr };   /* root: every part of a frame, device by device */
 	size_t    staging_bytes = 0;
 	hipEvent_t done[SLOTS] = { nullptr, nullptr };     /* root: frame of this slot assembled (staging free again) */
 	uint32_t* d_frame = nullptr;                       /* root: framebuffer of the host-surface path when host_via_root */
@@ -284,86 +271,46 @@ int ensure_buffers(lol_gpu_multi* m, int w, int h, const uint32_t* dev_rows, boo
 
 extern "C" {
 
-int lol_gpu_choose_band_rows(int h, int n_devices) {
-	if (h <= 0 || n_devices <= 0) return 0;
-	if (n_devices == 1) return h;
+int lol_gpu_choose_band_rows(int h, int n_parts) {
+	if (h <= 0 || n_parts <= 0) return 0;
+	if (n_parts == 1) return h;
 	/* equal parts first (multiples of the kernel's 4-row wave patch, so no wave straddles two bands) ... */
 	for (int band = 16; band >= 4; band -= 4)
-		if (h % (band * n_devices) == 0) return band;
-	/* ... else the tallest band that still deals every device at least eight bands (parts then differ by one band) */
+		if (h % (band * n_parts) == 0) return band;
+	/* ... else the tallest band that still deals every part at least eight bands (parts then differ by one band) */
 	for (int band = 16; band >= 4; band -= 4)
-		if (h / band >= 8 * n_devices) return band;
+		if (h / band >= 8 * n_parts) return band;
 	return 4;
+}
+
+int lol_gpu_split_rows(int n_parts, int band_rows, int root_band_rows, int root_stride, lol_gpu_rows* out) {
+	if (n_parts < 1 || n_parts > MAX_PARTS || band_rows < 1 || root_band_rows < 0 || root_stride < 1 || !out) return LOL_GPU_ERR_ARG;
+	if (n_parts == 1) { out[0] = { band_rows, band_rows, 0, 0 }; return LOL_GPU_OK; }
+	int at = 0;
+	for (int p = 0; p < n_parts; p++) {
+		const int b = (root_band_rows > 0 && p % root_stride == 0) ? root_band_rows : band_rows;
+		out[p] = { b, 0, at, 0 };
+		at += b;
+	}
+	if (at > 0xFFFF) return LOL_GPU_ERR_ARG;
+	for (int p = 0; p < n_parts; p++) out[p].cycle_rows = at;
+	return LOL_GPU_OK;
 }
 
 int lol_gpu_part_frame_row(int h, const lol_gpu_rows* rows, int local_row) {
 	if (!rows) return local_row >= 0 && local_row < h ? local_row : -1;
 	if (local_row < 0 || local_row >= lol_gpu_part_rows(h, rows)) return -1;
 	const int band = local_row / rows->band_rows;
-	return (band * rows->n_parts + rows->part) * rows->band_rows + (local_row - band * rows->band_rows);
+	return band * rows->cycle_rows + rows->offset_rows + (local_row - band * rows->band_rows);
 }
 
-int lol_gpu_deal_parts(int n_devices, int per_dev, int root_parts, int* owner, int cap) {
-	if (n_devices < 1 || per_dev < 1 || root_parts < 0 || root_parts > per_dev) return LOL_GPU_ERR_ARG;
-	if (n_devices == 1) root_parts = per_dev;             /* the only device owns everything */
-	const int n_parts = (n_devices - 1) * per_dev + root_parts;
-	if (n_parts < 1 || n_parts > MAX_PARTS || (owner && cap < n_parts)) return LOL_GPU_ERR_ARG;
-	int p = 0;
-	for (int round = 0; round < per_dev; round++)
-		for (int d = 0; d < n_devices; d++) {
-			if (d == 0 && round >= root_parts) continue;      /* the root sits out the last rounds */
-			if (owner) owner[p] = d;
-			p++;
-		}
-	return n_parts;
-}
-
-int lol_gpu_choose_band_rows_for(int h, const int* owner, int n_parts, int n_devices) {
-	if (h <= 0 || !owner || n_parts < 1 || n_parts > MAX_PARTS || n_devices < 1) return 0;
-	if (n_parts == 1) return h;
-	/* the cost of a frame is its busiest device: fewest rows there wins, the taller band on ties (bands are multiples
-	 * of the kernel's 4-row wave patch, so no wave straddles two bands) */
-	int best = 0;
-	long best_rows = -1;
-	for (int band = 16; band >= 4; band -= 4) {
-		long rows[LOL_GPU_MULTI_MAX_DEVICES] = { 0 };
-		for (int part = 0; part < n_parts; part++) {
-			lol_gpu_rows R = { band, n_parts, part };
-			if (owner[part] < 0 || owner[part] >= n_devices || owner[part] >= LOL_GPU_MULTI_MAX_DEVICES) return 0;
-			rows[owner[part]] += lol_gpu_part_rows(h, &R);
-		}
-		long mx = 0;
-		for (int d = 0; d < n_devices; d++) if (rows[d] > mx) mx = rows[d];
-		if (best_rows < 0 || mx < best_rows) { best_rows = mx; best = band; }
-	}
-	return best;
-}
-
-static int assemble_with(lol_gpu* ctx, const void* parts, const PartTable& tab, int n_parts, int band_rows, int w, int h,
-                         void* dst, size_t pitch_bytes, void* stream);
-
-int lol_gpu_assemble_parts_at(lol_gpu* ctx, const void* parts, const uint32_t* part_row0, int n_parts, int band_rows,
-                              int w, int h, void* dst, size_t pitch_bytes, void* stream) {
-	if (!part_row0 || n_parts < 1 || n_parts > MAX_PARTS) return LOL_GPU_ERR_ARG;
+int lol_gpu_assemble_parts_at(lol_gpu* ctx, const void* parts, const lol_gpu_rows* part_rows, const uint32_t* part_row0,
+                              int n_parts, int w, int h, void* dst, size_t pitch_bytes, void* stream) {
+	if (!ctx || !parts || !dst || !part_row0) return LOL_GPU_ERR_ARG;
+	if (w < 1 || h < 1 || pitch_bytes % 4 || pitch_bytes < (size_t)w * 4) return LOL_GPU_ERR_ARG;
 	PartTable tab;
-	for (int r = 0; r < n_parts; r++) tab.row0[r] = part_row0[r];
-	return assemble_with(ctx, parts, tab, n_parts, band_rows, w, h, dst, pitch_bytes, stream);
-}
-
-int lol_gpu_assemble_parts(lol_gpu* ctx, const void* parts, int n_parts, int band_rows, int w, int h,
-                           void* dst, size_t pitch_bytes, void* stream) {
-	if (n_parts < 1 || n_parts > MAX_PARTS || band_rows < 1 || h < 1) return LOL_GPU_ERR_ARG;
-	PartTable tab;
-	if (!fill_table(tab, n_parts, band_rows, h)) return LOL_GPU_ERR_ARG;
-	return assemble_with(ctx, parts, tab, n_parts, band_rows, w, h, dst, pitch_bytes, stream);
-}
-
-static int assemble_with(lol_gpu* ctx, const void* parts, const PartTable& tab, int n_parts, int band_rows, int w, int h,
-                         void* dst, size_t pitch_bytes, void* stream) {
-	if (!ctx || !parts || !dst) return LOL_GPU_ERR_ARG;
-	if (n_parts < 1 || n_parts > MAX_PARTS || band_rows < 1 || w < 1 || h < 1 ||
-	    pitch_bytes % 4 || pitch_bytes < (size_t)w * 4)
-		return LOL_GPU_ERR_ARG;
+	if (!table_from_rows(tab, part_rows, n_parts)) return LOL_GPU_ERR_ARG;
+	for (int p = 0; p < n_parts; p++) tab.row0[p] = part_row0[p];
 	if (hipSetDevice(lol_gpu_device(ctx)) != hipSuccess) return LOL_GPU_ERR_HIP;
 	hipStream_t s = static_cast<hipStream_t>(stream);
 	if (!s) {
@@ -372,7 +319,21 @@ static int assemble_with(lol_gpu* ctx, const void* parts, const PartTable& tab, 
 		if (st != LOL_GPU_OK) return st;
 		s = hipStreamLegacy;
 	}
-	return launch_assemble(parts, tab, n_parts, band_rows, w, h, dst, pitch_bytes, s) == hipSuccess ? LOL_GPU_OK : LOL_GPU_ERR_HIP;
+	return launch_assemble(parts, tab, w, h, dst, pitch_bytes, s) == hipSuccess ? LOL_GPU_OK : LOL_GPU_ERR_HIP;
+}
+
+int lol_gpu_assemble_parts(lol_gpu* ctx, const void* parts, int n_parts, int band_rows, int w, int h,
+                           void* dst, size_t pitch_bytes, void* stream) {
+	if (n_parts < 1 || n_parts > MAX_PARTS || band_rows < 1 || h < 1) return LOL_GPU_ERR_ARG;
+	lol_gpu_rows rows[MAX_PARTS];
+	uint32_t row0[MAX_PARTS];
+	if (lol_gpu_split_rows(n_parts, band_rows, 0, 1, rows) != LOL_GPU_OK) return LOL_GPU_ERR_ARG;
+	uint32_t row = 0;
+	for (int p = 0; p < n_parts; p++) {               /* parts back to back, in part order */
+		row0[p] = row;
+		row += (uint32_t)lol_gpu_part_rows(h, &rows[p]);
+	}
+	return lol_gpu_assemble_parts_at(ctx, parts, rows, row0, n_parts, w, h, dst, pitch_bytes, stream);
 }
 
 int lol_gpu_multi_create(const int* devices, int n, lol_gpu_multi** out) {
@@ -413,7 +374,6 @@ int lol_gpu_multi_create(const int* devices, int n, lol_gpu_multi** out) {
 		if (e != hipSuccess) return bail("event setup", hipGetErrorString(e));
 	}
 	if (const char* e = getenv("LOL_GPU_MULTI_HOST_VIA_ROOT")) m->host_via_root = e[0] == '1';
-	m->n_parts = lol_gpu_deal_parts(n, m->per_dev, m->root_parts, m->owner, MAX_PARTS);
 	*out = m;
 	return LOL_GPU_OK;
 }
@@ -460,8 +420,16 @@ int lol_gpu_multi_device_count(const lol_gpu_multi* m) { return m ? m->n : 0; }
 lol_gpu* lol_gpu_multi_context(lol_gpu_multi* m, int i) { return m && i >= 0 && i < m->n ? m->dev[i].ctx : nullptr; }
 
 int lol_gpu_multi_set_band_rows(lol_gpu_multi* m, int band_rows) {
-	if (!m || band_rows < 0) return LOL_GPU_ERR_ARG;
+	if (!m || band_rows < 0 || band_rows > 4096) return LOL_GPU_ERR_ARG;
 	m->band_override = band_rows;
+	return LOL_GPU_OK;
+}
+
+int lol_gpu_multi_set_root_band_rows(lol_gpu_multi* m, int root_band_rows) {
+	if (!m || root_band_rows < 0 || root_band_rows > 4096) return LOL_GPU_ERR_ARG;
+	int st = lol_gpu_multi_sync(m);
+	if (st != LOL_GPU_OK) return st;
+	m->root_band = root_band_rows;
 	return LOL_GPU_OK;
 }
 
@@ -481,17 +449,12 @@ int lol_gpu_multi_set_parts_per_device(lol_gpu_multi* m, int parts) {
 	int st = lol_gpu_multi_sync(m);
 	if (st != LOL_GPU_OK) return st;
 	m->per_dev = parts;
-	m->root_parts = parts;                                 /* equal shares until lol_gpu_multi_set_root_parts says otherwise */
-	m->n_parts = lol_gpu_deal_parts(m->n, m->per_dev, m->root_parts, m->owner, MAX_PARTS);
 	return LOL_GPU_OK;
 }
 
-int lol_gpu_multi_set_root_parts(lol_gpu_multi* m, int root_parts) {
-	if (!m || root_parts < 0 || root_parts > m->per_dev || (m->n == 1 && root_parts != m->per_dev)) return LOL_GPU_ERR_ARG;
-	int st = lol_gpu_multi_sync(m);
-	if (st != LOL_GPU_OK) return st;
-	m->root_parts = root_parts;
-	m->n_parts = lol_gpu_deal_parts(m->n, m->per_dev, m->root_parts, m->owner, MAX_PARTS);
+int lol_gpu_multi_set_host_via_root(lol_gpu_multi* m, int enable) {
+	if (!m) return LOL_GPU_ERR_ARG;
+	m->host_via_root = enable ? 1 : 0;
 	return LOL_GPU_OK;
 }
 
@@ -501,12 +464,6 @@ int lol_gpu_multi_set_pixel_format(lol_gpu_multi* m, const lol_gpu_pixel_format*
 		int st = lol_gpu_set_pixel_format(m->dev[i].ctx, fmt);
 		if (st != LOL_GPU_OK) return mfail(m, st, "lol_gpu_set_pixel_format", lol_gpu_error(m->dev[i].ctx));
 	}
-	return LOL_GPU_OK;
-}
-
-int lol_gpu_multi_set_host_via_root(lol_gpu_multi* m, int enable) {
-	if (!m) return LOL_GPU_ERR_ARG;
-	m->host_via_root = enable ? 1 : 0;
 	return LOL_GPU_OK;
 }
 
@@ -523,33 +480,48 @@ static int ensure_comms(lol_gpu_multi* m) {
 	return LOL_GPU_OK;
 }
 
-/* the partition of a frame of height h: band height, part table (device-major), rows per device */
-struct Split { int band; PartTable tab; uint32_t dev_row0[LOL_GPU_MULTI_MAX_DEVICES], dev_rows[LOL_GPU_MULTI_MAX_DEVICES]; };
+/* the partition of a frame of height h: one lol_gpu_rows per part (part p belongs to device p % n), the part table with
+ * the parts stored device by device (a device's parts back to back, in part order: the layout of the per-device buffers
+ * and, concatenated in device order, of the root's staging buffer), rows per device */
+struct Split {
+	int n_parts;
+	lol_gpu_rows rows[MAX_PARTS];
+	PartTable tab;
+	uint32_t dev_row0[LOL_GPU_MULTI_MAX_DEVICES], dev_rows[LOL_GPU_MULTI_MAX_DEVICES];
+};
 
 static int split_frame(lol_gpu_multi* m, int h, Split& S) {
-	const bool equal = m->root_parts == m->per_dev;
-	S.band = m->band_override > 0 ? m->band_override
-	       : equal ? lol_gpu_choose_band_rows(h, m->n_parts) : lol_gpu_choose_band_rows_for(h, m->owner, m->n_parts, m->n);
-	if (S.band <= 0 || !fill_device_major(S.tab, S.dev_row0, S.dev_rows, m->owner, m->n_parts, m->n, S.band, h))
+	S.n_parts = m->n * m->per_dev;
+	const int band = m->band_override > 0 ? m->band_override : lol_gpu_choose_band_rows(h, S.n_parts);
+	/* the root's lighter bands only when there is someone else to take the rest */
+	const int root_band = m->n > 1 ? m->root_band : 0;
+	if (lol_gpu_split_rows(S.n_parts, band, root_band, m->n, S.rows) != LOL_GPU_OK || !table_from_rows(S.tab, S.rows, S.n_parts))
 		return mfail(m, LOL_GPU_ERR_ARG, "bad row partition");
+	uint32_t row = 0;
+	for (int d = 0; d < m->n; d++) {
+		S.dev_row0[d] = row;
+		for (int p = d; p < S.n_parts; p += m->n) {
+			const int k = lol_gpu_part_rows(h, &S.rows[p]);
+			if (k < 0) return mfail(m, LOL_GPU_ERR_ARG, "bad row partition");
+			S.tab.row0[p] = row;
+			row += (uint32_t)k;
+		}
+		S.dev_rows[d] = row - S.dev_row0[d];
+	}
+	if (row != (uint32_t)h) return mfail(m, LOL_GPU_ERR_ARG, "bad row partition");
 	return LOL_GPU_OK;
 }
 
 /* queue the kernels of one frame: device d renders its parts back to back into part[slot] on its render stream */
-/* `surface` != nullptr: the kernels store straight into that whole-frame surface (device d's view of it: surface[d]),
- * every row at its frame position, instead of into the compact part buffers */
-static int render_parts(lol_gpu_multi* m, const lol_frame_camera* cam, int w, int h, int max_steps, const Split& S, int slot,
-                        void* const* surface = nullptr, size_t surface_pitch = 0) {
+static int render_parts(lol_gpu_multi* m, const lol_frame_camera* cam, int w, int h, int max_steps, const Split& S, int slot) {
 	for (int d = 0; d < m->n; d++) {
 		Device& D = m->dev[d];
 		M_HIP(m, hipSetDevice(D.id));
 		M_HIP(m, hipStreamWaitEvent(D.render, D.sent[slot], 0));      /* the frame two back has left part[slot] */
-		for (int part = 0; part < m->n_parts; part++) {
-			if (m->owner[part] != d) continue;
-			lol_gpu_rows R = { S.band, m->n_parts, part, surface ? 1 : 0 };
-			if (lol_gpu_part_rows(h, &R) <= 0) continue;
-			void* dst = surface ? surface[d] : static_cast<void*>(D.part[slot] + (size_t)(S.tab.row0[part] - S.dev_row0[d]) * w);
-			int st = lol_gpu_render_device(D.ctx, cam, w, h, max_steps, &R, dst, surface ? surface_pitch : (size_t)w * 4, nullptr, D.render);
+		for (int p = d; p < S.n_parts; p += m->n) {
+			if (lol_gpu_part_rows(h, &S.rows[p]) <= 0) continue;
+			uint32_t* dst = D.part[slot] + (size_t)(S.tab.row0[p] - S.dev_row0[d]) * w;
+			int st = lol_gpu_render_device(D.ctx, cam, w, h, max_steps, &S.rows[p], dst, (size_t)w * 4, nullptr, D.render);
 			if (st != LOL_GPU_OK) return mfail(m, st, "lol_gpu_render_device", lol_gpu_error(D.ctx));
 		}
 		M_HIP(m, hipEventRecord(D.rendered[slot], D.render));
@@ -594,7 +566,7 @@ int lol_gpu_multi_render_device(lol_gpu_multi* m, const lol_frame_camera* cam, i
 		M_HIP(m, hipEventRecord(m->dev[d].sent[slot], m->dev[d].xchg));
 	}
 	M_HIP(m, hipSetDevice(root.id));
-	M_HIP(m, launch_assemble(m->staging[slot], S.tab, m->n_parts, S.band, w, h, dst, pitch_bytes, root.xchg));
+	M_HIP(m, launch_assemble(m->staging[slot], S.tab, w, h, dst, pitch_bytes, root.xchg));
 	M_HIP(m, hipEventRecord(m->done[slot], root.xchg));
 	return LOL_GPU_OK;
 }
@@ -611,8 +583,7 @@ int lol_gpu_multi_sync(lol_gpu_multi* m) {
 }
 
 /* One part of the frame from its compact device copy into the host surface: the part's bands are band_rows rows each,
- * n_parts * band_rows rows apart in the frame — one strided 3-D copy (+ one 2-D copy if the part owns the frame's
- * partial last band). */
+ * cycle_rows rows apart in the frame — one strided 3-D copy (+ one 2-D copy if the part's last band is cut by the frame's end). */
 static hipError_t copy_part_to_host(const uint32_t* part_dev, const lol_gpu_rows& R, int w, int h,
                                     char* host, size_t pitch, hipStream_t s) {
 	const int rows = lol_gpu_part_rows(h, &R);
@@ -621,15 +592,14 @@ static hipError_t copy_part_to_host(const uint32_t* part_dev, const lol_gpu_rows
 		hipMemcpy3DParms p;
 		memset(&p, 0, sizeof p);
 		p.srcPtr = make_hipPitchedPtr(const_cast<uint32_t*>(part_dev), (size_t)w * 4, (size_t)w * 4, (size_t)R.band_rows);
-		p.dstPtr = make_hipPitchedPtr(host + (size_t)R.part * R.band_rows * pitch, pitch, (size_t)w * 4,
-		                              (size_t)R.n_parts * R.band_rows);
+		p.dstPtr = make_hipPitchedPtr(host + (size_t)R.offset_rows * pitch, pitch, (size_t)w * 4, (size_t)R.cycle_rows);
 		p.extent = make_hipExtent((size_t)w * 4, (size_t)R.band_rows, (size_t)full);
 		p.kind = hipMemcpyDeviceToHost;
 		const hipError_t e = hipMemcpy3DAsync(&p, s);
 		if (e != hipSuccess) return e;
 	}
 	if (tail > 0) {
-		const size_t y0 = ((size_t)full * R.n_parts + R.part) * R.band_rows;
+		const size_t y0 = (size_t)full * R.cycle_rows + R.offset_rows;
 		const hipError_t e = hipMemcpy2DAsync(host + y0 * pitch, pitch, part_dev + (size_t)full * R.band_rows * w, (size_t)w * 4,
 		                                      (size_t)w * 4, (size_t)tail, hipMemcpyDeviceToHost, s);
 		if (e != hipSuccess) return e;
@@ -662,7 +632,7 @@ int lol_gpu_multi_render_host(lol_gpu_multi* m, const lol_frame_camera* cam, int
 		M_HIP(m, hipStreamSynchronize(root.xchg));
 		return LOL_GPU_OK;
 	}
-	/* every device writes its own bands into the surface: N links in parallel, no exchange, no RCCL */
+	/* every device copies its own bands into the surface: N links in parallel, no exchange, no RCCL */
 	Split S;
 	int st = split_frame(m, h, S);
 	if (st != LOL_GPU_OK) return st;
@@ -676,11 +646,9 @@ int lol_gpu_multi_render_host(lol_gpu_multi* m, const lol_frame_camera* cam, int
 	auto copy_device = [m, &S, slot, w, h, host_pixels, pitch_bytes](int d) -> hipError_t {
 		Device& D = m->dev[d];
 		hipError_t e = hipSetDevice(D.id);
-		for (int part = 0; part < m->n_parts && e == hipSuccess; part++) {
-			if (m->owner[part] != d) continue;
-			lol_gpu_rows R = { S.band, m->n_parts, part };
-			if (lol_gpu_part_rows(h, &R) <= 0) continue;
-			e = copy_part_to_host(D.part[slot] + (size_t)(S.tab.row0[part] - S.dev_row0[d]) * w, R, w, h,
+		for (int p = d; p < S.n_parts && e == hipSuccess; p += m->n) {
+			if (lol_gpu_part_rows(h, &S.rows[p]) <= 0) continue;
+			e = copy_part_to_host(D.part[slot] + (size_t)(S.tab.row0[p] - S.dev_row0[d]) * w, S.rows[p], w, h,
 			                      static_cast<char*>(host_pixels), pitch_bytes, D.xchg);
 		}
 		if (e == hipSuccess) e = hipEventRecord(D.sent[slot], D.xchg);

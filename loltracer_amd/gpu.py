@@ -21,8 +21,14 @@ _STATUS = {0: "ok", -1: "no HIP device", -2: "HIP runtime error", -3: "bad argum
 
 
 class Rows(C.Structure):
-    """lol_gpu_rows: band-interleaved row partition (multi-GPU row tiles)."""
-    _fields_ = [("band_rows", C.c_int32), ("n_parts", C.c_int32), ("part", C.c_int32), ("in_place", C.c_int32)]
+    """lol_gpu_rows: the rows one launch renders — `band_rows` rows at `offset_rows` of every `cycle_rows` (multi-GPU
+    row tiles; include/lol_gpu.h)."""
+    _fields_ = [("band_rows", C.c_int32), ("cycle_rows", C.c_int32), ("offset_rows", C.c_int32), ("in_place", C.c_int32)]
+
+    @classmethod
+    def equal(cls, band_rows: int, n_parts: int, part: int, in_place: int = 0) -> "Rows":
+        """Part `part` of n_parts equal parts with bands of band_rows rows."""
+        return cls(band_rows, band_rows * n_parts, band_rows * part, in_place)
 
 
 class PixelFormat(C.Structure):
@@ -178,14 +184,12 @@ def gpu_lib() -> C.CDLL:
         lib.lol_gpu_multi_memcpy_d2h.restype = C.c_int
         lib.lol_gpu_assemble_parts.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]
         lib.lol_gpu_assemble_parts.restype = C.c_int
-        lib.lol_gpu_assemble_parts_at.argtypes = [vp, vp, P(C.c_uint32), C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]
+        lib.lol_gpu_assemble_parts_at.argtypes = [vp, vp, P(Rows), P(C.c_uint32), C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]
         lib.lol_gpu_assemble_parts_at.restype = C.c_int
-        lib.lol_gpu_deal_parts.argtypes = [C.c_int, C.c_int, C.c_int, P(C.c_int), C.c_int]
-        lib.lol_gpu_deal_parts.restype = C.c_int
-        lib.lol_gpu_choose_band_rows_for.argtypes = [C.c_int, P(C.c_int), C.c_int, C.c_int]
-        lib.lol_gpu_choose_band_rows_for.restype = C.c_int
-        lib.lol_gpu_multi_set_root_parts.argtypes = [vp, C.c_int]
-        lib.lol_gpu_multi_set_root_parts.restype = C.c_int
+        lib.lol_gpu_split_rows.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, P(Rows)]
+        lib.lol_gpu_split_rows.restype = C.c_int
+        lib.lol_gpu_multi_set_root_band_rows.argtypes = [vp, C.c_int]
+        lib.lol_gpu_multi_set_root_band_rows.restype = C.c_int
         lib.lol_gpu_multi_set_pixel_format.argtypes = [vp, P(PixelFormat)]
         lib.lol_gpu_multi_set_pixel_format.restype = C.c_int
         _lib = lib
@@ -206,7 +210,7 @@ EXPORTED_SYMBOLS = [
     "lol_gpu_multi_set_parts_per_device", "lol_gpu_multi_set_host_via_root",
     "lol_gpu_set_pixel_format",
     "lol_gpu_render_host_pending_size", "lol_gpu_render_host_discard", "lol_gpu_kernel_key",
-    "lol_gpu_assemble_parts_at", "lol_gpu_deal_parts", "lol_gpu_choose_band_rows_for", "lol_gpu_multi_set_root_parts",
+    "lol_gpu_assemble_parts_at", "lol_gpu_split_rows", "lol_gpu_multi_set_root_band_rows",
     "lol_gpu_multi_set_pixel_format",
 ]
 
@@ -225,25 +229,23 @@ def part_rows(h: int, rows: Rows | None) -> int:
     return gpu_lib().lol_gpu_part_rows(h, C.byref(rows) if rows is not None else None)
 
 
-def deal_parts(n_devices: int, per_dev: int, root_parts: int) -> list:
-    """owner[p] of lol_gpu_deal_parts (pure host logic, no device needed)."""
-    owner = (C.c_int * 64)()
-    n = gpu_lib().lol_gpu_deal_parts(n_devices, per_dev, root_parts, owner, 64)
-    if n < 0:
-        raise GpuError(n, f"lol_gpu_deal_parts({n_devices}, {per_dev}, {root_parts})")
-    return list(owner[:n])
+def split_rows(n_parts: int, band_rows: int, root_band_rows: int = 0, root_stride: int = 1) -> list:
+    """lol_gpu_split_rows (pure host logic, no device needed): the Rows of every part of a frame cut into n_parts
+    parts with bands of band_rows rows, those of parts p % root_stride == 0 root_band_rows tall (0 = band_rows)."""
+    arr = (Rows * n_parts)()
+    st = gpu_lib().lol_gpu_split_rows(n_parts, band_rows, root_band_rows, root_stride, arr)
+    if st != LOL_GPU_OK:
+        raise GpuError(st, f"lol_gpu_split_rows({n_parts}, {band_rows}, {root_band_rows}, {root_stride})")
+    return [Rows(r.band_rows, r.cycle_rows, r.offset_rows, r.in_place) for r in arr]
 
 
-def choose_band_rows_for(h: int, owner: list, n_devices: int) -> int:
-    arr = (C.c_int * len(owner))(*owner)
-    return int(gpu_lib().lol_gpu_choose_band_rows_for(h, arr, len(owner), n_devices))
-
-
-def assemble_parts_at(ctx_renderer, parts_ptr: int, part_row0: list, band_rows: int, w: int, h: int, dst_ptr: int,
+def assemble_parts_at(ctx_renderer, parts_ptr: int, part_rows: list, part_row0: list, w: int, h: int, dst_ptr: int,
                       pitch_bytes: int, stream: int | None):
     """lol_gpu_assemble_parts_at on the renderer's device: un-interleave gathered parts (device pointers)."""
-    arr = (C.c_uint32 * len(part_row0))(*part_row0)
-    st = gpu_lib().lol_gpu_assemble_parts_at(ctx_renderer._ctx, C.c_void_p(parts_ptr), arr, len(part_row0), band_rows, w, h,
+    n = len(part_rows)
+    rows = (Rows * n)(*part_rows)
+    row0 = (C.c_uint32 * n)(*part_row0)
+    st = gpu_lib().lol_gpu_assemble_parts_at(ctx_renderer._ctx, C.c_void_p(parts_ptr), rows, row0, n, w, h,
                                              C.c_void_p(dst_ptr), pitch_bytes, _stream_arg(stream))
     if st != LOL_GPU_OK:
         raise GpuError(st, "lol_gpu_assemble_parts_at")
@@ -408,8 +410,9 @@ class MultiRenderer:
     def set_host_via_root(self, enable: bool):
         self._check(self._lib.lol_gpu_multi_set_host_via_root(self._m, 1 if enable else 0))
 
-    def set_root_parts(self, root_parts: int):
-        self._check(self._lib.lol_gpu_multi_set_root_parts(self._m, root_parts))
+    def set_root_band_rows(self, rows: int):
+        """Band height of the root's parts (0 = like the others): its smaller share of the rows."""
+        self._check(self._lib.lol_gpu_multi_set_root_band_rows(self._m, rows))
 
     def set_pixel_format(self, fmt):
         if isinstance(fmt, str):

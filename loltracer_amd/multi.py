@@ -11,10 +11,11 @@ un-interleaves them.  One process per GPU; torch.distributed is only the
 transport.
 
 Cost-weighted split (`Partition`): rank 0 also receives and un-interleaves the
-whole frame, so with an equal share it is the straggler.  The parts are dealt
-round-robin over the ranks, `per_rank` rounds of one part each, and the root
-sits out the last `per_rank - root_parts` rounds — the same dealing as
-lol_gpu_deal_parts behind the C ABI, so both hosts cut a frame identically.
+whole frame, so with an equal share it is the straggler.  Every rank owns one
+band per cycle of rows and renders its part with ONE launch (eight small
+launches took 2.7x as long as one, measured); the root's bands are simply less
+tall than the others' — the geometry of lol_gpu_split_rows behind the C ABI,
+so both hosts cut a frame identically.
 
 Everything here is device-agnostic (tensors in, tensors out) so the same code
 runs under gloo on CPU in the tests and under nccl (= RCCL) on MI355X; on a GPU
@@ -70,82 +71,72 @@ def assemble(parts: torch.Tensor, h: int, band_rows: int) -> torch.Tensor:
     return parts.view(world, nb, band_rows, w).permute(1, 0, 2, 3).reshape(h, w)
 
 
-def deal_parts(world: int, per_rank: int, root_parts: Optional[int] = None) -> List[int]:
-    """owner[p] = rank of part p: per_rank rounds of one part per rank, the root (rank 0) sitting out the last
-    per_rank - root_parts rounds.  Mirrors lol_gpu_deal_parts (include/lol_gpu.h)."""
-    if root_parts is None or world == 1:
-        root_parts = per_rank
-    if world < 1 or per_rank < 1 or not 0 <= root_parts <= per_rank:
-        raise ValueError(f"deal_parts({world}, {per_rank}, {root_parts})")
-    return [r for rnd in range(per_rank) for r in range(world) if not (r == 0 and rnd >= root_parts)]
+def split_rows(world: int, band_rows: int, root_band_rows: int = 0):
+    """[(band_rows, cycle_rows, offset_rows)] of every rank: one band per rank per cycle, in rank order, rank 0's
+    root_band_rows tall (0 = like the others).  Mirrors lol_gpu_split_rows (include/lol_gpu.h)."""
+    if world < 1 or band_rows < 1 or root_band_rows < 0:
+        raise ValueError(f"split_rows({world}, {band_rows}, {root_band_rows})")
+    if world == 1:
+        return [(band_rows, band_rows, 0)]
+    heights = [root_band_rows or band_rows] + [band_rows] * (world - 1)
+    cycle = sum(heights)
+    out, at = [], 0
+    for hgt in heights:
+        out.append((hgt, cycle, at))
+        at += hgt
+    return out
 
 
-def choose_band_rows_for(h: int, owner: List[int], world: int) -> int:
-    """Band height for a deal: the multiple of 4 up to 16 that leaves the busiest rank the fewest rows (ties: the
-    taller band).  Mirrors lol_gpu_choose_band_rows_for."""
-    n_parts = len(owner)
-    if n_parts == 1:
-        return h
-    best, best_rows = 0, -1
-    for band in (16, 12, 8, 4):
-        rows = [0] * world
-        for p, r in enumerate(owner):
-            rows[r] += part_rows(h, band, n_parts, p)
-        if best_rows < 0 or max(rows) < best_rows:
-            best, best_rows = band, max(rows)
-    return best
+def rows_of_split(h: int, band: int, cycle: int, offset: int) -> int:
+    """Rows of a frame of height h that belong to the part (band rows at `offset` of every `cycle`): lol_gpu_part_rows."""
+    n = 0
+    for y0 in range(offset, h, cycle):
+        n += min(band, h - y0)
+    return n
 
 
 class Partition:
     """How one frame of `h` rows is cut over `world` ranks: the same on every rank.
 
-    band          band height
-    owner[p]      rank of part p;  parts_of[r] = the parts of rank r, ascending
-    rows_of[p]    rows part p holds;  rank_rows[r] = rows rank r renders
+    geometry[r]   (band_rows, cycle_rows, offset_rows) of rank r — its lol_gpu_rows: ONE launch renders the rank's part
+    rank_rows[r]  rows rank r renders
     max_rows      rows of every rank's local buffer (padded to the largest, so one gather of equal tensors serves)
-    local_row0[p] first row of part p inside its owner's local buffer (parts back to back)
-    part_row0[p]  first row of part p inside the gathered [world * max_rows, w] staging buffer
+    part_row0[r]  first row of rank r inside the gathered [world * max_rows, w] staging buffer
     """
 
-    def __init__(self, h: int, world: int, per_rank: int = 1, root_parts: Optional[int] = None, band_rows: int = 0):
-        self.h, self.world, self.per_rank = h, world, per_rank
-        self.owner = deal_parts(world, per_rank, root_parts)
-        self.root_parts = per_rank if (root_parts is None or world == 1) else root_parts
-        self.n_parts = len(self.owner)
-        equal = self.root_parts == per_rank
-        self.band = band_rows or ((choose_band_rows(h, self.n_parts) if equal else 0)
-                                  or choose_band_rows_for(h, self.owner, world))
+    def __init__(self, h: int, world: int, band_rows: int = 0, root_band_rows: int = 0):
+        self.h, self.world = h, world
+        if world == 1:
+            band_rows, root_band_rows = h, 0
+        self.band = band_rows or choose_band_rows(h, world)
         if self.band <= 0:
-            raise ValueError(f"cannot cut {h} rows into bands for {self.n_parts} parts")
-        self.parts_of = [[p for p in range(self.n_parts) if self.owner[p] == r] for r in range(world)]
-        self.rows_of = [part_rows(h, self.band, self.n_parts, p) for p in range(self.n_parts)]
-        self.rank_rows = [sum(self.rows_of[p] for p in ps) for ps in self.parts_of]
+            self.band = 4 if h >= 4 * world else 1
+        self.root_band = root_band_rows if world > 1 else 0
+        self.geometry = split_rows(world, self.band, self.root_band)
+        self.rank_rows = [rows_of_split(h, *g) for g in self.geometry]
         assert sum(self.rank_rows) == h
         self.max_rows = max(self.rank_rows)
-        self.local_row0, self.part_row0 = [0] * self.n_parts, [0] * self.n_parts
-        for r, ps in enumerate(self.parts_of):
-            row = 0
-            for p in ps:
-                self.local_row0[p] = row
-                self.part_row0[p] = r * self.max_rows + row
-                row += self.rows_of[p]
+        self.part_row0 = [r * self.max_rows for r in range(world)]
 
     def frame_rows_of_rank(self, rank: int) -> torch.Tensor:
-        """Frame row of every (used) local row of `rank`, parts back to back."""
-        ys = [frame_rows_of_part(self.h, self.band, self.n_parts, p) for p in self.parts_of[rank]]
-        return torch.cat(ys) if ys else torch.zeros(0, dtype=torch.long)
+        """Frame row of every (used) local row of `rank`, in local order (the inverse of the kernel's row mapping)."""
+        band, cycle, offset = self.geometry[rank]
+        ys = []
+        for y0 in range(offset, self.h, cycle):
+            ys.extend(range(y0, min(y0 + band, self.h)))
+        return torch.tensor(ys, dtype=torch.long)
 
     def staging_index(self) -> torch.Tensor:
         """index[y] = row of the gathered staging buffer that holds frame row y."""
         idx = torch.empty(self.h, dtype=torch.long)
-        for p in range(self.n_parts):
-            ys = frame_rows_of_part(self.h, self.band, self.n_parts, p)
-            idx[ys] = self.part_row0[p] + torch.arange(len(ys))
+        for r in range(self.world):
+            ys = self.frame_rows_of_rank(r)
+            idx[ys] = self.part_row0[r] + torch.arange(len(ys))
         return idx
 
     def describe(self) -> dict:
-        return {"band_rows": self.band, "n_parts": self.n_parts, "parts_per_rank": self.per_rank,
-                "root_parts": self.root_parts, "rows_per_rank": self.rank_rows}
+        return {"band_rows": self.band, "root_band_rows": self.root_band or self.band, "cycle_rows": self.geometry[0][1],
+                "rows_per_rank": self.rank_rows}
 
 
 def gather_frame(local: torch.Tensor, h: int, band_rows: int, group=None, dst: int = 0,
@@ -197,7 +188,7 @@ class GatherPipeline:
         self.single = self.world == 1 and not (force_collective and dist.is_initialized())
         if dst != 0:
             raise ValueError("the root of the partition is rank 0")
-        self.partition = partition if partition is not None else Partition(h, self.world, 1, None, band_rows if self.world > 1 else h)
+        self.partition = partition if partition is not None else Partition(h, self.world, band_rows if self.world > 1 else h)
         P = self.partition
         if P.h != h:
             raise ValueError("partition is for another frame height")
@@ -250,8 +241,8 @@ class GatherPipeline:
         self.frames_done += 1
 
     def submit(self, render):
-        """render(local_buffer): enqueue the rendering of this rank's parts into the [max_rows, w] tensor
-        (part p at rows partition.local_row0[p] …)."""
+        """render(local_buffer): enqueue the rendering of this rank's part into the [max_rows, w] tensor (compactly,
+        from row 0; rows beyond partition.rank_rows[rank] are padding)."""
         slot = self.n % self.depth
         self.n += 1
         if self.single:

@@ -40,9 +40,14 @@ def test_struct_sizes_match_the_headers():
 
 def test_part_rows_is_pure_host_logic():
     assert gpu.part_rows(2160, None) == 2160
-    assert [gpu.part_rows(4320, gpu.Rows(4, 8, r)) for r in range(8)] == [540] * 8
-    assert [gpu.part_rows(20, gpu.Rows(8, 2, r)) for r in range(2)] == [12, 8]
-    assert gpu.part_rows(10, gpu.Rows(0, 1, 0)) == -1
+    assert [gpu.part_rows(4320, gpu.Rows.equal(4, 8, r)) for r in range(8)] == [540] * 8
+    assert [gpu.part_rows(20, gpu.Rows.equal(8, 2, r)) for r in range(2)] == [12, 8]
+    assert gpu.part_rows(10, gpu.Rows.equal(0, 1, 0)) == -1
+    # bands of different heights inside one cycle (the root's smaller share): 7 + 3 x 8 rows per cycle of 31
+    split = gpu.split_rows(4, 8, 7, 4)
+    assert [(r.band_rows, r.cycle_rows, r.offset_rows) for r in split] == [(7, 31, 0), (8, 31, 7), (8, 31, 15), (8, 31, 23)]
+    assert [gpu.part_rows(100, r) for r in split] == [28, 24, 24, 24] and sum(gpu.part_rows(4320, r) for r in split) == 4320
+    assert gpu.part_rows(10, gpu.Rows(4, 8, 5)) == -1          # the band sticks out of its cycle
 
 
 def test_no_gpu_is_a_loud_error_not_a_fallback():

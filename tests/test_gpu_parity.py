@@ -149,7 +149,7 @@ def test_band_partition_reassembles_to_the_full_frame(torch_cuda, renderer, scen
     full = gpu_render(torch_cuda, renderer, sc, w, h)["xrgb"]
     out = np.zeros_like(full)
     for part in range(n_parts):
-        rows = gpu.Rows(band, n_parts, part)
+        rows = gpu.Rows.equal(band, n_parts, part)
         g = gpu_render(torch_cuda, renderer, sc, w, h, rows=rows)["xrgb"]
         nb = g.shape[0] // band
         for b in range(nb):
@@ -198,7 +198,7 @@ def test_full_size_sampled_rows_and_partition(torch_cuda, renderer, scenes):
     assert h % (band * n_parts) == 0
     out = np.zeros_like(g["xrgb"])
     for part in range(n_parts):
-        pg = gpu_render(torch_cuda, renderer, sc, w, h, rows=gpu.Rows(band, n_parts, part))["xrgb"]
+        pg = gpu_render(torch_cuda, renderer, sc, w, h, rows=gpu.Rows.equal(band, n_parts, part))["xrgb"]
         v = pg.reshape(-1, band, w)
         out.reshape(-1, n_parts, band, w)[:, part] = v
     assert np.array_equal(out, g["xrgb"])
@@ -275,7 +275,7 @@ def test_baseline_configs_2_and_4_at_full_size(torch_cuda, scenes):
     from loltracer_amd import multi
     band, n_parts = multi.choose_band_rows(h, 8), 8
     for part in (0, 5):
-        pg = gpu_render(torch_cuda, r, sc, w, h, rows=gpu.Rows(band, n_parts, part))["xrgb"]
+        pg = gpu_render(torch_cuda, r, sc, w, h, rows=gpu.Rows.equal(band, n_parts, part))["xrgb"]
         assert np.array_equal(pg.reshape(-1, band, w), full.reshape(-1, n_parts, band, w)[:, part])
     r.close()
 

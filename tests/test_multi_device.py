@@ -31,7 +31,7 @@ def test_every_frame_row_belongs_to_exactly_one_part_row(h, band, n):
     lib = gpu.gpu_lib()
     seen = np.zeros(h, dtype=np.int32)
     for r in range(n):
-        rows = gpu.Rows(band, n, r)
+        rows = gpu.Rows.equal(band, n, r)
         k = gpu.part_rows(h, rows)
         ys = [lib.lol_gpu_part_frame_row(h, C.byref(rows), i) for i in range(k)]
         assert ys == sorted(ys) and all(0 <= y < h for y in ys)
@@ -87,7 +87,7 @@ def test_parts_assembled_by_the_library_equal_the_whole_frame(scenes, w, h, band
     staging = torch.full((h, w), -1, dtype=torch.int32, device="cuda")
     row0 = 0
     for part in range(n):
-        rows = gpu.Rows(band, n, part)
+        rows = gpu.Rows.equal(band, n, part)
         k = gpu.part_rows(h, rows)
         if k:
             r.render_into(staging[row0:].data_ptr(), w, h, 256, rows=rows)
@@ -106,32 +106,40 @@ def test_parts_assembled_by_the_library_equal_the_whole_frame(scenes, w, h, band
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("w,h,world,per,k", [(640, 360, 8, 8, 7), (333, 181, 3, 4, 2), (512, 432, 8, 8, 5), (256, 97, 2, 3, 0)])
-def test_weighted_parts_padded_per_rank_assemble_to_the_whole_frame(scenes, w, h, world, per, k):
-    """What rank 0 of the one-process-per-GPU host does with unequal parts (the root owns fewer bands): every rank's
-    parts back to back in a buffer padded to the largest rank, the buffers gathered rank by rank, then
-    lol_gpu_assemble_parts_at with the table of where each part starts.  One device renders every rank's parts here,
-    and the in-place form (lol_gpu_rows.in_place) writes the same parts straight into a whole frame."""
+@pytest.mark.parametrize("w,h,world,band,root", [(640, 360, 8, 16, 14), (333, 181, 3, 8, 5), (512, 432, 8, 12, 10), (256, 97, 2, 12, 1),
+                                                  (640, 360, 8, 12, 0), (128, 50, 4, 16, 15)])
+def test_weighted_parts_padded_per_rank_assemble_to_the_whole_frame(scenes, w, h, world, band, root):
+    """What rank 0 of the one-process-per-GPU host does when the root's bands are less tall than the others': every rank's
+    part (ONE launch) in a buffer padded to the largest rank, the buffers gathered rank by rank, then
+    lol_gpu_assemble_parts_at with the geometry of every part and where it starts.  One device renders every rank's part
+    here, and the in-place form (lol_gpu_rows.in_place) writes the same parts straight into a whole frame."""
     import torch
     from loltracer_amd import multi
     r = gpu.Renderer(0)
     r.prepare(scenes["scene4"])
     whole = _frame(r, torch, w, h)
-    P = multi.Partition(h, world, per, k)
+    P = multi.Partition(h, world, band, root)
+    geometry = [gpu.Rows(*g, 0) for g in P.geometry]
+    assert [gpu.part_rows(h, g) for g in geometry] == P.rank_rows
     staging = torch.full((world * P.max_rows, w), -1, dtype=torch.int32, device="cuda")
     pitch_px = w + 3
     direct = torch.zeros((h, pitch_px), dtype=torch.int32, device="cuda")
-    for p in range(P.n_parts):
-        if not P.rows_of[p]:
+    torch.cuda.synchronize()
+    for p in range(world):
+        if not P.rank_rows[p]:
             continue
-        r.render_into(staging[P.part_row0[p]:].data_ptr(), w, h, 256, rows=gpu.Rows(P.band, P.n_parts, p))
-        r.render_into(direct.data_ptr(), w, h, 256, rows=gpu.Rows(P.band, P.n_parts, p, 1), pitch_bytes=pitch_px * 4)
+        r.render_into(staging[P.part_row0[p]:].data_ptr(), w, h, 256, rows=geometry[p])
+        r.render_into(direct.data_ptr(), w, h, 256, rows=gpu.Rows(*P.geometry[p], 1), pitch_bytes=pitch_px * 4)
     r.sync()
     out = torch.zeros((h, pitch_px), dtype=torch.int32, device="cuda")
-    gpu.assemble_parts_at(r, staging.data_ptr(), P.part_row0, P.band, w, h, out.data_ptr(), pitch_px * 4, None)
+    torch.cuda.synchronize()
+    gpu.assemble_parts_at(r, staging.data_ptr(), geometry, P.part_row0, w, h, out.data_ptr(), pitch_px * 4, None)
     torch.cuda.synchronize()
     assert torch.equal(out[:, :w], whole) and int(out[:, w:].abs().sum()) == 0
     assert torch.equal(direct[:, :w], whole) and int(direct[:, w:].abs().sum()) == 0
+    # the CPU-side index of the same partition (what the gloo tests assemble with) agrees
+    idx = P.staging_index().cuda()
+    assert torch.equal(staging[idx], whole)
     r.close()
 
 

@@ -132,64 +132,56 @@ def test_kernel_row_mapping_agrees_with_partition_helper():
         assert ys == [((r // band) * world + p) * band + r % band for r in range(len(ys))]
 
 
-# ---------------------------------------------------------------- cost-weighted split (the root owns fewer parts)
+# ---------------------------------------------------------------- cost-weighted split (the root's bands are less tall)
 
-def test_deal_parts_and_band_choice_match_the_library():
-    """loltracer_amd.multi (one process per GPU) and lol_gpu_deal_parts / lol_gpu_choose_band_rows_for (behind the C ABI)
-    must cut a frame identically."""
+def test_split_geometry_matches_the_library():
+    """loltracer_amd.multi (one process per GPU) and lol_gpu_split_rows / lol_gpu_part_rows (behind the C ABI) must cut a
+    frame identically."""
     from loltracer_amd import gpu
-    for world in (1, 2, 3, 4, 8):
-        for per in (1, 2, 4, 8):
-            if world * per > 64:
-                continue
-            for k in range(per + 1):
-                owner = multi.deal_parts(world, per, k)
-                assert owner == gpu.deal_parts(world, per, k), (world, per, k)
-                want = per if world == 1 else k
-                assert owner.count(0) == want and all(owner.count(r) == per for r in range(1, world))
-                if len(owner) > 1:
-                    for h in (4320, 2160, 1080, 97, 720):
-                        assert multi.choose_band_rows_for(h, owner, world) == gpu.choose_band_rows_for(h, owner, world)
-    # the root sits out the LAST rounds, everything else is a plain round-robin
-    assert multi.deal_parts(3, 3, 1) == [0, 1, 2, 1, 2, 1, 2]
+    for world in (1, 2, 3, 4, 8, 16):
+        for band, root in ((16, 0), (16, 15), (12, 11), (12, 10), (8, 7), (16, 12), (4, 1), (7, 3)):
+            geo = multi.split_rows(world, band, root)
+            lib = gpu.split_rows(world, band, root, world)
+            assert geo == [(r.band_rows, r.cycle_rows, r.offset_rows) for r in lib], (world, band, root)
+            for h in (4320, 2160, 1080, 97, 720, 5):
+                assert [multi.rows_of_split(h, *g) for g in geo] == [gpu.part_rows(h, r) for r in lib]
+    assert multi.split_rows(3, 8, 5) == [(5, 21, 0), (8, 21, 5), (8, 21, 13)]
     with pytest.raises(ValueError):
-        multi.deal_parts(2, 2, 3)
-    with pytest.raises(gpu.GpuError):
-        gpu.deal_parts(8, 9, 9)                       # more than 64 parts
+        multi.split_rows(2, 0)
 
 
-@pytest.mark.parametrize("world,per,k,h", [(8, 8, 7, 4320), (8, 8, 5, 4320), (4, 8, 7, 4320), (2, 8, 7, 4320), (3, 4, 2, 101),
-                                            (8, 1, 1, 4320), (2, 3, 0, 50)])
-def test_partition_covers_every_row_once_and_is_balanced(world, per, k, h):
-    P = multi.Partition(h, world, per, k)
+@pytest.mark.parametrize("world,band,root,h", [(8, 16, 15, 4320), (8, 12, 10, 4320), (4, 8, 7, 4320), (2, 16, 12, 4320), (3, 8, 5, 101),
+                                                (8, 12, 0, 4320), (2, 12, 1, 50), (5, 4, 3, 17)])
+def test_partition_covers_every_row_once_and_is_balanced(world, band, root, h):
+    P = multi.Partition(h, world, band, root)
     seen = torch.cat([P.frame_rows_of_rank(r) for r in range(world)])
     assert sorted(seen.tolist()) == list(range(h))
     assert P.rank_rows == [len(P.frame_rows_of_rank(r)) for r in range(world)]
     idx = P.staging_index()
     assert len(set(idx.tolist())) == h and int(idx.max()) < world * P.max_rows
-    # the root's share follows root_parts / n_parts, the others are equal to within one band per part
+    # the others are equal to within one band, the root's share follows its band height
     others = P.rank_rows[1:]
-    if others:
-        assert max(others) - min(others) <= P.band * per
-        if per > 1 and h >= 1000:
-            assert abs(P.rank_rows[0] / h - k / P.n_parts) < 0.01
-    # part p's rows in the kernel's mapping (include/lol_gpu.h: lol_gpu_part_frame_row)
+    assert max(others) - min(others) <= band
+    if h >= 1000:
+        rb = root or band
+        assert abs(P.rank_rows[0] / h - rb / (rb + (world - 1) * band)) < 0.01
+    # the kernel's mapping (include/lol_gpu.h: lol_gpu_part_frame_row) is the inverse
     from loltracer_amd import gpu
     lib = gpu.gpu_lib()
-    for p in (0, P.n_parts // 2, P.n_parts - 1):
-        rows = gpu.Rows(P.band, P.n_parts, p)
-        assert gpu.part_rows(h, rows) == P.rows_of[p]
-        ys = multi.frame_rows_of_part(h, P.band, P.n_parts, p).tolist()
+    for r in (0, world // 2, world - 1):
+        rows = gpu.Rows(*P.geometry[r], 0)
+        ys = P.frame_rows_of_rank(r).tolist()
         assert ys == [lib.lol_gpu_part_frame_row(h, rows, i) for i in range(len(ys))]
+        assert lib.lol_gpu_part_frame_row(h, rows, len(ys)) == -1
 
 
-def _weighted_worker(rank, world, port, w, h, per, k, frames, q):
+def _weighted_worker(rank, world, port, w, h, band, root, frames, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        P = multi.Partition(h, world, per, k)
+        P = multi.Partition(h, world, band, root)
         pipe = multi.GatherPipeline(w, h, P.band, torch.device("cpu"), depth=2, partition=P)
         ys = P.frame_rows_of_rank(rank)
         assert pipe.local[0].shape == (P.max_rows, w) and len(ys) == P.rank_rows[rank]
@@ -201,21 +193,21 @@ def _weighted_worker(rank, world, port, w, h, per, k, frames, q):
         last = pipe.drain()
         if rank == 0:
             want = ((frames - 1) * 1000003 + torch.arange(h).view(-1, 1) * 4099 + torch.arange(w).view(1, -1)).to(torch.int32)
-            q.put(bool(torch.equal(last, want)) and P.rank_rows[0] <= P.rank_rows[1])
+            q.put(bool(torch.equal(last, want)) and P.rank_rows[0] < P.rank_rows[1])
         else:
             assert last is None
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,h,per,k", [(2, 120, 4, 3), (3, 101, 4, 2), (4, 96, 2, 0)])
-def test_unequal_parts_gather_and_assemble(world, h, per, k):
-    """The root owns fewer bands than the others (root_parts < parts_per_rank), heights that no band divides,
-    a root that renders nothing at all: the gathered, padded parts still assemble to the frame."""
+@pytest.mark.parametrize("world,h,band,root", [(2, 120, 8, 6), (3, 101, 8, 5), (4, 96, 4, 1)])
+def test_unequal_parts_gather_and_assemble(world, h, band, root):
+    """The root's bands are less tall than the others' (its smaller share), heights that no cycle divides: the gathered,
+    padded parts still assemble to the frame."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_weighted_worker, args=(r, world, port, 20, h, per, k, 4, q)) for r in range(world)]
+    procs = [ctx.Process(target=_weighted_worker, args=(r, world, port, 20, h, band, root, 4, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

@@ -38,15 +38,17 @@ def main():
     r.sync()
     out = {"frame": f"{w}x{h}", "bytes_moved": 2 * w * h * 4, "cases": []}
     stream = torch.cuda.current_stream().cuda_stream
-    for per, k in ((1, 1), (8, 8), (8, 7), (8, 6)):
-        P = multi.Partition(h, world, per, k)
+    for band, root in ((12, 0), (16, 15), (12, 10), (16, 12)):
+        P = multi.Partition(h, world, band, root)
+        geometry = [gpu.Rows(*g, 0) for g in P.geometry]
         staging = torch.zeros((world, P.max_rows, w), dtype=torch.int32, device="cuda")
-        for p in range(P.n_parts):
-            r.render_into(staging.view(-1, w)[P.part_row0[p]:].data_ptr(), w, h, rows=gpu.Rows(P.band, P.n_parts, p))
+        torch.cuda.synchronize()
+        for p in range(world):
+            r.render_into(staging.view(-1, w)[P.part_row0[p]:].data_ptr(), w, h, rows=geometry[p])
         r.sync()
         frame = torch.empty((h, w), dtype=torch.int32, device="cuda")
-        rec = {"parts_per_rank": per, "root_parts": k, **P.describe()}
-        if per == 1:
+        rec = dict(P.describe())
+        if not root:
             ms = timed(lambda: frame.copy_(multi.assemble(staging, h, P.band)))
             rec["torch_permute_copy_ms"] = round(ms, 4)
             rec["torch_permute_copy_GBps"] = round(out["bytes_moved"] / ms / 1e6, 1)
@@ -56,7 +58,7 @@ def main():
         ms = timed(lambda: torch.index_select(staging.view(-1, w), 0, idx, out=frame))
         rec["torch_index_select_ms"] = round(ms, 4)
         frame.zero_()
-        ms = timed(lambda: gpu.assemble_parts_at(r, staging.data_ptr(), P.part_row0, P.band, w, h, frame.data_ptr(), w * 4, stream))
+        ms = timed(lambda: gpu.assemble_parts_at(r, staging.data_ptr(), geometry, P.part_row0, w, h, frame.data_ptr(), w * 4, stream))
         rec["library_kernel_ms"] = round(ms, 4)
         rec["library_kernel_GBps"] = round(out["bytes_moved"] / ms / 1e6, 1)
         rec["library_equal"] = bool(torch.equal(frame, whole))

@@ -12,7 +12,7 @@ for band in (2, 4, 6, 12, 20, 36, 540):
     if h % (band * n): continue
     ts = []
     for part in (0, 3, 7):
-        rows = gpu.Rows(band, n, part); nr = gpu.part_rows(h, rows)
+        rows = gpu.Rows.equal(band, n, part); nr = gpu.part_rows(h, rows)
         buf = torch.zeros((nr, w), dtype=torch.int32, device="cuda")
         for i in range(6):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
