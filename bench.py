@@ -437,7 +437,7 @@ def main():
 
     def assembler(staging, frame, P, stream_handle):
         """the root's un-interleave: the library's uint4 kernel on the assembly stream (lol_gpu_assemble_parts_at)"""
-        gpu.assemble_parts_at(r, staging.data_ptr(), [gpu.Rows(*g, 0) for g in P.geometry], P.part_row0, w, h,
+        gpu.assemble_parts_at(r, staging.data_ptr(), [gpu.Rows(*g) for g in P.geometry], P.part_row0, w, h,
                               frame.data_ptr(), w * 4, stream_handle)
 
     if os.environ.get("LOL_BENCH_ASSEMBLE") == "torch":     # A/B: the round-2 torch index copy instead
@@ -468,7 +468,7 @@ def main():
         if P is None:
             r.render_into(dst_tensor.data_ptr(), w, h, max_steps, stream=stream, frame_camera=fc)
         elif P.rank_rows[rank]:                      # ONE launch: this rank's band of every cycle, compactly
-            r.render_into(dst_tensor.data_ptr(), w, h, max_steps, rows=gpu.Rows(*P.geometry[rank], 0), stream=stream,
+            r.render_into(dst_tensor.data_ptr(), w, h, max_steps, rows=gpu.Rows(*P.geometry[rank]), stream=stream,
                           frame_camera=fc)
         if timed:
             e1.record()

@@ -57,8 +57,6 @@ typedef struct lol_gpu_rows {
 	int32_t band_rows;
 	int32_t cycle_rows;
 	int32_t offset_rows;
-	int32_t in_place;   /* 0: the part is stored compactly (above); 1: `dst` is the whole frame and every row of the part
-	                     * lands at its frame position — what a part written straight into a shared frame needs */
 } lol_gpu_rows;
 
 /*

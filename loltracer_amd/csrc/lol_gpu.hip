@@ -542,10 +542,12 @@ std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast, co
 					i++;                                /* the smooth min is part of this macro-op; depth unchanged */
 				} else {
 					m[0] = lol::mop_header(kind, depth == 0 ? lol::MOP_SET : lol::MOP_PUSH);
+					if (depth > 0) m[0] |= (uint32_t)(depth - 1) << lol::MOP_SLOT_SHIFT;      /* the accumulator goes to this slot */
 					depth++;
 				}
 			} else {                                     /* SMIN / SMIN_R on two computed operands */
 				m[0] = lol::mop_header(lol::MOP_POP, o.op == LOL_OP_SMIN ? lol::MOP_SMIN_X : lol::MOP_SMIN);
+				m[0] |= (uint32_t)(depth - 2) << lol::MOP_SLOT_SHIFT;                           /* the operand under the accumulator */
 				smin_fields(m, o);
 				depth--;
 			}
@@ -1334,7 +1336,7 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	if (!ctx->have_prog) return fail(ctx, LOL_GPU_ERR_NO_PROGRAM, "no scene program uploaded");
 	if (w <= 0 || h <= 0 || max_steps < 0 || pitch_bytes % 4 || pitch_bytes < (size_t)w * 4)
 		return fail(ctx, LOL_GPU_ERR_ARG, "bad frame geometry");
-	lol_gpu_rows whole = { h, h, 0, 0 };
+	lol_gpu_rows whole = { h, h, 0 };
 	const lol_gpu_rows* R = rows ? rows : &whole;
 	int n_rows = lol_gpu_part_rows(h, R);
 	if (n_rows < 0) return fail(ctx, LOL_GPU_ERR_ARG, "bad row partition");
@@ -1357,8 +1359,7 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	L.materials     = reinterpret_cast<const uint32_t*>(base + offsetof(lol_program, materials));
 	L.root_material = reinterpret_cast<const uint32_t*>(base + offsetof(lol_program, root_material));
 	L.ambient[0] = P.ambient_color.x; L.ambient[1] = P.ambient_color.y; L.ambient[2] = P.ambient_color.z;
-	L.flags = (ctx->miss_skip ? lol::FLAG_MISS_SKIP : 0u) | (ctx->dark_skip ? lol::FLAG_DARK_SKIP : 0u) |
-	          (R->in_place ? lol::FLAG_IN_PLACE : 0u);
+	L.flags = (ctx->miss_skip ? lol::FLAG_MISS_SKIP : 0u) | (ctx->dark_skip ? lol::FLAG_DARK_SKIP : 0u);
 	L.dst = static_cast<uint32_t*>(dst);
 	L.pitch_px = (uint32_t)(pitch_bytes / 4);
 	L.fmt_shift = ctx->fmt_shift; L.fmt_loss = ctx->fmt_loss; L.fmt_amask = ctx->fmt_amask;

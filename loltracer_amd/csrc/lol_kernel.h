@@ -66,7 +66,6 @@ constexpr int LIGHT_DWORDS = 9, MATERIAL_DWORDS = 10;
 /* Launch.flags */
 constexpr u32 FLAG_MISS_SKIP = 1u;   /* a wave whose rays all escaped may skip normal + lights (see shade_pixel) */
 constexpr u32 FLAG_DARK_SKIP = 2u;   /* lanes whose diffuse incidence for a light is exactly 0 need no shadow march for it */
-constexpr u32 FLAG_IN_PLACE  = 4u;   /* dst is a whole-frame surface: a pixel lands at its FRAME row, not at the part's local row (lol_gpu_rows.in_place) */
 
 /* = lol_frame_camera */
 struct Cam { float origin[3], dir[3], right[3], up[3]; float width, height; };
@@ -86,7 +85,7 @@ struct Launch {
 	const u32* root_material;
 	float  ambient[3];
 	u32    flags;                /* FLAG_* */
-	u32*   dst;                  /* 32-bit pixels (fmt_* below), pitch_px dwords per row (local rows, or frame rows with FLAG_IN_PLACE) */
+	u32*   dst;                  /* 32-bit pixels (fmt_* below), pitch_px dwords per local row */
 	u32    pitch_px;
 	/* SDL_MapRGB's description of the surface's pixel format (renderer.h:17-22; lol_gpu_pixel_format), one byte per channel:
 	 * pixel = (r >> Rloss) << Rshift | (g >> Gloss) << Gshift | (b >> Bloss) << Bshift | Amask */
@@ -98,6 +97,26 @@ struct Launch {
 	u32*   dbg_hit_id;
 	u32*   dbg_steps;
 };
+
+/* Fields of the launch arguments that only the last few instructions of a kernel need (destination, pitch, pixel
+ * format, diagnostics) are read THERE, from the kernel-argument segment, through a pointer the compiler cannot see
+ * through: read from the by-value parameter they are loaded at kernel entry and stay in SGPRs for the whole kernel —
+ * a dozen registers of a file that is full (the interpreter kernel spilled SGPRs into a VGPR and lost its eighth
+ * wave per SIMD over three new fields: 2860 -> 2720 Mpixels/s on C3). */
+struct LaunchTail {
+	u32*   dst; u32 pitch_px; u32 fmt_shift, fmt_loss, fmt_amask;
+	float* dbg_rgb; float* dbg_hit_dist; u32* dbg_hit_id; u32* dbg_steps;
+};
+__device__ __forceinline__ LaunchTail launch_tail(const Launch& L0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	typedef const __attribute__((address_space(4))) Launch* kernarg_ptr;
+	kernarg_ptr L = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+	asm volatile("" : "+s"(L));                    /* opaque: these loads are not merged with the ones at kernel entry */
+	return { L->dst, L->pitch_px, L->fmt_shift, L->fmt_loss, L->fmt_amask, L->dbg_rgb, L->dbg_hit_dist, L->dbg_hit_id, L->dbg_steps };
+#else
+	return { L0.dst, L0.pitch_px, L0.fmt_shift, L0.fmt_loss, L0.fmt_amask, L0.dbg_rgb, L0.dbg_hit_dist, L0.dbg_hit_id, L0.dbg_steps };
+#endif
+}
 
 struct V3 { float x, y, z; };
 
@@ -456,6 +475,11 @@ constexpr u32 MOPB_CULL_CHAIN = 65536u;   /* one or more tests of inner runs fol
 constexpr u32 CULLC_NEXT = 1u, CULLC_AFTER = 2u;
 constexpr u32 MOP_TIE = 32768u;         /* with MOP_TOP: evaluated after an object that follows it in the file → ties go to the lower id */
 constexpr u32 CULL_COOLDOWN = 3u;       /* after a test that did not allow the skip, this many evaluations do not test */
+/* The operand stack under the accumulator is a set of numbered slots, and the slot a PUSH fills / a POP empties is known
+ * when the list is built (the post-order depth): it travels in the record (bits 20-23), so the slots never move.  (As a
+ * shifting stack — s[j] = s[j - 1] — every record of the general path paid four v_mov for values it did not touch: the
+ * loop-carried copies of the shifted registers; read off the ISA.) */
+constexpr u32 MOP_SLOT_SHIFT = 20u, MOP_SLOT_MASK = 15u;
 __host__ __device__ constexpr u32 mop_smin_bits(u32 hdr) {
 	return !(hdr & MOPB_SMIN) ? 0u : !(hdr & MOP_FASTDIV) ? MOPB_SMIN_EXACT : (hdr & MOPB_X_IS_A) ? MOPB_SMIN_XF : MOPB_SMIN_AF;
 }
@@ -512,10 +536,15 @@ struct Interp {
 			/* LOL_KEEP_BRANCH: an empty volatile asm keeps the compiler from turning a rarely taken uniform branch into
 			 * v_cndmask selects that every macro-op would then pay for (half-rate VALU, 4 cycles each) */
 #define LOL_KEEP_BRANCH() asm volatile("" ::: "memory")
+			/* LOL_RARE / LOL_OFTEN: where the body of a header test goes — rare bodies out of line, so that the common
+			 * record (a sphere smooth-minned into the accumulator) falls through its tests instead of jumping over them:
+			 * a taken branch costs the wave an instruction refetch (+0.7 % on C3, measured) */
+#define LOL_RARE(c) __builtin_expect(!!(c), 0)
+#define LOL_OFTEN(c) __builtin_expect(!!(c), 1)
 			float x = 0.f;
-			if (hdr & MOPB_SPHERE)
+			if (LOL_OFTEN(hdr & MOPB_SPHERE))
 				x = KIND ? sd_sphere_fast<KIND ? KIND : 1>(p, F(2), F(3), F(4), F(5), r) : sd_sphere(p, F(2), F(3), F(4), F(5));
-			if (hdr & MOPB_NOT_SPHERE) {                             /* grouped: a sphere macro-op pays one test for these */
+			if (LOL_RARE(hdr & MOPB_NOT_SPHERE)) {                   /* grouped: a sphere macro-op pays one test for these */
 				LOL_KEEP_BRANCH();
 				if (hdr & MOPB_RBOX)
 					x = KIND ? sd_round_box_fast<KIND ? KIND : 1>(p, F(2), F(3), F(4), F(5), F(6), F(7), F(8), r)
@@ -524,30 +553,31 @@ struct Interp {
 					x = p.y - F(2);                              /* plane: (p - (0,y,0)).y */
 				if (hdr & MOPB_POP) {
 					LOL_KEEP_BRANCH();
+					const u32 slot = hdr >> MOP_SLOT_SHIFT & MOP_SLOT_MASK;
 					x = s[0];
 #pragma unroll
-					for (int j = 0; j < SSIZE - 1; j++) s[j] = s[j + 1];
+					for (int j = 1; j < SSIZE; j++) x = slot == (u32)j ? s[j] : x;
 				}
 			}
-			if (hdr & MOPB_SMIN) {
+			if (LOL_OFTEN(hdr & MOPB_SMIN)) {
 				/* four independent skip-aheads (operand order x fast / exact blend factor), the common fast ones first:
 				 * a nested if / ?: here made the compiler hoist the FASTDIV test through a VGPR and add flag registers */
 				LOL_KEEP_BRANCH();
-				if (hdr & MOPB_SMIN_AF) { LOL_KEEP_BRANCH(); x = sminf_fastdiv(acc, x, F(9), F(10), F(11)); }
-				if (hdr & MOPB_SMIN_XF) { LOL_KEEP_BRANCH(); x = sminf_fastdiv(x, acc, F(9), F(10), F(11)); }
-				if (hdr & MOPB_SMIN_EXACT) {
+				if (LOL_OFTEN(hdr & MOPB_SMIN_AF)) { LOL_KEEP_BRANCH(); x = sminf_fastdiv(acc, x, F(9), F(10), F(11)); }
+				if (LOL_RARE(hdr & MOPB_SMIN_XF)) { LOL_KEEP_BRANCH(); x = sminf_fastdiv(x, acc, F(9), F(10), F(11)); }
+				if (LOL_RARE(hdr & MOPB_SMIN_EXACT)) {
 					LOL_KEEP_BRANCH();
 					if (!(hdr & MOPB_X_IS_A)) { LOL_KEEP_BRANCH(); x = sminf_(acc, x, F(9)); }
 					if (hdr & MOPB_X_IS_A) { LOL_KEEP_BRANCH(); x = sminf_(x, acc, F(9)); }
 				}
 			}
-			if (hdr & MOPB_TAIL) {
+			if (LOL_RARE(hdr & MOPB_TAIL)) {
 				LOL_KEEP_BRANCH();
 				if (hdr & MOPB_PUSH) {
 					LOL_KEEP_BRANCH();
+					const u32 slot = hdr >> MOP_SLOT_SHIFT & MOP_SLOT_MASK;
 #pragma unroll
-					for (int j = SSIZE - 1; j > 0; j--) s[j] = s[j - 1];
-					s[0] = acc;
+					for (int j = 0; j < SSIZE; j++) s[j] = slot == (u32)j ? acc : s[j];
 				}
 				if (hdr & MOP_TOP) {                                    /* (tests only follow finished objects) */
 					LOL_KEEP_BRANCH();
@@ -600,6 +630,8 @@ struct Interp {
 				}
 			}
 			acc = x;
+#undef LOL_RARE
+#undef LOL_OFTEN
 #undef LOL_KEEP_BRANCH
 		}
 		rg = r;
@@ -700,7 +732,7 @@ __host__ __device__ inline u32 common_lds_dwords(u32 n_lights, u32 n_materials, 
 	return n_lights * LIGHT_DWORDS + n_materials * MATERIAL_DWORDS + n_roots + TILE_W * TILE_H;
 }
 
-struct Pixel { u32 px; V3 rgb; Hit hit; u32 shadow_steps; };
+struct Pixel { V3 rgb; Hit hit; u32 shadow_steps; };      /* rgb: post-gamma colour; packed into the surface's format by store_pixel */
 
 /* frame row of local row r of this launch's part (the inverse: lol_gpu_part_frame_row) */
 __device__ __forceinline__ int frame_row(const Launch& L, int r) {
@@ -797,37 +829,37 @@ __device__ __forceinline__ Pixel shade_pixel(const Launch& L, Sdf& sdf, const u3
 	/* gamma + colorf_to_pixfmt, naive_renderer.c:231-232, renderer.h:17-22 */
 	const float g = 1.f / 2.2f;
 	c = { powf_glibc(c.x, g), powf_glibc(c.y, g), powf_glibc(c.z, g) };
-	/* Uint8 r = colorf.x * 255 …; SDL_MapRGB(fmt, r, g, b) for a non-palettised format (SDL2 src/video/SDL_pixels.c):
-	 * (r >> Rloss) << Rshift | (g >> Gloss) << Gshift | (b >> Bloss) << Bshift | Amask.  XRGB8888 = shifts 16/8/0, no loss, no alpha. */
-	const u32 r8 = (u32)(c.x * 255.f) & 0xFFu, g8 = (u32)(c.y * 255.f) & 0xFFu, b8 = (u32)(c.z * 255.f) & 0xFFu;
-	const u32 px = (r8 >> (L.fmt_loss & 0xFFu)) << (L.fmt_shift & 0xFFu) |
-	               (g8 >> (L.fmt_loss >> 8 & 0xFFu)) << (L.fmt_shift >> 8 & 0xFFu) |
-	               (b8 >> (L.fmt_loss >> 16 & 0xFFu)) << (L.fmt_shift >> 16 & 0xFFu) | L.fmt_amask;
-	return { px, c, hit, shadow_steps };
+	return { c, hit, shadow_steps };
 }
 
-/* Write the lane's pixel (and the optional diagnostics).  Every thread of the block must call this. */
+/* Pack the lane's colour for the surface, write it (and the optional diagnostics).  Every thread of the block must call this. */
 __device__ __forceinline__ void store_pixel(const Launch& L, const Pixel& P, u32* lds) {
+	const LaunchTail T = launch_tail(L);
+	/* colorf_to_pixfmt, renderer.h:17-22: Uint8 r = colorf.x * 255 …; SDL_MapRGB(fmt, r, g, b) for a non-palettised format
+	 * (SDL2 src/video/SDL_pixels.c): (r >> Rloss) << Rshift | (g >> Gloss) << Gshift | (b >> Bloss) << Bshift | Amask.
+	 * XRGB8888 = shifts 16 / 8 / 0, no loss, no alpha. */
+	const u32 r8 = (u32)(P.rgb.x * 255.f) & 0xFFu, g8 = (u32)(P.rgb.y * 255.f) & 0xFFu, b8 = (u32)(P.rgb.z * 255.f) & 0xFFu;
+	const u32 px = (r8 >> (T.fmt_loss & 0xFFu)) << (T.fmt_shift & 0xFFu) |
+	               (g8 >> (T.fmt_loss >> 8 & 0xFFu)) << (T.fmt_shift >> 8 & 0xFFu) |
+	               (b8 >> (T.fmt_loss >> 16 & 0xFFu)) << (T.fmt_shift >> 16 & 0xFFu) | T.fmt_amask;
 	u32* l_tile = lds + L.n_lights * LIGHT_DWORDS + L.n_materials * MATERIAL_DWORDS + L.n_roots;
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int tx = wave * WAVE_W + (lane % WAVE_W), ty = lane / WAVE_W;
 	const int gx = blockIdx.x * TILE_W + tx, gr = blockIdx.y * TILE_H + ty;
 	if (gx < L.w && gr < L.n_rows) {
 		unsigned long long o = (unsigned long long)gr * L.w + gx;
-		if (L.dbg_rgb) { L.dbg_rgb[o * 3 + 0] = P.rgb.x; L.dbg_rgb[o * 3 + 1] = P.rgb.y; L.dbg_rgb[o * 3 + 2] = P.rgb.z; }
-		if (L.dbg_hit_dist) L.dbg_hit_dist[o] = P.hit.dist;
-		if (L.dbg_hit_id) L.dbg_hit_id[o] = P.hit.id;
-		if (L.dbg_steps) L.dbg_steps[o] = (P.hit.steps & 0xFFFFu) | (P.shadow_steps << 16);
+		if (T.dbg_rgb) { T.dbg_rgb[o * 3 + 0] = P.rgb.x; T.dbg_rgb[o * 3 + 1] = P.rgb.y; T.dbg_rgb[o * 3 + 2] = P.rgb.z; }
+		if (T.dbg_hit_dist) T.dbg_hit_dist[o] = P.hit.dist;
+		if (T.dbg_hit_id) T.dbg_hit_id[o] = P.hit.id;
+		if (T.dbg_steps) T.dbg_steps[o] = (P.hit.steps & 0xFFFFu) | (P.shadow_steps << 16);
 	}
 	/* through LDS so the block stores whole row segments (64 bytes each with the default 16x4 patch) */
-	l_tile[ty * TILE_W + tx] = P.px;
+	l_tile[ty * TILE_W + tx] = px;
 	__syncthreads();
 	const int sx = threadIdx.x % TILE_W, sy = threadIdx.x / TILE_W;
 	const int ox = blockIdx.x * TILE_W + sx, orow = blockIdx.y * TILE_H + sy;
-	if (ox < L.w && orow < L.n_rows) {
-		const int drow = (L.flags & FLAG_IN_PLACE) ? frame_row(L, orow) : orow;
-		L.dst[(unsigned long long)drow * L.pitch_px + ox] = l_tile[sy * TILE_W + sx];
-	}
+	if (ox < L.w && orow < L.n_rows)
+		T.dst[(unsigned long long)orow * T.pitch_px + ox] = l_tile[sy * TILE_W + sx];
 }
 
 /* stage lights | materials | root_material into `lds` (no barrier) */

@@ -285,11 +285,11 @@ int lol_gpu_choose_band_rows(int h, int n_parts) {
 
 int lol_gpu_split_rows(int n_parts, int band_rows, int root_band_rows, int root_stride, lol_gpu_rows* out) {
 	if (n_parts < 1 || n_parts > MAX_PARTS || band_rows < 1 || root_band_rows < 0 || root_stride < 1 || !out) return LOL_GPU_ERR_ARG;
-	if (n_parts == 1) { out[0] = { band_rows, band_rows, 0, 0 }; return LOL_GPU_OK; }
+	if (n_parts == 1) { out[0] = { band_rows, band_rows, 0 }; return LOL_GPU_OK; }
 	int at = 0;
 	for (int p = 0; p < n_parts; p++) {
 		const int b = (root_band_rows > 0 && p % root_stride == 0) ? root_band_rows : band_rows;
-		out[p] = { b, 0, at, 0 };
+		out[p] = { b, 0, at };
 		at += b;
 	}
 	if (at > 0xFFFF) return LOL_GPU_ERR_ARG;

@@ -23,12 +23,12 @@ _STATUS = {0: "ok", -1: "no HIP device", -2: "HIP runtime error", -3: "bad argum
 class Rows(C.Structure):
     """lol_gpu_rows: the rows one launch renders — `band_rows` rows at `offset_rows` of every `cycle_rows` (multi-GPU
     row tiles; include/lol_gpu.h)."""
-    _fields_ = [("band_rows", C.c_int32), ("cycle_rows", C.c_int32), ("offset_rows", C.c_int32), ("in_place", C.c_int32)]
+    _fields_ = [("band_rows", C.c_int32), ("cycle_rows", C.c_int32), ("offset_rows", C.c_int32)]
 
     @classmethod
-    def equal(cls, band_rows: int, n_parts: int, part: int, in_place: int = 0) -> "Rows":
+    def equal(cls, band_rows: int, n_parts: int, part: int) -> "Rows":
         """Part `part` of n_parts equal parts with bands of band_rows rows."""
-        return cls(band_rows, band_rows * n_parts, band_rows * part, in_place)
+        return cls(band_rows, band_rows * n_parts, band_rows * part)
 
 
 class PixelFormat(C.Structure):
@@ -236,7 +236,7 @@ def split_rows(n_parts: int, band_rows: int, root_band_rows: int = 0, root_strid
     st = gpu_lib().lol_gpu_split_rows(n_parts, band_rows, root_band_rows, root_stride, arr)
     if st != LOL_GPU_OK:
         raise GpuError(st, f"lol_gpu_split_rows({n_parts}, {band_rows}, {root_band_rows}, {root_stride})")
-    return [Rows(r.band_rows, r.cycle_rows, r.offset_rows, r.in_place) for r in arr]
+    return [Rows(r.band_rows, r.cycle_rows, r.offset_rows) for r in arr]
 
 
 def assemble_parts_at(ctx_renderer, parts_ptr: int, part_rows: list, part_row0: list, w: int, h: int, dst_ptr: int,

@@ -33,7 +33,7 @@ def sdl_map_rgb(rgb: np.ndarray, f: gpu.PixelFormat) -> np.ndarray:
 
 
 def test_pixel_format_struct_matches_the_header():
-    assert C.sizeof(gpu.PixelFormat) == 12 and C.sizeof(gpu.Rows) == 16
+    assert C.sizeof(gpu.PixelFormat) == 12 and C.sizeof(gpu.Rows) == 12
 
 
 def test_oracle_packs_through_the_surface_format(scenes):

@@ -169,7 +169,7 @@ def test_partition_covers_every_row_once_and_is_balanced(world, band, root, h):
     from loltracer_amd import gpu
     lib = gpu.gpu_lib()
     for r in (0, world // 2, world - 1):
-        rows = gpu.Rows(*P.geometry[r], 0)
+        rows = gpu.Rows(*P.geometry[r])
         ys = P.frame_rows_of_rank(r).tolist()
         assert ys == [lib.lol_gpu_part_frame_row(h, rows, i) for i in range(len(ys))]
         assert lib.lol_gpu_part_frame_row(h, rows, len(ys)) == -1

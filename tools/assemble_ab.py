@@ -40,7 +40,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     for band, root in ((12, 0), (16, 15), (12, 10), (16, 12)):
         P = multi.Partition(h, world, band, root)
-        geometry = [gpu.Rows(*g, 0) for g in P.geometry]
+        geometry = [gpu.Rows(*g) for g in P.geometry]
         staging = torch.zeros((world, P.max_rows, w), dtype=torch.int32, device="cuda")
         torch.cuda.synchronize()
         for p in range(world):
