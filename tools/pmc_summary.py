@@ -46,11 +46,16 @@ def main():
     ap.add_argument("--pixels", type=int, default=3840 * 2160)
     ap.add_argument("--out", required=True)
     ap.add_argument("--merge", action="store_true", help="keep the other kernels already in --out")
+    ap.add_argument("--kernel-key", default=None, help="lol_gpu_kernel_key() of the code that was profiled (bench.py: config.kernel_key)")
+    ap.add_argument("--min-dispatches", type=int, default=1, help="fail when a counter was seen on fewer dispatches of the kernel")
     a = ap.parse_args()
     c, n, ms = summarise(a.csv, a.kernel)
     if not c:
         sys.exit(f"no rows of kernel {a.kernel!r} in {a.csv}")
-    rec = {"workload": a.workload, "pixels_per_launch": a.pixels, "counters_avg_per_dispatch": c,
+    few = {k: v for k, v in n.items() if v < a.min_dispatches}
+    if few:
+        sys.exit(f"kernel {a.kernel!r}: fewer than {a.min_dispatches} dispatches behind {few} — is this the profile of another kernel's run?")
+    rec = {"workload": a.workload, "pixels_per_launch": a.pixels, "kernel_key": a.kernel_key, "counters_avg_per_dispatch": c,
            "dispatches_per_counter": n, "kernel_ms_under_pmc": ms, "sources": [os.path.basename(p) for p in a.csv]}
     if "WRITE_SIZE" in c and "FETCH_SIZE" in c:
         rec["write_bytes"] = c["WRITE_SIZE"] * 1024
@@ -70,6 +75,10 @@ def main():
                 rec[f"cycles_per_{name}_instruction_per_simd"] = cyc / (c[key] / simds)
         if "SQ_INSTS_VALU" in c:
             rec["valu_instructions_per_pixel"] = c["SQ_INSTS_VALU"] * 64 / a.pixels
+        if "SQ_INSTS_VALU_TRANS_F32" in c and "SQ_INSTS_VALU" in c:
+            rec["transcendental_share_of_valu"] = c["SQ_INSTS_VALU_TRANS_F32"] / c["SQ_INSTS_VALU"]
+        if "SQC_ICACHE_REQ" in c and "SQC_ICACHE_MISSES" in c:
+            rec["icache_miss_rate"] = c["SQC_ICACHE_MISSES"] / max(c["SQC_ICACHE_REQ"], 1.0)
     out = {"source": "rocprofv3 --pmc passes on MI355X (tools/final_profile.sh), summarised by tools/pmc_summary.py",
            "units": "WRITE_SIZE / FETCH_SIZE are KiB per dispatch as reported; bytes = KiB*1024; FETCH doubled per the gfx950 "
                     "correction (MI355X_MICROARCH.md, HBM); GRBM_GUI_ACTIVE sums the 8 XCDs", "kernels": {}}
