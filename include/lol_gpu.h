@@ -198,7 +198,13 @@ int         lol_gpu_verify_fast_paths(lol_gpu* ctx, float k, unsigned long long 
  * The same switch governs the per-light form: where a surface faces away from a light (diffuse incidence
  * clamps to exactly 0) both Phong terms of that light are +-0 for any shadow factor, so that lane does not
  * march the shadow ray (needs all light intensities and material colours finite and every shininess >= 0).
- * lol_gpu_miss_skip_active(): bit 0 = escaped-wave skip, bit 1 = zero-incidence skip.
+ *
+ * And the shadow march itself: softshadow returns maxf(res, 0) (naive_renderer.c:88-89), and once res <= 0 no later step
+ * can bring the factor back above 0 — min only lowers it, and no NaN can appear when every number of the scene, its lights
+ * and the camera is finite and below 10^15 (checked on the host) — so a lane's march ends there instead of going on to
+ * res < -1 or t > L; a ray that grazes along just inside a surface otherwise takes all 128 steps while its wave waits
+ * (C3: 5630 -> 7510 Mpixels/s).  Same pixels; lol_gpu_debug.steps counts the steps really marched.
+ * lol_gpu_miss_skip_active(): bit 0 = escaped-wave skip, bit 1 = zero-incidence skip, bit 2 = settled-shadow exit.
  */
 int         lol_gpu_set_miss_skip(lol_gpu* ctx, int enable);
 int         lol_gpu_miss_skip_active(const lol_gpu* ctx);

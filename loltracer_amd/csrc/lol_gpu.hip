@@ -81,6 +81,7 @@ struct lol_gpu {
 	int          want_cull = 1;          /* allow the exact culling of top-level objects (plan_culling) */
 	bool         miss_skip = false;      /* the uploaded program qualifies (miss_skip_ok) */
 	bool         dark_skip = false;      /* the uploaded program qualifies (dark_skip_ok) */
+	bool         shadow_settle = false;  /* the uploaded program qualifies (shadow_settle_ok) */
 	int          interp_sqrt_kind = 0;   /* fast sqrt of the interpreter: 3 (sqrt_r2) when proven and allowed, else 0 */
 	int          sqrt_verified = -1;     /* -1 not run, 0 none proven, else the lol::sqrt_fast KIND proven on this device */
 	bool         sqrt_tiny_ok = false;   /* the second counter of that run was 0 too (sd_sphere_fast_nr) */
@@ -160,6 +161,27 @@ bool dark_skip_ok(const lol_program& P) {
 		for (float v : f) if (!finite(v)) return false;
 		if (!(m.shininess >= 0.0f)) return false;
 	}
+	return true;
+}
+
+/* Conditions for FLAG_SHADOW_SETTLED (lol_kernel.h, soft_shadow): nothing a shadow march can compute overflows or turns
+ * NaN, so that a factor that has reached 0 stays there.  Every number of the scene finite and below 10^15 in magnitude
+ * (positions, radii, box sizes, smoothness, light positions): 128 steps of at most the scene's extent keep every
+ * coordinate below 10^18 and every squared length below 10^36 < FLT_MAX.  The camera is checked per frame (launch). */
+bool shadow_settle_ok(const lol_program& P) {
+	auto sane = [](float v) { return v - v == 0.0f && fabsf(v) < 1e15f; };
+	for (uint32_t i = 0; i < P.n_ops; i++) {
+		const lol_op& o = P.ops[i];
+		const int nf = o.op == LOL_OP_SPHERE ? 4 : o.op == LOL_OP_RBOX ? 7 : (o.op == LOL_OP_PLANE || o.op == LOL_OP_SMIN || o.op == LOL_OP_SMIN_R) ? 1 : 0;
+		for (int j = 0; j < nf; j++) if (!sane(o.f[j])) return false;
+	}
+	for (uint32_t i = 0; i < P.n_lights; i++)
+		if (!sane(P.lights[i].point.x) || !sane(P.lights[i].point.y) || !sane(P.lights[i].point.z)) return false;
+	return true;
+}
+bool camera_sane(const lol_frame_camera& c) {
+	const float* f = reinterpret_cast<const float*>(&c);
+	for (size_t i = 0; i < sizeof c / 4; i++) if (!(f[i] - f[i] == 0.0f && fabsf(f[i]) < 1e15f)) return false;
 	return true;
 }
 
@@ -1214,6 +1236,7 @@ int lol_gpu_set_miss_skip(lol_gpu* ctx, int enable) {
 		const bool allowed = ctx->want_miss_skip && !(ms && ms[0] == '0');
 		ctx->miss_skip = allowed && miss_skip_ok(ctx->h_prog);
 		ctx->dark_skip = allowed && dark_skip_ok(ctx->h_prog);
+		ctx->shadow_settle = allowed && shadow_settle_ok(ctx->h_prog) && !(getenv("LOL_GPU_SHADOW_SETTLE") && getenv("LOL_GPU_SHADOW_SETTLE")[0] == '0');
 	}
 	return LOL_GPU_OK;
 }
@@ -1240,7 +1263,7 @@ int lol_gpu_set_cull(lol_gpu* ctx, int enable) {
 
 /* bit 0: escaped-wave skip active; bit 1: zero-incidence shadow skip active */
 int lol_gpu_miss_skip_active(const lol_gpu* ctx) {
-	return ctx ? (ctx->miss_skip ? 1 : 0) | (ctx->dark_skip ? 2 : 0) : 0;
+	return ctx ? (ctx->miss_skip ? 1 : 0) | (ctx->dark_skip ? 2 : 0) | (ctx->shadow_settle ? 4 : 0) : 0;
 }
 
 /* Run the exhaustive (all 2^32 inputs) equivalence checks directly: mismatch counts out. */
@@ -1310,6 +1333,8 @@ int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog) {
 	const char* ms = getenv("LOL_GPU_MISS_SKIP");
 	ctx->miss_skip = ctx->want_miss_skip && !(ms && ms[0] == '0') && miss_skip_ok(*prog);
 	ctx->dark_skip = ctx->want_miss_skip && !(ms && ms[0] == '0') && dark_skip_ok(*prog);
+	ctx->shadow_settle = ctx->want_miss_skip && !(ms && ms[0] == '0') && shadow_settle_ok(*prog) &&
+	                     !(getenv("LOL_GPU_SHADOW_SETTLE") && getenv("LOL_GPU_SHADOW_SETTLE")[0] == '0');
 	specialise(ctx);          /* a failed specialisation is not an error: the interpreter renders the new scene */
 	return LOL_GPU_OK;
 }
@@ -1359,7 +1384,8 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	L.materials     = reinterpret_cast<const uint32_t*>(base + offsetof(lol_program, materials));
 	L.root_material = reinterpret_cast<const uint32_t*>(base + offsetof(lol_program, root_material));
 	L.ambient[0] = P.ambient_color.x; L.ambient[1] = P.ambient_color.y; L.ambient[2] = P.ambient_color.z;
-	L.flags = (ctx->miss_skip ? lol::FLAG_MISS_SKIP : 0u) | (ctx->dark_skip ? lol::FLAG_DARK_SKIP : 0u);
+	L.flags = (ctx->miss_skip ? lol::FLAG_MISS_SKIP : 0u) | (ctx->dark_skip ? lol::FLAG_DARK_SKIP : 0u) |
+	          (ctx->shadow_settle && camera_sane(*cam) ? lol::FLAG_SHADOW_SETTLED : 0u);
 	L.dst = static_cast<uint32_t*>(dst);
 	L.pitch_px = (uint32_t)(pitch_bytes / 4);
 	L.fmt_shift = ctx->fmt_shift; L.fmt_loss = ctx->fmt_loss; L.fmt_amask = ctx->fmt_amask;

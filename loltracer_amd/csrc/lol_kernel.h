@@ -66,6 +66,7 @@ constexpr int LIGHT_DWORDS = 9, MATERIAL_DWORDS = 10;
 /* Launch.flags */
 constexpr u32 FLAG_MISS_SKIP = 1u;   /* a wave whose rays all escaped may skip normal + lights (see shade_pixel) */
 constexpr u32 FLAG_DARK_SKIP = 2u;   /* lanes whose diffuse incidence for a light is exactly 0 need no shadow march for it */
+constexpr u32 FLAG_SHADOW_SETTLED = 4u;   /* a shadow march ends as soon as its factor can only be 0 (soft_shadow) */
 
 /* = lol_frame_camera */
 struct Cam { float origin[3], dir[3], right[3], up[3]; float width, height; };
@@ -678,10 +679,21 @@ __device__ __forceinline__ Hit march(Sdf& sdf, V3 ro, V3 rd, int max_steps) {
 
 /* in_shadow + softshadow, naive_renderer.c:73-100.  dir/light_dist come from the caller,
  * which needs the same normalize(light - p) for the Phong term. */
+/*
+ * `settled` (FLAG_SHADOW_SETTLED, wave-uniform): the march of a lane also ends once res <= 0.  The factor returned is
+ * maxf(res, 0), and from res <= 0 on every further step can only keep it there: res' = minf(res, v) = (res < v ? res : v)
+ * is <= 0 again for every v that is not NaN, and v = 50 s / t is NaN only for a non-finite s or t, or for 0 / 0 — which
+ * the host rules out before it sets the flag (lol_gpu.hip, shadow_settle_ok: every scene constant, light and the camera
+ * finite and below 10^15, so nothing the 128 steps can reach overflows; t returns to exactly 0 only at the ray's own
+ * origin, where s is what it was on the first step, and had that been 0 res would have been NaN from the first step on,
+ * never <= 0).  The reference goes on until res < -1 or t > L; a ray that grazes along just inside a surface does so for
+ * all 128 steps while its 63 neighbours wait.  Same pixels; the shadow step counts of lol_gpu_debug shrink.
+ */
 template <class Sdf>
-__device__ __forceinline__ float soft_shadow(Sdf& sdf, V3 p, V3 dir, float max_dist, u32& steps, bool needed) {
+__device__ __forceinline__ float soft_shadow(Sdf& sdf, V3 p, V3 dir, float max_dist, u32& steps, bool needed, bool settled) {
 	V3 ro = add(p, dir);
 	float res = 1.f, t = 0.f;
+	const float stop_at = settled ? 0.f : -1.f;          /* res < -1 (naive_renderer.c:85), or res <= 0 */
 	bool alive = needed;          /* a lane that does not need the factor never marches (returns 1) */
 	u64 marching = Sdf::MASKS ? vote(needed) : 0;
 	for (int i = 0; i < 128; i++) {
@@ -693,9 +705,9 @@ __device__ __forceinline__ float soft_shadow(Sdf& sdf, V3 p, V3 dir, float max_d
 			res = minf_(res, 50.f * s / t);
 			t += s;
 			steps++;
-			if (res < -1.f || t > max_dist) alive = false;
+			if (res < -1.f || t > max_dist || (settled && res <= 0.f)) alive = false;
 		}
-		if constexpr (Sdf::MASKS) marching &= ~(vote(res < -1.f) | vote(t > max_dist));
+		if constexpr (Sdf::MASKS) marching &= ~((settled ? vote(res <= stop_at) : vote(res < stop_at)) | vote(t > max_dist));
 	}
 	return maxf_(res, 0.f);
 }
@@ -812,7 +824,7 @@ __device__ __forceinline__ Pixel shade_pixel(const Launch& L, Sdf& sdf, const u3
 			bool needed = true;
 			if (L.flags & FLAG_DARK_SKIP) needed = di > 0.f;
 			if ((L.flags & FLAG_MISS_SKIP) && hit.id == 0u) needed = false;
-			float shadow = soft_shadow(sdf, p, light_dir, light_dist, shadow_steps, needed);
+			float shadow = soft_shadow(sdf, p, light_dir, light_dist, shadow_steps, needed, (L.flags & FLAG_SHADOW_SETTLED) != 0u);
 
 			V3 refl = sub(scale(n, 2.f * dot(light_dir, n)), light_dir);
 			V3 Id = mul(scale(lds_v3(lp + 3), shadow * di), m_diff);

@@ -23,6 +23,8 @@ typedef struct { float x, y, z; } v3;
 
 struct tally {               /* per-pixel work counters, folded into lol_oracle_counters */
 	uint64_t sdf_evals, node_evals, march_steps, shadow_steps;
+	uint64_t settled_steps;        /* shadow steps up to and including the first one that left res <= 0 (all of them if none did) */
+	uint64_t settle_violations;    /* shadow rays whose res was <= 0 at some step and whose factor still came out != 0 */
 };
 
 /* ------------------------------------------------------------------ float.h */
@@ -137,15 +139,19 @@ static struct world_dist get_intersection(const lol_scene* sc, v3 ro, v3 rd, int
 static float softshadow(const lol_scene* sc, v3 ro, v3 rd, int max_steps, float max_dist, float w,
                         struct tally* t) {
 	float res = 1.f, dist = 0.f;
+	int settled = 0;      /* checker-side bookkeeping only (not in the reference): see lol_oracle.h, settled_steps */
 	for (int i = 0; i < max_steps; i++) {
 		v3 p = v3add(ro, v3scale(rd, dist));
 		float scene_dist = sdf(sc, p, t).dist;
 		t->shadow_steps++;
+		if (!settled) t->settled_steps++;
 		res = minf(res, w * scene_dist / dist);
 		dist += scene_dist;
+		if (res <= 0.f) settled = 1;
 		if (res < -1 || dist > max_dist)
 			break;
 	}
+	if (settled && maxf(res, 0.f) != 0.f) t->settle_violations++;
 	return maxf(res, 0.f);
 }
 
@@ -183,13 +189,16 @@ static v3 get_light(const lol_scene* sc, v3 cam_pos, v3 p, v3 n, uint32_t obj_id
 	v3 total = { 0.f, 0.f, 0.f };
 	for (size_t li = 0; li < sc->n_lights; li++) {
 		const lol_light* light = &sc->lights[li];
-		uint64_t before = t->shadow_steps;
+		uint64_t before = t->shadow_steps, settled_before = t->settled_steps;
 		float shadow = in_shadow(sc, light, p, t);
 		if (probe && li < LOL_MAX_LIGHTS) {
 			probe->shadow[li] = shadow;
 			probe->shadow_steps[li] = (uint32_t)(t->shadow_steps - before);
 		}
-		if (per_light && li < 4) per_light[li] = (uint16_t)(t->shadow_steps - before);
+		if (per_light && li < 4) {
+			per_light[li] = (uint16_t)(t->shadow_steps - before);
+			per_light[4 + li] = (uint16_t)(t->settled_steps - settled_before);
+		}
 		v3 Id = from_lol(light->diffuse_intensity);
 		v3 Is = from_lol(light->specular_intensity);
 		v3 light_dir = v3normalize(v3sub(from_lol(light->point), p));
@@ -286,21 +295,21 @@ static void render_row(const lol_scene* sc, const lol_camera* cam, int w, int h,
                        lol_oracle_counters* ctr) {
 	float fw = (float)w, fh = (float)h;
 	for (int x = 0; x < w; x++) {
-		struct tally t = { 0, 0, 0, 0 };
+		struct tally t = { 0, 0, 0, 0, 0, 0 };
 		int missed = 0;
 		uint32_t hit_id = 0, dark = 0;
-		uint16_t per_light[4] = { 0, 0, 0, 0 };
+		uint16_t per_light[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 		uint32_t px = shade_pixel(sc, cam, x, y, fw, fh, max_steps, &t,
 		                          rgb ? rgb + ((size_t)y * w + x) * 3 : NULL, NULL, &missed, &hit_id, &dark,
 		                          per_light);
 		if (xrgb) memcpy((char*)xrgb + (size_t)y * pitch + (size_t)x * 4, &px, 4);
 		if (steps) {
-			uint16_t* o = steps + ((size_t)y * w + x) * 8;
+			uint16_t* o = steps + ((size_t)y * w + x) * 12;
 			o[0] = (uint16_t)t.march_steps;
 			o[1] = (uint16_t)(t.shadow_steps > 65535 ? 65535 : t.shadow_steps);
 			o[2] = (uint16_t)(hit_id > 65535 ? 65535 : hit_id);
 			o[3] = (uint16_t)dark;             /* bit i: light i has diffuse incidence exactly 0 here */
-			for (int k = 0; k < 4; k++) o[4 + k] = per_light[k];
+			for (int k = 0; k < 8; k++) o[4 + k] = per_light[k];
 		}
 		if (ctr) {
 			ctr->pixels++;
@@ -308,6 +317,7 @@ static void render_row(const lol_scene* sc, const lol_camera* cam, int w, int h,
 			ctr->node_evals += t.node_evals;
 			ctr->march_steps += t.march_steps;
 			ctr->shadow_steps += t.shadow_steps;
+			ctr->settle_violations += t.settle_violations;
 			ctr->miss_pixels += (uint64_t)missed;
 		}
 	}
@@ -351,6 +361,7 @@ static void* worker(void* arg) {
 		j->ctr->node_evals += local.node_evals;
 		j->ctr->march_steps += local.march_steps;
 		j->ctr->shadow_steps += local.shadow_steps;
+		j->ctr->settle_violations += local.settle_violations;
 		j->ctr->miss_pixels += local.miss_pixels;
 		pthread_mutex_unlock(&j->lock);
 	}
@@ -393,13 +404,13 @@ void lol_oracle_render_sample(const lol_scene* sc, const lol_camera* cam, int w,
 
 void lol_oracle_probe_pixel(const lol_scene* sc, const lol_camera* cam, int w, int h, int max_steps,
                             int x, int y, lol_oracle_probe* out) {
-	struct tally t = { 0, 0, 0, 0 };
+	struct tally t = { 0, 0, 0, 0, 0, 0 };
 	memset(out, 0, sizeof *out);
 	shade_pixel(sc, cam, x, y, (float)w, (float)h, max_steps, &t, NULL, out, NULL, NULL, NULL, NULL);
 }
 
 float lol_oracle_sdf(const lol_scene* sc, float px, float py, float pz, uint32_t* id) {
-	struct tally t = { 0, 0, 0, 0 };
+	struct tally t = { 0, 0, 0, 0, 0, 0 };
 	struct world_dist d = sdf(sc, (v3){ px, py, pz }, &t);
 	if (id) *id = d.id;
 	return d.dist;

@@ -42,6 +42,8 @@ typedef struct lol_oracle_counters {
 	uint64_t march_steps;      /* iterations of get_intersection loop naive_renderer.c:56 */
 	uint64_t shadow_steps;     /* iterations of softshadow loop       naive_renderer.c:80 */
 	uint64_t miss_pixels;      /* id == 0 after the march */
+	uint64_t settle_violations;/* checker-side: shadow rays whose running factor was <= 0 at some step and still came out
+	                            * != 0 — the property the renderer's early exit (FLAG_SHADOW_SETTLED) rests on; must be 0 */
 } lol_oracle_counters;
 
 /* The surface's SDL_PixelFormat fields that SDL_MapRGB reads (renderer.h:17-22); NULL / default = XRGB8888.
@@ -73,8 +75,9 @@ typedef struct lol_oracle_probe {
  *   xrgb   : h rows of `pitch_bytes`; pixel (x,y) at xrgb + y*pitch + 4*x,
  *            value r<<16|g<<8|b (renderer.h:17-22 with an XRGB8888 surface)
  *   rgb    : optional w*h*3 floats, post-gamma pre-quantisation, row-major
- *   steps  : optional w*h x 8 uint16 per pixel: {march steps, shadow steps (all lights), hit id,
- *            bit mask of lights whose diffuse incidence is exactly 0, shadow steps of lights 0..3}
+ *   steps  : optional w*h x 12 uint16 per pixel: {march steps, shadow steps (all lights), hit id,
+ *            bit mask of lights whose diffuse incidence is exactly 0, shadow steps of lights 0..3,
+ *            "settled" shadow steps of lights 0..3 = steps up to and including the first that left res <= 0}
  *   ctr    : optional counters, accumulated (caller zeroes)
  */
 void lol_oracle_render_rows(const lol_scene* scene, const lol_camera* cam,

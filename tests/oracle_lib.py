@@ -14,7 +14,8 @@ ORACLE_SO = os.path.join(ROOT, "oracle", "liblol_oracle.so")
 
 class Counters(C.Structure):
     _fields_ = [("pixels", C.c_uint64), ("sdf_evals", C.c_uint64), ("node_evals", C.c_uint64),
-                ("march_steps", C.c_uint64), ("shadow_steps", C.c_uint64), ("miss_pixels", C.c_uint64)]
+                ("march_steps", C.c_uint64), ("shadow_steps", C.c_uint64), ("miss_pixels", C.c_uint64),
+                ("settle_violations", C.c_uint64)]
 
 
 class Probe(C.Structure):
@@ -92,17 +93,23 @@ def render(scene: S.Scene, w: int, h: int, max_steps: int = 256, threads: int = 
 
 def render_rows(scene: S.Scene, w: int, h: int, y0: int, y1: int, max_steps: int = 256, camera=None,
                 want_steps: bool = False):
-    """Rows [y0,y1) → (xrgb [h,w] with only those rows filled, rgb [h,w,3], steps [h,w,8] | None);
+    """Rows [y0,y1) → (xrgb [h,w] with only those rows filled, rgb [h,w,3], steps [h,w,12] | None);
     steps[..., 0] march steps, [..., 1] shadow steps summed over lights, [..., 2] hit id, [..., 3] bit mask of
-    lights with diffuse incidence exactly 0, [..., 4:8] shadow steps of lights 0..3."""
+    lights with diffuse incidence exactly 0, [..., 4:8] shadow steps of lights 0..3, [..., 8:12] their "settled"
+    shadow steps (up to and including the first step that left res <= 0)."""
     cam = camera if camera is not None else scene.c.camera
     xrgb = np.zeros((h, w), dtype=np.uint32)
     rgb = np.zeros((h, w, 3), dtype=np.float32)
-    steps = np.zeros((h, w, 8), dtype=np.uint16) if want_steps else None
+    steps = np.zeros((h, w, 12), dtype=np.uint16) if want_steps else None
+    global last_counters
+    last_counters = Counters()
     lib().lol_oracle_render_rows(scene.ptr, C.byref(cam), w, h, max_steps, y0, y1,
                                  xrgb.ctypes.data, w * 4, rgb.ctypes.data,
-                                 steps.ctypes.data if steps is not None else None, None)
+                                 steps.ctypes.data if steps is not None else None, C.byref(last_counters))
     return xrgb, rgb, steps
+
+
+last_counters = None          # the work counters of the last render_rows() call (settle_violations must stay 0)
 
 
 def probe(scene: S.Scene, w: int, h: int, x: int, y: int, max_steps: int = 256, camera=None) -> Probe:

@@ -73,15 +73,22 @@ def check_against_oracle(g, sc, w, h, max_steps=256, y0=0, y1=None, camera=None)
     y1 = h if y1 is None else y1
     ox, orgb, osteps = O.render_rows(sc, w, h, y0, y1, max_steps, camera=camera, want_steps=True)
     ox, orgb, osteps = ox[y0:y1], orgb[y0:y1], osteps[y0:y1]
+    # what the kernel's early shadow exit (skip & 4) rests on, checked by the reference arithmetic itself on these very rays:
+    # a running shadow factor that was <= 0 once never comes out != 0
+    assert O.last_counters.settle_violations == 0
     gx = g["xrgb"][:, :w]
     assert np.array_equal(g["steps"] & 0xFFFF, osteps[..., 0]), "march step counts differ"
     gsh, osh = g["steps"] >> 16, osteps[..., 1]
     skip = g.get("miss_skip", 0)
     want = osh.astype(np.int64)
-    if skip & 2:
-        # lanes whose diffuse incidence for a light is exactly 0 do not march that light's shadow ray
-        for li in range(4):
-            want = want - np.where((osteps[..., 3] >> li) & 1, osteps[..., 4 + li], 0)
+    for li in range(4):
+        full = osteps[..., 4 + li].astype(np.int64)
+        # a shadow march ends once its factor can only be 0 (skip & 4: res <= 0 — the oracle counts those steps too) ...
+        marched = osteps[..., 8 + li].astype(np.int64) if skip & 4 else full
+        # ... and lanes whose diffuse incidence for a light is exactly 0 do not march that light's shadow ray at all
+        if skip & 2:
+            marched = np.where((osteps[..., 3] >> li) & 1, 0, marched)
+        want = want - (full - marched)
     if skip & 1:
         # escaped rays never march shadows (whole waves of them skip the normal taps too)
         want = np.where(osteps[..., 2] == 0, 0, want)
@@ -238,7 +245,7 @@ def test_miss_skip_is_exact_and_conditional(torch_cuda, scenes):
     w, h = 200, 120
     r = gpu.Renderer(0)
     on = gpu_render(torch_cuda, r, sc, w, h)
-    assert on["miss_skip"] == 3 and (on["steps"][on["id"] == 0] >> 16).max() == 0
+    assert on["miss_skip"] == 7 and (on["steps"][on["id"] == 0] >> 16).max() == 0
     r.set_miss_skip(False)
     off = gpu_render(torch_cuda, r, sc, w, h)
     assert not off["miss_skip"]

@@ -59,8 +59,15 @@ def test_device_frames_equal_the_reference_composition(scenes, name, mode):
     from test_gpu_parity import gpu_render, HOST_LIBM_IS_FMA_VARIANT
     g = np.load(os.path.join(HERE, "golden", "ref_frames.npz"))
     r = gpu.Renderer(0, specialize=mode)
-    r.set_miss_skip(False)                     # march every shadow ray, so that the shadow step counts are comparable
     w, h = 64, 36
+    # production configuration first (exact skips on: fewer shadow steps, the same pixels) ...
+    d = gpu_render(torch, r, scenes[name], w, h)
+    assert d["miss_skip"] & 4, "the settled-shadow exit should be active on the example scenes"
+    assert np.array_equal(d["id"], g[f"{name}_hit_id"])
+    if HOST_LIBM_IS_FMA_VARIANT:
+        assert np.array_equal(d["rgb"].view(np.uint32), g[f"{name}_rgb"].view(np.uint32))
+        assert np.array_equal(d["xrgb"][:, :w], g[f"{name}_xrgb"])
+    r.set_miss_skip(False)                     # ... then march every shadow ray, so that the shadow step counts are comparable
     d = gpu_render(torch, r, scenes[name], w, h)
     assert np.array_equal(d["id"], g[f"{name}_hit_id"])
     assert np.array_equal(d["dist"].view(np.uint32), g[f"{name}_hit_dist"].view(np.uint32))

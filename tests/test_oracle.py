@@ -230,3 +230,21 @@ def test_max_steps_zero_and_empty_scene():
     # no objects: sdf = +inf, miss material #0, ambient * mat.ambient, gamma
     want = np.power(np.array([0.5, 0.25, 0.125], dtype=np.float32), np.float32(1 / 2.2))
     assert np.allclose(rgb[0, 0], want, atol=1e-6) and c.miss_pixels == 32
+
+
+def test_a_settled_shadow_factor_stays_settled(scenes):
+    """softshadow (naive_renderer.c:73-90) returns maxf(res, 0); once res <= 0 no later step brings it back above 0 (min
+    only lowers it, and a finite scene produces no NaN).  The renderer ends a shadow march there (FLAG_SHADOW_SETTLED);
+    the oracle counts the rays that would contradict it — none, on every example scene, several sizes, moved cameras."""
+    import bench
+    for name, sc in scenes.items():
+        for (w, h) in ((64, 36), (160, 90)):
+            _, _, ctr = O.render(sc, w, h, threads=4, want_counters=True)
+            assert ctr.settle_violations == 0, (name, w, h)
+    sc = scenes["scene4"]
+    for i in range(0, 256, 32):
+        _, _, ctr = O.render(sc, 96, 54, threads=4, camera=bench.orbit_camera(i, 256), want_counters=True)
+        assert ctr.settle_violations == 0, i
+    # the settled step counts are a prefix of the full ones, light by light
+    _, _, steps = O.render_rows(sc, 96, 54, 0, 54, want_steps=True)
+    assert (steps[..., 8:12] <= steps[..., 4:8]).all() and (steps[..., 8:12] < steps[..., 4:8]).any()
