@@ -166,6 +166,10 @@ const char* lol_gpu_kernel_name(const lol_gpu* ctx);
  * pipeline source this library was built from for "render_interp".  Profiles record it (profiles/pmc_traffic.json) so
  * that a counter figure is only ever quoted for the code it was measured on. */
 const char* lol_gpu_kernel_key(const lol_gpu* ctx);
+/* Frame ranges pushed to roctx so far by this process (LOL_GPU_ROCTX=1 marks every frame launch for
+ * `rocprofv3 --marker-trace`, the counterpart of the reference's -j/--jitdump aid); 0 when not asked for, -1 when asked
+ * for but no roctx library could be loaded (also reported once on stderr). */
+long lol_gpu_roctx_ranges(void);
 
 /*
  * Scene specialisation (the GPU analogue of the reference's tracing JIT, whose render_prepare

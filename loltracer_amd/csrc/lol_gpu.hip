@@ -25,6 +25,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <functional>
 #include <cstddef>
@@ -883,12 +884,15 @@ std::string generate_source(const lol_program& P, const FastPaths* fast, bool cu
 struct Roctx {
 	int  (*push)(const char*) = nullptr;
 	int  (*pop)() = nullptr;
+	std::atomic<long> ranges{0};        /* ranges pushed so far (lol_gpu_roctx_ranges) */
+	bool asked = false;                 /* LOL_GPU_ROCTX=1 was set */
 	std::once_flag once;
 	void init() { std::call_once(once, [this] { resolve(); }); }      /* frames may be launched from several host threads */
 	void resolve() {
 		const char* e = getenv("LOL_GPU_ROCTX");
 		if (!e || e[0] != '1') return;
-		for (const char* name : { "librocprofiler-sdk-roctx.so", "libroctx64.so" }) {
+		asked = true;
+		for (const char* name : { "librocprofiler-sdk-roctx.so", "libroctx64.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so", "/opt/rocm/lib/libroctx64.so" }) {
 			if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
 				push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
 				pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
@@ -896,14 +900,15 @@ struct Roctx {
 				push = nullptr; pop = nullptr;
 			}
 		}
+		/* asked for and not there: say so once instead of silently tracing nothing */
+		fprintf(stderr, "lol_gpu: LOL_GPU_ROCTX=1 but no roctx library could be loaded (%s): frames are not marked\n", dlerror());
 	}
 } g_roctx;
 
+unsigned long long fnv64(const void* data, size_t n);
 std::string fnv_hex(const void* data, size_t n) {
-	unsigned long long h = 0xcbf29ce484222325ull;
-	for (size_t i = 0; i < n; i++) { h ^= static_cast<const unsigned char*>(data)[i]; h *= 0x100000001b3ull; }
 	char b[20];
-	snprintf(b, sizeof b, "%016llx", h);
+	snprintf(b, sizeof b, "%016llx", fnv64(data, n));
 	return b;
 }
 
@@ -933,17 +938,33 @@ std::string disk_cache_path(const std::string& key) {
 	return dir + name;
 }
 
+/* GPU code is only ever loaded from a file this user wrote: the file and its directory must belong to the effective
+ * user and must not be writable by group or others (a shared LOL_GPU_CACHE_DIR / XDG_CACHE_HOME would otherwise let
+ * another user plant kernels), and the code object must match the checksum stored next to it. */
+bool private_to_user(const struct stat& st) { return st.st_uid == geteuid() && !(st.st_mode & (S_IWGRP | S_IWOTH)); }
+
+unsigned long long fnv64(const void* data, size_t n) {
+	unsigned long long h = 0xcbf29ce484222325ull;
+	for (size_t i = 0; i < n; i++) { h ^= static_cast<const unsigned char*>(data)[i]; h *= 0x100000001b3ull; }
+	return h;
+}
+
 bool disk_cache_load(const std::string& key, std::vector<char>& code) {
 	const std::string path = disk_cache_path(key);
 	if (path.empty()) return false;
+	struct stat dir_st, file_st;
+	const std::string dir = path.substr(0, path.rfind('/'));
+	if (stat(dir.c_str(), &dir_st) != 0 || !S_ISDIR(dir_st.st_mode) || !private_to_user(dir_st)) return false;
 	FILE* f = fopen(path.c_str(), "rb");
 	if (!f) return false;
 	bool ok = false;
-	unsigned long long klen = 0, clen = 0;
-	if (fread(&klen, 8, 1, f) == 1 && fread(&clen, 8, 1, f) == 1 && klen == key.size() && clen > 0 && clen < (1ull << 28)) {
+	unsigned long long klen = 0, clen = 0, sum = 0;
+	if (fstat(fileno(f), &file_st) == 0 && S_ISREG(file_st.st_mode) && private_to_user(file_st) &&
+	    fread(&klen, 8, 1, f) == 1 && fread(&clen, 8, 1, f) == 1 && fread(&sum, 8, 1, f) == 1 &&
+	    klen == key.size() && clen > 0 && clen < (1ull << 28)) {
 		std::string k(klen, 0);
 		code.resize(clen);
-		ok = fread(&k[0], 1, klen, f) == klen && k == key && fread(code.data(), 1, clen, f) == clen;
+		ok = fread(&k[0], 1, klen, f) == klen && k == key && fread(code.data(), 1, clen, f) == clen && fnv64(code.data(), clen) == sum;
 	}
 	fclose(f);
 	return ok;
@@ -957,9 +978,10 @@ void disk_cache_store(const std::string& key, const std::vector<char>& code) {
 	const std::string t = path + tmp;
 	FILE* f = fopen(t.c_str(), "wb");
 	if (!f) return;
-	const unsigned long long klen = key.size(), clen = code.size();
-	const bool ok = fwrite(&klen, 8, 1, f) == 1 && fwrite(&clen, 8, 1, f) == 1 && fwrite(key.data(), 1, klen, f) == klen &&
-	                fwrite(code.data(), 1, clen, f) == clen;
+	(void)fchmod(fileno(f), 0600);
+	const unsigned long long klen = key.size(), clen = code.size(), sum = fnv64(code.data(), code.size());
+	const bool ok = fwrite(&klen, 8, 1, f) == 1 && fwrite(&clen, 8, 1, f) == 1 && fwrite(&sum, 8, 1, f) == 1 &&
+	                fwrite(key.data(), 1, klen, f) == klen && fwrite(code.data(), 1, clen, f) == clen;
 	if (fclose(f) != 0 || !ok || rename(t.c_str(), path.c_str()) != 0) (void)remove(t.c_str());
 }
 
@@ -969,32 +991,8 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
 	if (src_out) *src_out = src;
 	int rtc_major = 0, rtc_minor = 0;
 	(void)hiprtcVersion(&rtc_major, &rtc_minor);
-	std::string key = "lol_gpu/2|hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) + "|" + arch + "|" +
-	                  (getenv("LOL_GPU_RTC_FLAGS") ? getenv("LOL_GPU_RTC_FLAGS") : "") + "|" +
-	                  (getenv("LOL_GPU_SCHED") ? getenv("LOL_GPU_SCHED") : "") + "|";
-	if (shape) key += std::to_string(shape[0]) + "x" + std::to_string(shape[1]) + "x" + std::to_string(shape[2]);
-	key += "|" + src;
-	{
-		std::lock_guard<std::mutex> lock(g_cache_mutex);
-		auto it = g_code_cache.find(key);
-		if (it != g_code_cache.end()) { code = it->second; log.clear(); return true; }
-	}
-	/* on disk the pipeline source (lol_kernel.h, embedded in this library) is part of the key: another build of the
-	 * library must not pick up this one's kernels */
-	const std::string disk_key = key + "|" + LOL_KERNEL_H_TEXT;
-	if (disk_cache_load(disk_key, code)) {
-		std::lock_guard<std::mutex> lock(g_cache_mutex);
-		g_code_cache[key] = code;
-		log = "(code object from the disk cache)";
-		return true;
-	}
-	const char* hdr_src[] = { LOL_KERNEL_H_TEXT };
-	const char* hdr_name[] = { "lol_kernel.h" };
-	hiprtcProgram prog = nullptr;
-	if (hiprtcCreateProgram(&prog, src.c_str(), "lol_render_spec.hip", 1, hdr_src, hdr_name) != HIPRTC_SUCCESS) {
-		log = "hiprtcCreateProgram failed";
-		return false;
-	}
+	/* the option list first: it is part of the cache key (a changed flag — -ffp-contract above all — must never be served
+	 * a code object compiled under the old one) */
 	std::string arch_opt = "--offload-arch=" + arch;
 	/* -ffp-contract=off: no FMA contraction (the reference has none); the rest are hipcc's defaults made explicit */
 	std::vector<std::string> extra;                     /* LOL_GPU_RTC_FLAGS: extra hipRTC options, for tuning experiments */
@@ -1031,6 +1029,31 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
 		opts.push_back(d0); opts.push_back(d1); opts.push_back(d2);
 	}
 	for (auto& x : extra) opts.push_back(x.c_str());
+	std::string key = "lol_gpu/3|hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) + "|";
+	for (const char* o : opts) { key += o; key += ' '; }
+	key += "|" + src;
+	{
+		std::lock_guard<std::mutex> lock(g_cache_mutex);
+		auto it = g_code_cache.find(key);
+		if (it != g_code_cache.end()) { code = it->second; log.clear(); return true; }
+	}
+	/* on disk the pipeline source (lol_kernel.h, embedded in this library) is part of the key: another build of the
+	 * library must not pick up this one's kernels */
+	const std::string disk_key = key + "|" + LOL_KERNEL_H_TEXT;
+	if (disk_cache_load(disk_key, code)) {
+		std::lock_guard<std::mutex> lock(g_cache_mutex);
+		g_code_cache[key] = code;
+		log = "(code object from the disk cache)";
+		return true;
+	}
+	const char* hdr_src[] = { LOL_KERNEL_H_TEXT };
+	const char* hdr_name[] = { "lol_kernel.h" };
+	hiprtcProgram prog = nullptr;
+	if (hiprtcCreateProgram(&prog, src.c_str(), "lol_render_spec.hip", 1, hdr_src, hdr_name) != HIPRTC_SUCCESS) {
+		log = "hiprtcCreateProgram failed";
+		return false;
+	}
+	bool options_dropped = false;
 	hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
 	if (r != HIPRTC_SUCCESS) {
 		/* a hipRTC that does not know the scheduling option must not cost the specialisation: once more without it */
@@ -1068,7 +1091,7 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
 		std::lock_guard<std::mutex> lock(g_cache_mutex);
 		g_code_cache[key] = code;
 	}
-	disk_cache_store(disk_key, code);
+	if (!options_dropped) disk_cache_store(disk_key, code);
 	return true;
 }
 
@@ -1407,6 +1430,7 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 		char label[96];
 		snprintf(label, sizeof label, "lol frame %dx%d rows=%d band=%d@%d/%d %s", w, h, n_rows, R->band_rows, R->offset_rows, R->cycle_rows, ctx->kernel_name);
 		g_roctx.push(label);
+		g_roctx.ranges++;
 	}
 	if (ctx->spec_fn) {
 		void* args[] = { &L };
@@ -1590,6 +1614,11 @@ int lol_gpu_memcpy_d2h(lol_gpu* ctx, void* host, const void* dev, size_t bytes) 
 }
 
 const char* lol_gpu_kernel_name(const lol_gpu* ctx) { return ctx ? ctx->kernel_name : ""; }
+
+long lol_gpu_roctx_ranges(void) {
+	g_roctx.init();
+	return g_roctx.asked && !g_roctx.push ? -1 : g_roctx.ranges.load();
+}
 
 const char* lol_gpu_kernel_key(const lol_gpu* ctx) {
 	static const std::string aot = fnv_hex(LOL_KERNEL_H_TEXT, sizeof LOL_KERNEL_H_TEXT);

@@ -115,6 +115,8 @@ def gpu_lib() -> C.CDLL:
         lib.lol_gpu_set_pixel_format.restype = C.c_int
         lib.lol_gpu_kernel_key.argtypes = [vp]
         lib.lol_gpu_kernel_key.restype = C.c_char_p
+        lib.lol_gpu_roctx_ranges.argtypes = []
+        lib.lol_gpu_roctx_ranges.restype = C.c_long
         lib.lol_gpu_sync.argtypes = [vp]
         lib.lol_gpu_sync.restype = C.c_int
         lib.lol_gpu_malloc.argtypes = [vp, C.c_size_t, P(vp)]
@@ -209,7 +211,7 @@ EXPORTED_SYMBOLS = [
     "lol_gpu_multi_malloc", "lol_gpu_multi_free", "lol_gpu_multi_memcpy_d2h", "lol_gpu_assemble_parts",
     "lol_gpu_multi_set_parts_per_device", "lol_gpu_multi_set_host_via_root",
     "lol_gpu_set_pixel_format",
-    "lol_gpu_render_host_pending_size", "lol_gpu_render_host_discard", "lol_gpu_kernel_key",
+    "lol_gpu_render_host_pending_size", "lol_gpu_render_host_discard", "lol_gpu_kernel_key", "lol_gpu_roctx_ranges",
     "lol_gpu_assemble_parts_at", "lol_gpu_split_rows", "lol_gpu_multi_set_root_band_rows",
     "lol_gpu_multi_set_pixel_format",
 ]

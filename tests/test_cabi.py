@@ -103,4 +103,23 @@ def test_code_objects_are_cached_on_disk(tmp_path, scenes):
         f.write(b"XXXX")
     assert "disk cache" not in run(cache)                         # recompiled, and the entry rewritten
     assert "disk cache" in run(cache)
-    assert "disk cache" not in run("")                            # switched off
+    # a code object whose bytes were changed (the stored checksum no longer matches) is not loaded either
+    path = os.path.join(cache, os.listdir(cache)[0])
+    with open(path, "r+b") as f:
+        f.seek(-9, os.SEEK_END)
+        f.write(b"\x00\x01")
+    assert "disk cache" not in run(cache)
+    assert "disk cache" in run(cache)
+    # GPU code is only taken from files and directories that are this user's alone
+    os.chmod(os.path.join(cache, os.listdir(cache)[0]), 0o666)
+    assert "disk cache" not in run(cache)                         # a file others may write: ignored (and replaced)
+    assert "disk cache" in run(cache)
+    os.chmod(cache, 0o777)
+    assert "disk cache" not in run(cache)                         # a directory others may write: never read from
+    os.chmod(cache, 0o700)
+    assert "disk cache" in run(cache)
+    # the options hipRTC is given are part of the key: another flag set is another kernel
+    env_flags = dict(os.environ, LOL_GPU_CACHE_DIR=cache, LOL_GPU_RTC_FLAGS="-DLOL_SOMETHING=1")
+    p = subprocess.run([sys.executable, "-c", code], env=env_flags, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "disk cache" not in p.stdout
+    assert "disk cache" not in run("")                            # switched off: compiles, writes nothing

@@ -315,3 +315,34 @@ def test_kernel_key_names_the_code(torch_cuda, scenes):
     ri.prepare(scenes["scene4"])
     assert len(ri.kernel_key()) == 16 and ri.kernel_key() != k4
     r.close(); ri.close()
+
+
+ROCTX_SCRIPT = r"""
+import sys
+sys.path.insert(0, {root!r})
+import numpy as np
+from loltracer_amd import gpu, scene as S
+lib = gpu.gpu_lib()
+before = lib.lol_gpu_roctx_ranges()
+r = gpu.Renderer(0)
+r.prepare(S.Scene.parse_file({scene!r}))
+buf = np.zeros((36, 64), dtype=np.uint32)
+for _ in range(3):
+    r.render_host(buf.ctypes.data, 64, 36)
+print("ranges", before, lib.lol_gpu_roctx_ranges(), int(buf.any()))
+"""
+
+
+@pytest.mark.gpu
+def test_roctx_ranges_mark_every_frame_when_asked_for():
+    """LOL_GPU_ROCTX=1 (the counterpart of the reference's -j/--jitdump aid): the roctx library resolves and
+    every frame launch pushes a range; without the variable nothing is loaded and nothing is pushed."""
+    import sys
+    for env_value, want in (("1", 3), (None, 0)):
+        env = {k: v for k, v in os.environ.items() if k != "LOL_GPU_ROCTX"}
+        if env_value:
+            env["LOL_GPU_ROCTX"] = env_value
+        p = subprocess.run([sys.executable, "-c", ROCTX_SCRIPT.format(root=ROOT, scene=SCENE4)], env=env, capture_output=True,
+                           text=True, timeout=180)
+        assert p.returncode == 0, p.stderr[-2000:]
+        assert f"ranges 0 {want} 1" in p.stdout, (p.stdout, p.stderr[-500:])
