@@ -191,6 +191,9 @@ const char* lol_gpu_specialize_log(const lol_gpu* ctx);
 /* sqrt_mismatches[0..2] = sqrt_pm, sqrt_gs, sqrt_r2 (lol_kernel.h); div_mismatches for the divisor k */
 int         lol_gpu_verify_fast_paths(lol_gpu* ctx, float k, unsigned long long sqrt_mismatches[3],
                                       unsigned long long* div_mismatches);
+/* The same exhaustive run for the blend factor WITHOUT its v_div_fixup_f32 (lol_kernel.h, smin_h_fast<false>): inputs on
+ * which it differs from the exact factor, or — for dlt = +-inf — fails to make the smooth minimum NaN.  0 = proven. */
+int         lol_gpu_verify_smin_no_fixup(lol_gpu* ctx, float k, unsigned long long* mismatches);
 /*
  * Escaped rays are shaded with material #0 (naive_renderer.c:103-112).  When that material has
  * diffuse == specular == 0, shininess >= 0 and all light intensities are finite, their colour is exactly

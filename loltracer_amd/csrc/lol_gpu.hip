@@ -86,7 +86,8 @@ struct lol_gpu {
 	int          interp_sqrt_kind = 0;   /* fast sqrt of the interpreter: 3 (sqrt_r2) when proven and allowed, else 0 */
 	int          sqrt_verified = -1;     /* -1 not run, 0 none proven, else the lol::sqrt_fast KIND proven on this device */
 	bool         sqrt_tiny_ok = false;   /* the second counter of that run was 0 too (sd_sphere_fast_nr) */
-	std::vector<std::pair<uint32_t, bool>> div_verified;   /* k bits → proven */
+	struct DivProof { uint32_t k_bits; bool ok, no_fixup_ok; };
+	std::vector<DivProof> div_verified;  /* per smoothness constant: smin_h_fast proven / proven without v_div_fixup too */
 	unsigned long long* d_bad = nullptr; /* mismatch counter of the verification kernels */
 	int          wave_w = LOL_WAVE_W, wave_h = LOL_WAVE_H, waves_x = LOL_WAVES_X;   /* footprint of the spec kernel */
 	char         err[512] = { 0 };
@@ -230,16 +231,23 @@ float smooth_sat_threshold(float k) {
 
 __global__ __launch_bounds__(VERIFY_THREADS) void verify_div_kernel(float k, float k2, float hrk, float ks, unsigned long long* bad) {
 	uint32_t base = blockIdx.x * VERIFY_THREADS + threadIdx.x;
-	unsigned n = 0;
+	unsigned n = 0, m = 0;
 	for (uint32_t it = 0; it < VERIFY_ITERS; it++) {
 		float x = __builtin_bit_cast(float, base + it * (VERIFY_BLOCKS * VERIFY_THREADS));
 		const float h = lol::smin_h_exact(x, k);
 		if (!same_float(lol::smin_h_fast(x, k2, hrk), h)) n++;
+		/* third counter — the same without v_div_fixup (smin_h_fast<false>): equal for every finite dlt and for NaN; for
+		 * dlt = +-inf the smooth minimum built on it must come out NaN (it does whenever the quotient is NaN: h clamps to
+		 * +0 and b - inf * 0 is NaN) */
+		const uint32_t xb = __builtin_bit_cast(uint32_t, x) & 0x7fffffffu;
+		if (xb != lol::F32_INF_BITS) { if (!same_float(lol::smin_h_fast<false>(x, k2, hrk), h)) m++; }
+		else { const float v = lol::sminf_fastdiv<false>(0.f - x, 0.f, k, k2, hrk); if (!(v != v)) m++; }
 		/* what sminf_fastdiv_sat relies on (ks > 0 only): saturated inputs have h == 1 / h == +0 exactly */
 		if (ks > 0.f && x >= ks && __builtin_bit_cast(uint32_t, h) != 0x3f800000u) n++;
 		if (ks > 0.f && x <= -ks && __builtin_bit_cast(uint32_t, h) != 0u) n++;
 	}
 	if (n) atomicAdd(bad, (unsigned long long)n);
+	if (m) atomicAdd(bad + 1, (unsigned long long)m);
 }
 
 /* diagnostic: out[i] = powf_glibc(x[i], y[i]) — lets the tests compare the device's powf with the CPU's */
@@ -280,8 +288,13 @@ struct FastPaths {
 	int sqrt_kind = 0;                    /* 0 plain sqrtf; 1 sqrt_pm, 2 sqrt_gs, 3 sqrt_r2 — proven on this device */
 	bool sqrt_tiny_ok = false;            /* ... and NaN-or-tiny below its domain: spheres may drop the range tracker (sd_sphere_fast_nr) */
 	std::vector<float> div_ok;            /* smoothness constants k whose smin_h_fast verified */
+	std::vector<float> div_nf_ok;         /* ... and verified without v_div_fixup as well (smin_h_fast<false>) */
 	bool has(float k) const {
 		for (float v : div_ok) if (memcmp(&v, &k, 4) == 0) return true;
+		return false;
+	}
+	bool has_nf(float k) const {
+		for (float v : div_nf_ok) if (memcmp(&v, &k, 4) == 0) return true;
 		return false;
 	}
 };
@@ -740,6 +753,10 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 			/* LOL_OP_SMIN / LOL_OP_SMIN_R */
 			const float ks = smooth_sat_threshold(o.f[0]);
 			const bool proven = fast && fast->has(o.f[0]);
+			/* without v_div_fixup where that is proven too; such an object's value is then voted on for NaN (an infinite
+			 * operand difference — lol_kernel.h, smin_h_fast) like one with spheres that carry no range tracker */
+			const char* fx = proven && fast->has_nf(o.f[0]) ? "<false>" : "";
+			if (fx[0]) object_has_nr = true;
 			/* the arithmetic shortcut only where the SDF is inlined: in the out-of-line function its four-way branching
 			 * costs more than it saves (504-op chain: 100 -> 42 Mpixels/s) */
 			const bool sat_arith = smin_sat && (!out_of_line || (getenv("LOL_GPU_SMIN_SAT") && atoi(getenv("LOL_GPU_SMIN_SAT")) == 2)) && ks > 0.f;
@@ -763,11 +780,11 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 				s += line;
 				const int a = emit_node(n.a);
 				if (sat_arith)
-					snprintf(line, sizeof line, "\t\t  t%d = sminf_fastdiv_sat(t%d, t%d, %s, %s, %s, %s, care);\n\t\t  } else t%d = t%d + 0.f;\n\t\t}\n",
-					         r, a, b, kk.c_str(), k2.c_str(), hrk.c_str(), kss.c_str(), r, b);
+					snprintf(line, sizeof line, "\t\t  t%d = sminf_fastdiv_sat%s(t%d, t%d, %s, %s, %s, %s, care);\n\t\t  } else t%d = t%d + 0.f;\n\t\t}\n",
+					         r, fx, a, b, kk.c_str(), k2.c_str(), hrk.c_str(), kss.c_str(), r, b);
 				else
-					snprintf(line, sizeof line, "\t\t  t%d = sminf_fastdiv(t%d, t%d, %s, %s, %s);\n\t\t  } else t%d = t%d + 0.f;\n\t\t}\n",
-					         r, a, b, kk.c_str(), k2.c_str(), hrk.c_str(), r, b);
+					snprintf(line, sizeof line, "\t\t  t%d = sminf_fastdiv%s(t%d, t%d, %s, %s, %s);\n\t\t  } else t%d = t%d + 0.f;\n\t\t}\n",
+					         r, fx, a, b, kk.c_str(), k2.c_str(), hrk.c_str(), r, b);
 				s += line;
 				return r;
 			}
@@ -776,10 +793,10 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 			const int first = emit_node(a_first ? n.a : n.b), second = emit_node(a_first ? n.b : n.a);
 			const int a = a_first ? first : second, b = a_first ? second : first;
 			if (proven && sat_arith)
-				snprintf(line, sizeof line, "\t\tconst float t%d = sminf_fastdiv_sat(t%d, t%d, %s, %s, %s, %s, care);\n", t, a, b,
+				snprintf(line, sizeof line, "\t\tconst float t%d = sminf_fastdiv_sat%s(t%d, t%d, %s, %s, %s, %s, care);\n", t, fx, a, b,
 				         kk.c_str(), k2.c_str(), hrk.c_str(), kss.c_str());
 			else if (proven)
-				snprintf(line, sizeof line, "\t\tconst float t%d = sminf_fastdiv(t%d, t%d, %s, %s, %s);\n", t, a, b, kk.c_str(), k2.c_str(), hrk.c_str());
+				snprintf(line, sizeof line, "\t\tconst float t%d = sminf_fastdiv%s(t%d, t%d, %s, %s, %s);\n", t, fx, a, b, kk.c_str(), k2.c_str(), hrk.c_str());
 			else
 				snprintf(line, sizeof line, "\t\tconst float t%d = sminf_(t%d, t%d, %s);\n", t, a, b, kk.c_str());
 			s += line; return t++;
@@ -1114,14 +1131,18 @@ FastPaths prove_fast_paths(lol_gpu* ctx, const lol_program& prog) {
 		if (o.op != LOL_OP_SMIN && o.op != LOL_OP_SMIN_R) continue;
 		uint32_t kb;
 		memcpy(&kb, &o.f[0], 4);
-		bool known = false, ok = false;
-		for (auto& e : ctx->div_verified) if (e.first == kb) { known = true; ok = e.second; }
+		bool known = false, ok = false, nf = false;
+		for (auto& e : ctx->div_verified) if (e.k_bits == kb) { known = true; ok = e.ok; nf = e.no_fixup_ok; }
 		if (!known) {
 			/* |k| >= 2^-100: see sminf_fastdiv (lol_kernel.h); then the exhaustive proof of the blend factor */
-			ok = (o.f[0] >= 0x1p-100f || o.f[0] <= -0x1p-100f) && run_verify(ctx, 0, o.f[0]) == 0;
-			ctx->div_verified.emplace_back(kb, ok);
+			unsigned long long nf_bad = 1;
+			ok = (o.f[0] >= 0x1p-100f || o.f[0] <= -0x1p-100f) && run_verify(ctx, 0, o.f[0], &nf_bad) == 0;
+			nf = ok && nf_bad == 0;
+			ctx->div_verified.push_back({ kb, ok, nf });
 		}
 		if (ok && !fast.has(o.f[0])) fast.div_ok.push_back(o.f[0]);
+		/* LOL_GPU_SMIN_FIXUP=1: keep v_div_fixup in every blend factor (A/B runs) */
+		if (nf && !fast.has_nf(o.f[0]) && !(getenv("LOL_GPU_SMIN_FIXUP") && getenv("LOL_GPU_SMIN_FIXUP")[0] == '1')) fast.div_nf_ok.push_back(o.f[0]);
 	}
 	return fast;
 }
@@ -1147,7 +1168,8 @@ bool specialise(lol_gpu* ctx) {
 	std::string note;
 	{
 		char b[160];
-		snprintf(b, sizeof b, "fast paths proven on device: sqrt=%d, smin divisors=%zu\n", fast.sqrt_kind, fast.div_ok.size());
+		snprintf(b, sizeof b, "fast paths proven on device: sqrt=%d, smin divisors=%zu (without div_fixup: %zu)\n", fast.sqrt_kind,
+		         fast.div_ok.size(), fast.div_nf_ok.size());
 		note = b;
 	}
 	std::vector<char> code;
@@ -1297,6 +1319,16 @@ int lol_gpu_verify_fast_paths(lol_gpu* ctx, float k, unsigned long long sqrt_mis
 	if (sqrt_mismatches)
 		for (int kind = 1; kind <= 3; kind++) sqrt_mismatches[kind - 1] = run_verify(ctx, kind, 0.f);
 	if (div_mismatches) *div_mismatches = run_verify(ctx, 0, k);
+	return LOL_GPU_OK;
+}
+
+/* ... and for the blend factor without v_div_fixup (smin_h_fast<false>): inputs on which it differs from the exact
+ * factor (finite and NaN dlt) or fails to turn the smooth minimum NaN (dlt = +-inf); 0 = proven, ~0 = could not run */
+int lol_gpu_verify_smin_no_fixup(lol_gpu* ctx, float k, unsigned long long* mismatches) {
+	if (!ctx || !mismatches) return LOL_GPU_ERR_ARG;
+	LOL_HIP(ctx, hipSetDevice(ctx->device));
+	unsigned long long second = ~0ull;
+	*mismatches = run_verify(ctx, 0, k, &second) == ~0ull ? ~0ull : second;
 	return LOL_GPU_OK;
 }
 
@@ -1672,7 +1704,7 @@ int lol_gpu_compile_offline(const lol_program* prog, const char* arch, const cha
 		fast.sqrt_tiny_ok = true;
 		for (uint32_t i = 0; i < prog->n_ops; i++)
 			if ((prog->ops[i].op == LOL_OP_SMIN || prog->ops[i].op == LOL_OP_SMIN_R) && !fast.has(prog->ops[i].f[0]))
-				fast.div_ok.push_back(prog->ops[i].f[0]);
+				{ fast.div_ok.push_back(prog->ops[i].f[0]); fast.div_nf_ok.push_back(prog->ops[i].f[0]); }
 	}
 	bool ok = compile_spec(*prog, &fast, arch, code, lg, &src, nullptr, culling_enabled(1));
 	if (log && logcap) snprintf(log, logcap, "%s", lg.c_str());

@@ -358,20 +358,27 @@ template <int KIND> __device__ __forceinline__ float sqrt_fast(float x) {
  * instructions instead of the 11 of a correctly rounded division (the .5f multiply folds away too).
  * smin_h_fast is what gets proven equal to smin_h_exact over all 2^32 values of dlt, per k. */
 __device__ __forceinline__ float smin_h_exact(float dlt, float k) { return clampf_(.5f + .5f * dlt / k, 0.f, 1.f); }
+/* FIXUP = false leaves v_div_fixup_f32 out (a half-rate instruction at the end of every blend factor's dependent chain).
+ * Used where the device has shown, again for every float dlt and per k, that the clamped factor is the same without it
+ * for every FINITE dlt and that the quotient is NaN for dlt = +-inf.  An infinite dlt makes the smooth minimum NaN in
+ * either form unless one OPERAND is -inf — and then this form's NaN reaches the object's value, where the generated code
+ * votes on it (like for a sphere without range tracker): that wave shades again through the plain path. */
+template <bool FIXUP = true>
 __device__ __forceinline__ float smin_h_fast(float dlt, float k2, float hrk) {
 	float q = dlt * hrk;
 	float r = __builtin_fmaf(-q, k2, dlt);
 	q = __builtin_fmaf(r, hrk, q);
-	q = __builtin_amdgcn_div_fixupf(q, k2, dlt);
+	if (FIXUP) q = __builtin_amdgcn_div_fixupf(q, k2, dlt);
 	return clampf_(.5f + q, 0.f, 1.f);
 }
 /* sminf (float.h:29-33) with the proven blend factor.  lerp(b, a, h) = b + (a - b)*h is written b - (b - a)*h:
  * a - b and b - a are exact negatives of each other unless a == b with equal signs, where h = .5 and the two
  * forms can only differ in the sign of a zero sum (a == b == -0) that the subtraction of k*h*(1-h) = k/4 != 0
  * then erases — lol_gpu.hip uses this form only for |k| >= 2^-100 so that k/4 is a non-zero normal number. */
+template <bool FIXUP = true>
 __device__ __forceinline__ float sminf_fastdiv(float a, float b, float k, float k2, float hrk) {
 	float dlt = b - a;
-	float h = smin_h_fast(dlt, k2, hrk);
+	float h = smin_h_fast<FIXUP>(dlt, k2, hrk);
 	return (b - dlt * h) - k * h * (1.f - h);
 }
 
@@ -383,6 +390,7 @@ __device__ __forceinline__ float sminf_fastdiv(float a, float b, float k, float 
  * WAVE — when every lane that still cares is saturated — so it costs one compare and a scalar branch where it does
  * not apply: two spheres more than k apart in distance is the common case away from the seams of a blob
  * (scene4 C3: +8.7 %).  NaN dlt is never saturated. */
+template <bool FIXUP = true>
 __device__ __forceinline__ float sminf_fastdiv_sat(float a, float b, float k, float k2, float hrk, float ks, u64 care) {
 	const float dlt = b - a;
 	if ((vote(!(__builtin_fabsf(dlt) >= ks)) & care) == 0) {
@@ -391,7 +399,7 @@ __device__ __forceinline__ float sminf_fastdiv_sat(float a, float b, float k, fl
 		const float r0 = b - dlt * 0.f;
 		return dlt > 0.f ? r1 : r0;
 	}
-	const float h = smin_h_fast(dlt, k2, hrk);
+	const float h = smin_h_fast<FIXUP>(dlt, k2, hrk);
 	return (b - dlt * h) - k * h * (1.f - h);
 }
 

@@ -218,8 +218,13 @@ def test_fast_paths_are_proven_exhaustively(torch_cuda, scenes):
         sq, dv = r.verify_fast_paths(k)
         assert sq == [0, 0, 0], f"sqrt_pm / sqrt_gs / sqrt_r2 differ from sqrtf on {sq} inputs"
         assert dv == 0, f"smooth-min division by {k} differs on {dv} inputs"
+    # the blend factor without its v_div_fixup: proven for the smoothness constants the example scenes use; where it is
+    # not (the count says on how many inputs) the generated code keeps the fix-up
+    for k in (3.0, 1.0, 0.5, 7.5):
+        print("no-fixup mismatches for k =", k, r.verify_smin_no_fixup(k))
+    assert r.verify_smin_no_fixup(3.0) == 0
     r.prepare(scenes["scene4"])
-    assert "sqrt=3, smin divisors=1" in r.specialize_log()
+    assert "sqrt=3, smin divisors=1 (without div_fixup: 1)" in r.specialize_log()
     r.close()
 
 
