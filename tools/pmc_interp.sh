@@ -1,5 +1,5 @@
 # PMC passes of the interpreter kernel on C3 (LOL_GPU_SPECIALIZE=0 makes bench.py time render_interp); outputs under gpurun_out/<name>
-export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-pmc_interp2}; mkdir -p $O; cd /tmp
+export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:?run on the GPU box}; O=$R/gpurun_out/${1:-pmc_interp2}; mkdir -p $O; cd /tmp
 export LOL_GPU_SPECIALIZE=0
 BP="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
 timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES --kernel-trace --output-format csv -d $O/sq -- $BP > $O/sq.log 2>&1 || exit 1
