@@ -1511,7 +1511,7 @@ static int ensure_copy_stream(lol_gpu* ctx) {
  * calls, and it is never registered with the device by this library — the HIP runtime pins the pages of a copy's
  * destination for the duration of that copy by itself and reaches PCIe line rate that way (56 GB/s into plain malloc'd
  * memory on MI355X, the same as into hipHostRegister'd memory: tools/d2h_bench.hip, profiles/r3_d2h_routes.jsonl).
- * So one frame costs kernel + copy here (C3: 1.45 + 0.59 + 0.1 ms); a host that can give the next camera early hides the
+ * So one frame costs kernel + copy here (C3: 1.09 + 0.59 + 0.1 ms); a host that can give the next camera early hides the
  * copy completely with lol_gpu_render_host_begin / _end below.  Two ways to hide it inside ONE call were built in round 3,
  * measured and removed (profiles/r3_host_surface_routes.md):
  *  - the surface registered once by address (hipHostRegister) and the kernel storing straight into it: +27 % per frame,
