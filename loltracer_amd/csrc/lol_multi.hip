@@ -493,9 +493,13 @@ struct Split {
 static int split_frame(lol_gpu_multi* m, int h, Split& S) {
 	S.n_parts = m->n * m->per_dev;
 	const int band = m->band_override > 0 ? m->band_override : lol_gpu_choose_band_rows(h, S.n_parts);
-	/* the root's lighter bands only when there is someone else to take the rest */
-	const int root_band = m->n > 1 ? m->root_band : 0;
-	if (lol_gpu_split_rows(S.n_parts, band, root_band, m->n, S.rows) != LOL_GPU_OK || !table_from_rows(S.tab, S.rows, S.n_parts))
+	/* the root's lighter bands only when there is someone else to take the rest.  (LOL_GPU_MULTI_TEST_ROOT_STRIDE=k, a test
+	 * hook: every k-th PART gets the root's band height even on one device, so that a one-GPU box runs unequal bands
+	 * through this very path — split, launches, exchange, assembly, host copies; tests/test_multi_device.py.) */
+	int root_band = m->n > 1 ? m->root_band : 0, root_stride = m->n;
+	if (const char* e = getenv("LOL_GPU_MULTI_TEST_ROOT_STRIDE"))
+		if (atoi(e) > 1 && m->root_band > 0) { root_band = m->root_band; root_stride = atoi(e); }
+	if (lol_gpu_split_rows(S.n_parts, band, root_band, root_stride, S.rows) != LOL_GPU_OK || !table_from_rows(S.tab, S.rows, S.n_parts))
 		return mfail(m, LOL_GPU_ERR_ARG, "bad row partition");
 	uint32_t row = 0;
 	for (int d = 0; d < m->n; d++) {

@@ -214,6 +214,39 @@ def test_host_surface_with_several_parts_per_device(scenes, parts, band, w, h, v
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("w,h,parts,band,root,stride", [(640, 360, 8, 12, 10, 8), (333, 181, 6, 8, 5, 3), (1280, 720, 8, 16, 15, 8)])
+def test_unequal_bands_through_the_multi_device_path(scenes, monkeypatch, w, h, parts, band, root, stride):
+    """The root's lighter bands (lol_gpu_multi_set_root_band_rows) need a second device to mean anything; the test hook
+    LOL_GPU_MULTI_TEST_ROOT_STRIDE gives every stride-th PART of ONE device the root's band height instead, so that bands of
+    unequal height go through the real split, the per-part launches, the RCCL exchange, the assembly kernel and the strided
+    host copies: device-resident frame and host surface equal the single-launch frame."""
+    import torch
+    monkeypatch.setenv("LOL_GPU_MULTI_TEST_ROOT_STRIDE", str(stride))
+    single = gpu.Renderer(0)
+    single.prepare(scenes["scene4"])
+    want = _frame(single, torch, w, h).cpu().numpy().view(np.uint32)
+    m = gpu.MultiRenderer([0])
+    m.prepare(scenes["scene4"])
+    m.set_parts_per_device(parts)
+    m.set_band_rows(band)
+    m.set_root_band_rows(root)
+    got = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(2):                                          # both buffer slots
+        m.render_into(got.data_ptr(), w, h)
+        m.sync()
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), want)
+    for via_root in (False, True):
+        m.set_host_via_root(via_root)
+        pitch = (w + 5) * 4
+        host = np.full((h, pitch // 4), 0xDEADBEEF, dtype=np.uint32)
+        m.render_host(host.ctypes.data, w, h, pitch_bytes=pitch)
+        assert np.array_equal(host[:, :w], want) and (host[:, w:] == 0xDEADBEEF).all()
+    m.close()
+    single.close()
+
+
+@pytest.mark.gpu
 def test_duplicate_devices_are_refused():
     with pytest.raises(gpu.GpuError) as e:
         gpu.MultiRenderer([0, 0])
