@@ -44,3 +44,33 @@ def test_world_size_mismatch_is_refused():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr
+
+
+def test_pmc_traffic_is_only_quoted_for_the_code_it_was_measured_on():
+    """roofline.traffic comes from profiles/pmc_traffic.json, which records lol_gpu_kernel_key() of the kernel the counters were
+    collected on: another key, workload or launch size gets null and a reason, never a stale figure."""
+    import json
+    rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
+    for kernel, r in rec.items():
+        assert r["kernel_key"] and len(r["kernel_key"]) == 16 and min(r["dispatches_per_counter"].values()) >= 100
+        got, why = bench.pmc_traffic(kernel, r["workload"], r["pixels_per_launch"], r["kernel_key"])
+        assert got == r["traffic_bytes"] and abs(got / r["algorithmic_bytes"] - 1) < 0.02
+        assert bench.pmc_traffic(kernel, r["workload"], r["pixels_per_launch"], "0" * 16)[0] is None
+        assert "another" in bench.pmc_traffic(kernel, "c2", r["pixels_per_launch"], r["kernel_key"])[1]
+        assert bench.pmc_traffic(kernel, r["workload"], 1234, r["kernel_key"])[0] is None
+    assert bench.pmc_traffic("no_such_kernel", "c3", 1, "x")[0] is None
+    # the two kernels' passes are different files (round 2's interpreter CSVs were copies of the specialised kernel's)
+    spec, interp = rec["lol_render_spec"], rec["render_interp"]
+    assert spec["counters_avg_per_dispatch"]["SQ_INSTS_SALU"] != interp["counters_avg_per_dispatch"]["SQ_INSTS_SALU"]
+
+
+def test_root_share_candidates_are_one_launch_splits():
+    from loltracer_amd import multi
+    for world in (2, 4, 8):
+        cands = bench.root_share_candidates(world, 4320)
+        assert cands[0][1] == 0 and len(cands) >= 3                      # the equal split first, then lighter roots
+        for band, root in cands:
+            P = multi.Partition(4320, world, band, root)
+            assert sum(P.rank_rows) == 4320 and P.rank_rows[0] <= min(P.rank_rows[1:])
+            assert max(P.rank_rows[1:]) - min(P.rank_rows[1:]) <= band
+    assert bench.root_share_candidates(1, 2160) == [(2160, 0)] or bench.root_share_candidates(1, 2160)[0][1] == 0

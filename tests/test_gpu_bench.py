@@ -55,3 +55,15 @@ def test_the_real_backends_chatter_stays_off_stdout():
     from native code; stdout must still be the one JSON line (the driver parses it), the banner goes to stderr."""
     out, err = _bench(["--steps", "3", "--warmup", "1", "--workload", "c4", "--no-cpu-baseline"], LOL_BENCH_FORCE_PIPE="1")
     assert out["backend"] == "nccl" and out["gather_ms"] is not None
+
+
+def test_in_process_transport_and_root_emulation():
+    """--transport cabi: the frame through lol_gpu_multi_* in ONE process (one device here: RCCL self-exchange + assembly) equals
+    the single launch; --emulate-root-of 8: one GPU plays rank 0 of an 8-rank run (its band of every cycle, 1-rank RCCL gather,
+    whole-frame assembly) and reports the root's cadence."""
+    out, err = _bench(["--transport", "cabi", "--gpus", "1", "--workload", "c4", "--steps", "3", "--warmup", "1"], LOL_BENCH_CHECK="1")
+    assert out["config"]["transport"] == "cabi" and out["frame_equal_to_single_launch"] is True and out["value"] > 0
+    out, err = _bench(["--emulate-root-of", "8", "--steps", "5", "--warmup", "1", "--no-cpu-baseline"], LOL_BENCH_ROOT_SHARE="16,15")
+    assert out["metric"].startswith("EMULATION") and out["unit"] == "ms/frame" and out["emulated_world"] == 8
+    assert out["partition"]["rows_per_rank"][0] == 512 and out["backend"] == "nccl"
+    assert out["assembly"].startswith("lol_gpu_assemble_parts_at") and 0 < out["root_kernel_ms"] < out["value"]
