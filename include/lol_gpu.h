@@ -226,6 +226,11 @@ int         lol_gpu_set_cull(lol_gpu* ctx, int enable);
  * the bounding sphere (centre, inflated radius R') when the object has one, 0 when it has none (planes, unions
  * with a plane or with smoothness <= 0, non-finite fields) and is therefore never culled. */
 int         lol_gpu_cull_bounds(const lol_program* prog, uint32_t root, float c_out[3], float* r_out);
+/* The tighter bound of a union of at least three primitives whose leaves split into two clusters much smaller than the
+ * one enclosing sphere: value(p) >= min_j (|p - c_j| - r'_j).  Returns how many spheres out[j] = {cx, cy, cz, r'} were
+ * written (0: the object is tested with its single sphere only; else 2); the specialised kernel skips such an object where
+ * the tests of BOTH spheres pass. */
+int         lol_gpu_cull_bounds_clusters(const lol_program* prog, uint32_t root, float out[3][4]);
 /*
  * Diagnostic: out[i] = the renderer's powf(x[i], y[i]) (device pointers, asynchronous on `stream`, NULL = the
  * context's stream).  The kernel's powf restates the algorithm of the CPU libm's powf so that colours round

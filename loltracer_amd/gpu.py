@@ -147,6 +147,8 @@ def gpu_lib() -> C.CDLL:
         lib.lol_gpu_sdf_batch.restype = C.c_int
         lib.lol_gpu_cull_bounds.argtypes = [P(S.Program), C.c_uint32, P(C.c_float), P(C.c_float)]
         lib.lol_gpu_cull_bounds.restype = C.c_int
+        lib.lol_gpu_cull_bounds_clusters.argtypes = [P(S.Program), C.c_uint32, P(C.c_float * 4)]
+        lib.lol_gpu_cull_bounds_clusters.restype = C.c_int
         lib.lol_gpu_set_cull.argtypes = [vp, C.c_int]
         lib.lol_gpu_set_cull.restype = C.c_int
         lib.lol_gpu_device.argtypes = [vp]
@@ -205,7 +207,7 @@ EXPORTED_SYMBOLS = [
     "lol_gpu_part_rows", "lol_gpu_render_device", "lol_gpu_render_host", "lol_gpu_sync", "lol_gpu_malloc",
     "lol_gpu_free", "lol_gpu_memcpy_d2h", "lol_gpu_kernel_name", "lol_gpu_set_specialize",
     "lol_gpu_specialize_log", "lol_gpu_compile_offline", "lol_gpu_verify_fast_paths", "lol_gpu_verify_smin_no_fixup", "lol_gpu_set_miss_skip",
-    "lol_gpu_miss_skip_active", "lol_gpu_powf_batch", "lol_gpu_device", "lol_gpu_sdf_batch", "lol_gpu_set_cull", "lol_gpu_cull_bounds",
+    "lol_gpu_miss_skip_active", "lol_gpu_powf_batch", "lol_gpu_device", "lol_gpu_sdf_batch", "lol_gpu_set_cull", "lol_gpu_cull_bounds", "lol_gpu_cull_bounds_clusters",
     "lol_gpu_render_host_begin", "lol_gpu_render_host_end", "lol_gpu_render_host_pending",
     "lol_gpu_multi_create", "lol_gpu_multi_destroy", "lol_gpu_multi_error", "lol_gpu_multi_device_count",
     "lol_gpu_multi_context", "lol_gpu_multi_upload_program", "lol_gpu_choose_band_rows", "lol_gpu_multi_set_band_rows",

@@ -8,6 +8,7 @@ GPU part — culling on == culling off, bit for bit (pixels, hit ids, distances,
 rule (the FIRST object of equal distance wins, naive_renderer.c:39) survives the re-ordering.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -41,6 +42,47 @@ def bounds_of(prog, root):
     c, r = (C.c_float * 3)(), C.c_float()
     st = gpu.gpu_lib().lol_gpu_cull_bounds(C.byref(prog), root, c, C.byref(r))
     return st, np.array(list(c), dtype=np.float64), float(r.value)
+
+
+def clusters_of(prog, root):
+    out = ((C.c_float * 4) * 3)()
+    n = gpu.gpu_lib().lol_gpu_cull_bounds_clusters(C.byref(prog), root, out)
+    assert n in (0, 2)
+    return [(np.array(list(out[j])[:3], dtype=np.float64), float(out[j][3])) for j in range(n)]
+
+
+def test_the_two_sphere_bound_holds_too():
+    """Round 3: unions of three or more primitives whose leaves fall into two clusters much smaller than the one enclosing
+    sphere are tested with two spheres, and skipped where BOTH tests pass: value(p) >= min_j (|p - C_j| - R'_j) must hold for
+    the oracle's SDF — points near the object, far away, and on shells just outside either sphere."""
+    rng = np.random.default_rng(2026)
+    l = O.lib()
+    checked = with_clusters = 0
+    for _ in range(260):
+        obj = rand_bounded(rng, int(rng.integers(2, 7)))
+        sc = S.Scene.parse_string(MAT + "scene { " + obj.replace("{", "{ material = #0,", 1) + " }")
+        prog = sc.flatten()
+        cl = clusters_of(prog, 0)
+        if not cl:
+            continue
+        with_clusters += 1
+        st, c1, r1 = bounds_of(prog, 0)
+        assert st == 1 and max(r for _, r in cl) < r1                # each cluster is smaller than the single sphere
+        unit = lambda d: d / np.linalg.norm(d, axis=1, keepdims=True)
+        pts = [rng.normal(size=(50, 3)) * 6 + c1, rng.normal(size=(20, 3)) * 300 + c1]
+        for cj, rj in cl:
+            pts.append(cj + unit(rng.normal(size=(50, 3))) * rj * rng.uniform(0.9, 1.3, size=(50, 1)))
+        for p in np.concatenate(pts).astype(np.float32):
+            oid = C.c_uint32()
+            v = l.lol_oracle_sdf(sc.ptr, float(p[0]), float(p[1]), float(p[2]), C.byref(oid))
+            bound = min(float(np.linalg.norm(p.astype(np.float64) - cj)) - rj for cj, rj in cl)
+            assert v >= bound, (obj, p, v, bound)
+            checked += 1
+    assert with_clusters > 40 and checked > 6000
+    # scene4's blob: two spheres of 5.7 and 7.8 instead of one of 11.1
+    prog = S.Scene.parse_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scenes", "scene4.lol")).flatten()
+    cl = clusters_of(prog, 0)
+    assert len(cl) == 2 and sorted(round(r, 1) for _, r in cl) == [5.7, 7.8] and clusters_of(prog, 1) == []
 
 
 def test_the_bound_holds_on_random_objects():
