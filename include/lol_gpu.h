@@ -213,7 +213,10 @@ int         lol_gpu_verify_smin_no_fixup(lol_gpu* ctx, float k, unsigned long lo
  * (C3: 5630 -> 7510 Mpixels/s).  Same pixels; lol_gpu_debug.steps counts the steps really marched.
  * lol_gpu_miss_skip_active(): bit 0 = escaped-wave skip, bit 1 = zero-incidence skip, bit 2 = settled-shadow exit.
  */
-int         lol_gpu_set_miss_skip(lol_gpu* ctx, int enable);
+int         lol_gpu_set_miss_skip(lol_gpu* ctx, int enable);          /* all three skips on (default) or off */
+/* The same, skip by skip: bit 0 = escaped waves, bit 1 = zero incidence, bit 2 = settled shadows (for tests that hold ONE
+ * skip's step counts against known answers). */
+int         lol_gpu_set_exact_skips(lol_gpu* ctx, unsigned mask);
 int         lol_gpu_miss_skip_active(const lol_gpu* ctx);
 /*
  * Exact culling of top-level objects in the specialised kernel (lol_gpu.hip, "exact culling"): sdf() is a strict-'<'

@@ -78,7 +78,7 @@ struct lol_gpu {
 	std::string  spec_log;
 	std::string  spec_key;               /* FNV-1a of the code object the frames run (lol_gpu_kernel_key) */
 	int          want_fast = 1;          /* allow the proven-exact shortcuts in the specialised kernel */
-	int          want_miss_skip = 1;     /* allow FLAG_MISS_SKIP when the program qualifies */
+	unsigned     want_skips = 7;         /* exact skips allowed when the program qualifies: bit 0 escaped waves, 1 zero incidence, 2 settled shadows */
 	int          want_cull = 1;          /* allow the exact culling of top-level objects (plan_culling) */
 	bool         miss_skip = false;      /* the uploaded program qualifies (miss_skip_ok) */
 	bool         dark_skip = false;      /* the uploaded program qualifies (dark_skip_ok) */
@@ -1075,6 +1075,8 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
                   std::string& log, std::string* src_out = nullptr, const int* shape = nullptr, bool cull = true) {
 	std::string src = generate_source(P, fast, cull);
 	if (src_out) *src_out = src;
+	if (const char* dump = getenv("LOL_GPU_DUMP_SPEC_SOURCE"))       /* debugging aid: the source as really generated on this device */
+		if (FILE* f = fopen(dump, "w")) { fputs(src.c_str(), f); fclose(f); }
 	int rtc_major = 0, rtc_minor = 0;
 	(void)hiprtcVersion(&rtc_major, &rtc_minor);
 	/* the option list first: it is part of the cache key (a changed flag — -ffp-contract above all — must never be served
@@ -1342,18 +1344,24 @@ int lol_gpu_set_specialize(lol_gpu* ctx, int enable) {
 	return LOL_GPU_OK;
 }
 
-int lol_gpu_set_miss_skip(lol_gpu* ctx, int enable) {
-	if (!ctx) return LOL_GPU_ERR_ARG;
-	ctx->want_miss_skip = enable ? 1 : 0;
-	if (ctx->have_prog) {
-		const char* ms = getenv("LOL_GPU_MISS_SKIP");              /* the environment switch still wins */
-		const bool allowed = ctx->want_miss_skip && !(ms && ms[0] == '0');
-		ctx->miss_skip = allowed && miss_skip_ok(ctx->h_prog);
-		ctx->dark_skip = allowed && dark_skip_ok(ctx->h_prog);
-		ctx->shadow_settle = allowed && shadow_settle_ok(ctx->h_prog) && !(getenv("LOL_GPU_SHADOW_SETTLE") && getenv("LOL_GPU_SHADOW_SETTLE")[0] == '0');
-	}
+/* which of the wanted skips the uploaded program (and the environment) allows */
+static void resolve_skips(lol_gpu* ctx) {
+	const char* ms = getenv("LOL_GPU_MISS_SKIP");                  /* the environment switches still win */
+	const char* ss = getenv("LOL_GPU_SHADOW_SETTLE");
+	const unsigned want = (ms && ms[0] == '0') ? 0u : ctx->want_skips;
+	ctx->miss_skip = (want & 1u) && miss_skip_ok(ctx->h_prog);
+	ctx->dark_skip = (want & 2u) && dark_skip_ok(ctx->h_prog);
+	ctx->shadow_settle = (want & 4u) && shadow_settle_ok(ctx->h_prog) && !(ss && ss[0] == '0');
+}
+
+int lol_gpu_set_exact_skips(lol_gpu* ctx, unsigned mask) {
+	if (!ctx || mask > 7u) return LOL_GPU_ERR_ARG;
+	ctx->want_skips = mask;
+	if (ctx->have_prog) resolve_skips(ctx);
 	return LOL_GPU_OK;
 }
+
+int lol_gpu_set_miss_skip(lol_gpu* ctx, int enable) { return lol_gpu_set_exact_skips(ctx, enable ? 7u : 0u); }
 
 /* Host-only view of the bound behind the culling test of top-level object `root` (0-based, file order):
  * 1 = bounded (centre and inflated radius R' out), 0 = no bound (never culled), < 0 = bad argument. */
@@ -1470,11 +1478,7 @@ int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog) {
 	ctx->have_prog = true;
 	ctx->n_mops = n_mops;
 	ctx->interp_sqrt_kind = fast.sqrt_kind == 3 ? 3 : 0;
-	const char* ms = getenv("LOL_GPU_MISS_SKIP");
-	ctx->miss_skip = ctx->want_miss_skip && !(ms && ms[0] == '0') && miss_skip_ok(*prog);
-	ctx->dark_skip = ctx->want_miss_skip && !(ms && ms[0] == '0') && dark_skip_ok(*prog);
-	ctx->shadow_settle = ctx->want_miss_skip && !(ms && ms[0] == '0') && shadow_settle_ok(*prog) &&
-	                     !(getenv("LOL_GPU_SHADOW_SETTLE") && getenv("LOL_GPU_SHADOW_SETTLE")[0] == '0');
+	resolve_skips(ctx);
 	specialise(ctx);          /* a failed specialisation is not an error: the interpreter renders the new scene */
 	return LOL_GPU_OK;
 }

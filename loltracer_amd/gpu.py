@@ -141,6 +141,8 @@ def gpu_lib() -> C.CDLL:
         lib.lol_gpu_powf_batch.restype = C.c_int
         lib.lol_gpu_set_miss_skip.argtypes = [vp, C.c_int]
         lib.lol_gpu_set_miss_skip.restype = C.c_int
+        lib.lol_gpu_set_exact_skips.argtypes = [vp, C.c_uint]
+        lib.lol_gpu_set_exact_skips.restype = C.c_int
         lib.lol_gpu_miss_skip_active.argtypes = [vp]
         lib.lol_gpu_miss_skip_active.restype = C.c_int
         lib.lol_gpu_sdf_batch.argtypes = [vp, vp, vp, vp, C.c_size_t, vp]
@@ -207,7 +209,7 @@ EXPORTED_SYMBOLS = [
     "lol_gpu_part_rows", "lol_gpu_render_device", "lol_gpu_render_host", "lol_gpu_sync", "lol_gpu_malloc",
     "lol_gpu_free", "lol_gpu_memcpy_d2h", "lol_gpu_kernel_name", "lol_gpu_set_specialize",
     "lol_gpu_specialize_log", "lol_gpu_compile_offline", "lol_gpu_verify_fast_paths", "lol_gpu_verify_smin_no_fixup", "lol_gpu_set_miss_skip",
-    "lol_gpu_miss_skip_active", "lol_gpu_powf_batch", "lol_gpu_device", "lol_gpu_sdf_batch", "lol_gpu_set_cull", "lol_gpu_cull_bounds", "lol_gpu_cull_bounds_clusters",
+    "lol_gpu_miss_skip_active", "lol_gpu_set_exact_skips", "lol_gpu_powf_batch", "lol_gpu_device", "lol_gpu_sdf_batch", "lol_gpu_set_cull", "lol_gpu_cull_bounds", "lol_gpu_cull_bounds_clusters",
     "lol_gpu_render_host_begin", "lol_gpu_render_host_end", "lol_gpu_render_host_pending",
     "lol_gpu_multi_create", "lol_gpu_multi_destroy", "lol_gpu_multi_error", "lol_gpu_multi_device_count",
     "lol_gpu_multi_context", "lol_gpu_multi_upload_program", "lol_gpu_choose_band_rows", "lol_gpu_multi_set_band_rows",
@@ -366,6 +368,10 @@ class Renderer:
 
     def set_miss_skip(self, enable: bool):
         self._check(self._lib.lol_gpu_set_miss_skip(self._ctx, 1 if enable else 0))
+
+    def set_exact_skips(self, mask: int):
+        """bit 0 escaped waves, bit 1 zero incidence, bit 2 settled shadows."""
+        self._check(self._lib.lol_gpu_set_exact_skips(self._ctx, mask))
 
     def miss_skip_active(self) -> int:
         """bit 0: escaped-wave skip active; bit 1: zero-incidence shadow skip active."""

@@ -31,7 +31,8 @@ Outputs (all DATA — inputs and expected outputs, no reference source text):
                         Pins rows a2, a3, a9 - a13 of SURVEY.md §8 for the oracle (tests/test_oracle.py).
   ref_frames.npz        the same composition for EVERY pixel of the 64x36 frame of each example scene (9216 pixels):
                         arrays <scene>_xrgb, _rgb, _rgb_linear, _hit_dist, _hit_id, _march_steps, _normal, _rd, _shadow,
-                        _shadow_steps — whole reference-composed frames for the oracle to equal.
+                        _shadow_steps, _shadow_settled_steps (steps up to the first that left the running factor <= 0) —
+                        whole reference-composed frames for the oracle to equal.
   ref_camera_path.json  the camera after every frame of a key script (W A S D Space LCtrl and the four arrows, singly and
                         held together), stepped the way main.c's update_camera does (main.c:70-112) with every vector
                         operation a call into the reference's compiled vec.h (v3cross, v3normalize, v3add, v3scale) —
@@ -403,15 +404,23 @@ class RefPipeline:
         rd = self.normalize(self.sub(light_point, p))
         ro = self.add(p, rd)
         res, dist, steps = f32(1.0), f32(0.0), 0
+        settled = 0       # bookkeeping beside the reference's loop: the step (counted from 1) that first left res <= 0
         with np.errstate(all="ignore"):
             for _ in range(128):
                 sd = f32(self.sdf(self.add(ro, self.scale(rd, float(dist))))[0])
                 res = f32(self.ref.ref_minf(C.c_float(float(res)), C.c_float(float(f32(50.0) * sd / dist))))
                 dist = dist + sd
                 steps += 1
+                if not settled and res <= f32(0.0):
+                    settled = steps
                 if res < f32(-1.0) or dist > f32(light_dist):
                     break
-        return self.ref.ref_maxf(C.c_float(float(res)), C.c_float(0.0)), steps
+        shadow = self.ref.ref_maxf(C.c_float(float(res)), C.c_float(0.0))
+        # what the renderer's early exit rests on, here with the reference's own minf / maxf: a factor that was
+        # <= 0 once comes out 0
+        assert not settled or shadow == 0.0, "a settled shadow factor came back"
+        self.last_settled_steps = settled or steps
+        return shadow, steps
 
     def light(self, p, n, oid, rec):                   # :129-175
         f32 = np.float32
@@ -422,6 +431,7 @@ class RefPipeline:
         for l in self.lights:
             shadow, sh_steps = self.in_shadow(l[:3], p)
             rec["shadow"].append(f2h(shadow)); rec["shadow_steps"].append(sh_steps)
+            rec["shadow_settled_steps"].append(self.last_settled_steps)
             light_dir = self.normalize(self.sub(l[:3], p))
             refl = self.sub(self.scale(n, float(f32(2.0) * f32(self.dot(light_dir, n)))), light_dir)
             camera_dir = self.normalize(self.sub(cam_pos, p))
@@ -448,7 +458,7 @@ class RefPipeline:
         p = self.add(ro, self.scale(rd, dist))
         n = self.normal(p, dist)
         rec = {"x": x, "y": y, "rd": [f2h(v) for v in rd], "hit_dist": f2h(dist), "hit_id": oid, "march_steps": steps,
-               "normal": [f2h(v) for v in n], "shadow": [], "shadow_steps": []}
+               "normal": [f2h(v) for v in n], "shadow": [], "shadow_steps": [], "shadow_settled_steps": []}
         lin = self.light(p, n, oid, rec)
         o = self.A3()
         self.ref.ref_v3pow(self.A3(*lin), C.c_float(float(f32(1.0) / f32(2.2))), o)
@@ -553,6 +563,7 @@ def main():
             frames[f"{name}_{key}"] = u([v for q in full for v in q[key]]).view(np.float32).reshape(H, W, 3)
         frames[f"{name}_shadow"] = u([v for q in full for v in q["shadow"]]).view(np.float32).reshape(H, W, nl)
         frames[f"{name}_shadow_steps"] = np.array([v for q in full for v in q["shadow_steps"]], dtype=np.uint32).reshape(H, W, nl)
+        frames[f"{name}_shadow_settled_steps"] = np.array([v for q in full for v in q["shadow_settled_steps"]], dtype=np.uint32).reshape(H, W, nl)
         if name in ("scene", "scene4"):
             pixels[name]["256x256"] = [pipe.pixel(x, y, 256, 256) for x, y in ((128, 128), (0, 0), (255, 255), (40, 200), (200, 60), (77, 131))]
         ref.ref_scene_free(sc)

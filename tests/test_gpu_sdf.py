@@ -67,7 +67,16 @@ def test_device_frames_equal_the_reference_composition(scenes, name, mode):
     if HOST_LIBM_IS_FMA_VARIANT:
         assert np.array_equal(d["rgb"].view(np.uint32), g[f"{name}_rgb"].view(np.uint32))
         assert np.array_equal(d["xrgb"][:, :w], g[f"{name}_xrgb"])
-    r.set_miss_skip(False)                     # ... then march every shadow ray, so that the shadow step counts are comparable
+    # ... then only the settled-shadow exit: every shadow ray is marched, each up to the first step that left its running
+    # factor <= 0 — the count the fixture records beside the reference's own loop (make_golden.py: in_shadow)
+    r.set_exact_skips(4)
+    d = gpu_render(torch, r, scenes[name], w, h)
+    assert d["miss_skip"] == 4
+    assert np.array_equal(d["steps"] >> 16, g[f"{name}_shadow_settled_steps"].sum(axis=-1))
+    assert np.array_equal(d["id"], g[f"{name}_hit_id"])
+    if HOST_LIBM_IS_FMA_VARIANT:
+        assert np.array_equal(d["xrgb"][:, :w], g[f"{name}_xrgb"])
+    r.set_miss_skip(False)                     # ... and finally march every shadow ray to the reference's own exit
     d = gpu_render(torch, r, scenes[name], w, h)
     assert np.array_equal(d["id"], g[f"{name}_hit_id"])
     assert np.array_equal(d["dist"].view(np.uint32), g[f"{name}_hit_dist"].view(np.uint32))

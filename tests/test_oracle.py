@@ -172,6 +172,10 @@ def test_whole_frames_equal_the_reference_composition(scenes, name):
     assert np.array_equal(steps[..., 0], g[f"{name}_march_steps"])
     assert np.array_equal(steps[..., 2], g[f"{name}_hit_id"])
     assert np.array_equal(steps[..., 1], g[f"{name}_shadow_steps"].sum(axis=-1))
+    # the checker's "settled" shadow steps (round 3) against the count made beside the reference's own loop, light by light
+    nl = min(g[f"{name}_shadow_steps"].shape[-1], 4)
+    assert np.array_equal(steps[..., 4:4 + nl], g[f"{name}_shadow_steps"][..., :nl])
+    assert np.array_equal(steps[..., 8:8 + nl], g[f"{name}_shadow_settled_steps"][..., :nl])
     assert len(np.unique(x)) > 50                       # a real picture, not a constant
 
 
