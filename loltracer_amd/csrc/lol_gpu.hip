@@ -1117,7 +1117,19 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
 		opts.push_back(d0); opts.push_back(d1); opts.push_back(d2);
 	}
 	for (auto& x : extra) opts.push_back(x.c_str());
-	std::string key = "lol_gpu/3|hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) + "|";
+	/* ... and so is the compiler: which libhiprtc this process has loaded.  A Python host gets the one torch ships, a C host the
+	 * system's, a process under rocprofv3 yet another mix — the same source came out as three different code objects — and one
+	 * compiler's output must not be handed to a process that would have compiled something else.
+	 * LOL_GPU_CACHE_ANY_COMPILER=1 leaves the compiler out of the key: a profiling aid (tools/final_profile.sh lets a plain run
+	 * compile the kernels, and the runs under the profiler load exactly those). */
+	std::string compiler = "?";
+	{
+		Dl_info info;
+		if (dladdr(reinterpret_cast<void*>(&hiprtcCompileProgram), &info) && info.dli_fname) compiler = info.dli_fname;
+		const char* any = getenv("LOL_GPU_CACHE_ANY_COMPILER");
+		if (any && any[0] == '1') compiler = "*";
+	}
+	std::string key = "lol_gpu/4|hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) + " " + compiler + "|";
 	for (const char* o : opts) { key += o; key += ' '; }
 	key += "|" + src;
 	{

@@ -11,7 +11,9 @@ B="python3 $R/bench.py --steps 20 --warmup 5"
 # different code objects that way (keys a9cd… / f6c3… / 254a…).  So the kernels the profiler times are the ones a plain run
 # compiles: one plain run first fills the on-disk code-object cache, the profiled runs load from it, and the recorded
 # kernel_key is the one the driver's own `python bench.py` will see.
+export LOL_GPU_CACHE_DIR=$O/code_cache LOL_GPU_CACHE_ANY_COMPILER=1      # a cache of this recipe's own, shared by all its runs
 python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/plain_first.json 2> /dev/null || exit 1
+LOL_GPU_SPECIALIZE=0 python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 || exit 1
 LOL_BENCH_HOST_SURFACE=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > $O/stats.log 2>&1 || exit 1
 grep -o '^{.*' $O/stats.log | tail -1 > $O/${TAG}_spec_c3_bench.json
 cp "$(find $O/stats -name "*kernel_stats.csv" | head -1)" $O/${TAG}_spec_c3_kernel_stats.csv
