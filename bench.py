@@ -632,7 +632,11 @@ def main():
             tops = kernel_mpix * 1e6 * fpp / 1e12
             out["valu"] = {"flops_per_pixel": round(fpp, 1), "sdf_evals_per_pixel": round(ctr.sdf_evals / ctr.pixels, 2),
                            "achieved": round(tops, 3), "peak": VALU_PEAK_TOPS, "unit": "Tops/s (unfused FP32)",
-                           "frac": round(tops / VALU_PEAK_TOPS, 4)}
+                           "frac": round(tops / VALU_PEAK_TOPS, 4),
+                           "note": "REFERENCE-counted work: the oracle's unfused flops per pixel x the measured Mpixels/s.  The kernel "
+                                   "skips part of that work exactly (culled objects, dark / escaped lanes, settled shadow marches: "
+                                   "DESIGN.md §3.6-3.7), so this can exceed 1; what it really issues is in profiles/pmc_traffic.json "
+                                   "(VALU instructions per pixel, cycles per VALU instruction)"}
         if world == 1 and local is not None and os.environ.get("LOL_BENCH_HOST_SURFACE", "1") != "0":
             torch.cuda.synchronize()
             hs_cams = [orbit_camera(i, 256) for i in range(0, 256, 16)] if orbit else None
