@@ -45,6 +45,7 @@
 static_assert(sizeof(lol_light) == lol::LIGHT_DWORDS * 4, "lol_light layout");
 static_assert(sizeof(lol_material) == lol::MATERIAL_DWORDS * 4, "lol_material layout");
 static_assert(sizeof(lol_frame_camera) == sizeof(lol::Cam), "lol_frame_camera layout");
+static_assert(LOL_MAX_OPS < (1u << (32 - lol::MOP_ID_SHIFT)), "object ids must fit the macro-op header");
 
 
 struct lol_gpu {
@@ -83,6 +84,7 @@ struct lol_gpu {
 	bool         miss_skip = false;      /* the uploaded program qualifies (miss_skip_ok) */
 	bool         dark_skip = false;      /* the uploaded program qualifies (dark_skip_ok) */
 	bool         shadow_settle = false;  /* the uploaded program qualifies (shadow_settle_ok) */
+	bool         finite_scene = false;   /* shadow_settle_ok(program), whatever the switches say: the interpreter's no-fixup list may run */
 	int          interp_sqrt_kind = 0;   /* fast sqrt of the interpreter: 3 (sqrt_r2) when proven and allowed, else 0 */
 	int          sqrt_verified = -1;     /* -1 not run, 0 none proven, else the lol::sqrt_fast KIND proven on this device */
 	bool         sqrt_tiny_ok = false;   /* the second counter of that run was 0 too (sd_sphere_fast_nr) */
@@ -583,17 +585,17 @@ CullPlan plan_culling(const std::vector<RootBound>& roots, bool enabled) {
  * `fast` lists the smoothness constants whose fast blend factor was proven on the device.
  */
 std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast, const std::vector<RootBound>& roots,
-                                 const CullPlan& plan) {
+                                 const CullPlan& plan, bool allow_nofixup) {
 	std::vector<uint32_t> out;
 	auto fbits32 = [](float v) { uint32_t u; memcpy(&u, &v, 4); return u; };
 	auto smin_fields = [&](uint32_t* m, const lol_op& sm) {
-		m[9] = fbits32(sm.f[0]);
-		if (fast && fast->has(sm.f[0])) {
-			m[0] |= lol::MOP_FASTDIV;
-			m[10] = fbits32(2.0f * sm.f[0]);
-			m[11] = fbits32(0.5f * (1.0f / sm.f[0]));
+		m[lol::MOP_K] = fbits32(sm.f[0]);
+		const bool fastdiv = fast && fast->has(sm.f[0]), nofixup = fastdiv && allow_nofixup && fast->has_nf(sm.f[0]);
+		if (fastdiv) {
+			m[lol::MOP_K + 1] = fbits32(2.0f * sm.f[0]);
+			m[lol::MOP_K + 2] = fbits32(0.5f * (1.0f / sm.f[0]));
 		}
-		m[0] |= lol::mop_smin_bits(m[0]);
+		m[0] |= lol::mop_smin_bits(m[0], fastdiv, nofixup);
 	};
 	/* LOL_GPU_INTERP_CULL_MIN_PRIMS: leave out the tests of runs with fewer primitives (measured: 1, i.e. keeping
 	 * every test, is fastest here too — a test is one turn of a scalar loop inside the rare TAIL branch). */
@@ -630,7 +632,13 @@ std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast, co
 			uint32_t m[lol::MOP_DWORDS] = { 0 };
 			if (o.op <= LOL_OP_PLANE) {
 				const uint32_t kind = o.op == LOL_OP_SPHERE ? lol::MOP_SPHERE : o.op == LOL_OP_RBOX ? lol::MOP_RBOX : lol::MOP_PLANE;
-				for (int j = 0; j < 7; j++) m[2 + j] = fbits32(o.f[j]);
+				for (int j = 0; j < 4; j++) m[lol::MOP_PARAMS + j] = fbits32(o.f[j]);
+				if (kind == lol::MOP_RBOX) {                 /* f = centre, b, r: b and r travel in a record of their own, in front */
+					uint32_t pre[lol::MOP_DWORDS] = { lol::MOPB_RBOX_PRE | lol::MOPB_NOT_SPHERE };
+					for (int j = 0; j < 4; j++) pre[lol::MOP_PARAMS + j] = fbits32(o.f[3 + j]);
+					out.insert(out.end(), pre, pre + lol::MOP_DWORDS);
+					m[lol::MOP_PARAMS + 3] = 0;
+				}
 				const lol_op* nx = i + 1 < R.top ? &P.ops[i + 1] : nullptr;
 				if (nx && (nx->op == LOL_OP_SMIN || nx->op == LOL_OP_SMIN_R) && depth >= 1) {
 					m[0] = lol::mop_header(kind, nx->op == LOL_OP_SMIN ? lol::MOP_SMIN : lol::MOP_SMIN_X);
@@ -638,20 +646,19 @@ std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast, co
 					i++;                                /* the smooth min is part of this macro-op; depth unchanged */
 				} else {
 					m[0] = lol::mop_header(kind, depth == 0 ? lol::MOP_SET : lol::MOP_PUSH);
-					if (depth > 0) m[0] |= (uint32_t)(depth - 1) << lol::MOP_SLOT_SHIFT;      /* the accumulator goes to this slot */
+					if (depth > 0) m[lol::MOP_SLOT_PUSH] = (uint32_t)(depth - 1);             /* the accumulator goes to this slot */
 					depth++;
 				}
 			} else {                                     /* SMIN / SMIN_R on two computed operands */
 				m[0] = lol::mop_header(lol::MOP_POP, o.op == LOL_OP_SMIN ? lol::MOP_SMIN_X : lol::MOP_SMIN);
-				m[0] |= (uint32_t)(depth - 2) << lol::MOP_SLOT_SHIFT;                           /* the operand under the accumulator */
+				m[lol::MOP_SLOT_POP] = (uint32_t)(depth - 2);                                   /* the operand under the accumulator */
 				smin_fields(m, o);
 				depth--;
 			}
 			last = out.size();
 			out.insert(out.end(), m, m + lol::MOP_DWORDS);
 		}
-		out[last] |= lol::MOP_TOP | lol::MOPB_TAIL | (R.id < max_id_seen ? lol::MOP_TIE : 0u);
-		out[last + 1] = R.id;
+		out[last] |= lol::MOP_TOP | lol::MOPB_TAIL | (R.id < max_id_seen ? lol::MOP_TIE : 0u) | R.id << lol::MOP_ID_SHIFT;
 		if (R.id > max_id_seen) max_id_seen = R.id;
 		if (begins[oi + 1]) {
 			const bool group_here = group_first && oi + 1 == plan.n_unbounded;
@@ -1312,7 +1319,7 @@ int lol_gpu_create(int device, lol_gpu** out) {
 	for (int i = 0; i < 2 && e == hipSuccess; i++) {
 		e = hipMalloc(reinterpret_cast<void**>(&ctx->d_prog[i]), sizeof(lol_program));
 		/* macro-ops + test records <= 1.5 x ops */
-		if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_mops[i]), (size_t)(2 * LOL_MAX_OPS) * lol::MOP_DWORDS * 4);
+		if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_mops[i]), (size_t)(2 * 3 * LOL_MAX_OPS) * lol::MOP_DWORDS * 4);      /* two lists (lol_gpu_upload_program) */
 	}
 	if (e != hipSuccess) {
 		fprintf(stderr, "lol_gpu_create: %s\n", hipGetErrorString(e));
@@ -1475,9 +1482,19 @@ int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog) {
 	 * rejected program leaves the previous scene rendering (the reference asserts instead: scene.c:284-292). */
 	FastPaths fast = prove_fast_paths(ctx, *prog);
 	const std::vector<RootBound> roots = analyse_roots(*prog);
-	const std::vector<uint32_t> mops = build_mops(*prog, &fast, roots, plan_culling(roots, culling_enabled(ctx->want_cull)));
+	/* Two lists of the same records: the second one takes the blend factors without v_div_fixup where the device proved
+	 * them.  That proof covers every FINITE difference of operands; the launch picks the second list only when nothing an
+	 * evaluation computes can be infinite (finite_scene, and a sane camera for that frame), the SDF of arbitrary points
+	 * (lol_gpu_sdf_batch) never does.  (The specialised kernel votes on NaN per object instead; here a vote per object
+	 * costs more than the fixup saves.) */
+	const CullPlan cull_plan = plan_culling(roots, culling_enabled(ctx->want_cull));
+	std::vector<uint32_t> mops = build_mops(*prog, &fast, roots, cull_plan, false);
 	const uint32_t n_mops = (uint32_t)(mops.size() / lol::MOP_DWORDS);
-	if (n_mops > 2 * LOL_MAX_OPS) return fail(ctx, LOL_GPU_ERR_UNSUPPORTED, "program exceeds interpreter limits");
+	if (n_mops > 3 * LOL_MAX_OPS) return fail(ctx, LOL_GPU_ERR_UNSUPPORTED, "program exceeds interpreter limits");
+	{
+		const std::vector<uint32_t> nofix = build_mops(*prog, &fast, roots, cull_plan, true);
+		mops.insert(mops.end(), nofix.begin(), nofix.end());
+	}
 	const int next = ctx->cur ^ 1;
 	hipError_t e = getenv("LOL_GPU_TEST_FAIL_UPLOAD") ? hipErrorOutOfMemory      /* fault injection for tests/test_gpu_resize.py */
 	                                                  : hipMemcpy(ctx->d_prog[next], prog, sizeof *prog, hipMemcpyHostToDevice);
@@ -1489,6 +1506,7 @@ int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog) {
 	ctx->h_prog = *prog;
 	ctx->have_prog = true;
 	ctx->n_mops = n_mops;
+	ctx->finite_scene = shadow_settle_ok(*prog);
 	ctx->interp_sqrt_kind = fast.sqrt_kind == 3 ? 3 : 0;
 	resolve_skips(ctx);
 	specialise(ctx);          /* a failed specialisation is not an error: the interpreter renders the new scene */
@@ -1535,7 +1553,7 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	const lol_program& P = ctx->h_prog;
 	L.n_ops = ctx->n_mops; L.n_lights = P.n_lights; L.n_materials = P.n_materials; L.n_roots = P.n_roots;
 	const char* base = reinterpret_cast<const char*>(ctx->d_prog[ctx->cur]);
-	L.ops           = ctx->d_mops[ctx->cur];
+	L.ops           = ctx->d_mops[ctx->cur] + (ctx->finite_scene && camera_sane(*cam) ? (size_t)ctx->n_mops * lol::MOP_DWORDS : 0u);
 	L.lights        = reinterpret_cast<const uint32_t*>(base + offsetof(lol_program, lights));
 	L.materials     = reinterpret_cast<const uint32_t*>(base + offsetof(lol_program, materials));
 	L.root_material = reinterpret_cast<const uint32_t*>(base + offsetof(lol_program, root_material));

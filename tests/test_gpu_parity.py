@@ -179,6 +179,19 @@ def test_moved_camera(torch_cuda, renderer, scenes):
     check_against_oracle(g, sc, w, h, camera=cam)
 
 
+def test_camera_beyond_the_sane_range(torch_cuda, renderer, scenes):
+    """A camera 10^16 away is not "sane" (lol_gpu.hip, camera_sane): the shadow marches run to the reference's own end and the
+    interpreter walks its list WITH v_div_fixup (the proof of the shorter blend factor covers finite operands only)."""
+    sc = scenes["scene4"]
+    cam = S.Camera()
+    cam.point = S.V3(1.0e16, 3.0, 2.5)
+    cam.direction = S.V3(-1.0, 0.0, 0.0)
+    cam.fov = float(np.float32(np.float32(60.0) / np.float32(180) * np.pi))
+    w, h = 64, 16
+    g = gpu_render(torch_cuda, renderer, sc, w, h, camera=cam)
+    check_against_oracle(g, sc, w, h, camera=cam)
+
+
 def test_render_host_surface(torch_cuda, renderer, scenes):
     sc = scenes["scene"]
     w, h, pitch = 50, 30, 64 * 4
