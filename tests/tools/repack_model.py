@@ -5,7 +5,7 @@ step counts (test infrastructure: runs the oracle, not the product).  For every 
   queue    the (pixel, light) marches of the patch are tasks; a lane that finishes takes the next one (list scheduling,
            refill only when at least R lanes are idle or nothing else is left)
   block-N  the same with N waves sharing one queue (N patches side by side)
-Usage: python tools/repack_model.py [--every 4] [--size 3840x2160]"""
+Usage: python tests/tools/repack_model.py [--every 4] [--size 3840x2160]"""
 import argparse
 import heapq
 import json
@@ -14,7 +14,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as O  # noqa: E402

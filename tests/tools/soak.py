@@ -1,6 +1,6 @@
-"""Soak: many random scenes, GPU (spec + interp) vs the CPU oracle.  python tools/soak.py [n] [seed] [stress]"""
+"""Soak: many random scenes, GPU (spec + interp) vs the CPU oracle.  python tests/tools/soak.py [n] [seed] [stress]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import test_gpu_fuzz as F
