@@ -45,7 +45,6 @@
 static_assert(sizeof(lol_light) == lol::LIGHT_DWORDS * 4, "lol_light layout");
 static_assert(sizeof(lol_material) == lol::MATERIAL_DWORDS * 4, "lol_material layout");
 static_assert(sizeof(lol_frame_camera) == sizeof(lol::Cam), "lol_frame_camera layout");
-static_assert(LOL_MAX_OPS < (1u << (32 - lol::MOP_ID_SHIFT)), "object ids must fit the macro-op header");
 
 
 struct lol_gpu {
@@ -589,13 +588,13 @@ std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast, co
 	std::vector<uint32_t> out;
 	auto fbits32 = [](float v) { uint32_t u; memcpy(&u, &v, 4); return u; };
 	auto smin_fields = [&](uint32_t* m, const lol_op& sm) {
-		m[lol::MOP_K] = fbits32(sm.f[0]);
-		const bool fastdiv = fast && fast->has(sm.f[0]), nofixup = fastdiv && allow_nofixup && fast->has_nf(sm.f[0]);
-		if (fastdiv) {
-			m[lol::MOP_K + 1] = fbits32(2.0f * sm.f[0]);
-			m[lol::MOP_K + 2] = fbits32(0.5f * (1.0f / sm.f[0]));
+		m[9] = fbits32(sm.f[0]);
+		if (fast && fast->has(sm.f[0])) {
+			m[0] |= lol::MOP_FASTDIV | (allow_nofixup && fast->has_nf(sm.f[0]) ? lol::MOP_NOFIXUP : 0u);
+			m[10] = fbits32(2.0f * sm.f[0]);
+			m[11] = fbits32(0.5f * (1.0f / sm.f[0]));
 		}
-		m[0] |= lol::mop_smin_bits(m[0], fastdiv, nofixup);
+		m[0] |= lol::mop_smin_bits(m[0]);
 	};
 	/* LOL_GPU_INTERP_CULL_MIN_PRIMS: leave out the tests of runs with fewer primitives (measured: 1, i.e. keeping
 	 * every test, is fastest here too — a test is one turn of a scalar loop inside the rare TAIL branch). */
@@ -632,13 +631,7 @@ std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast, co
 			uint32_t m[lol::MOP_DWORDS] = { 0 };
 			if (o.op <= LOL_OP_PLANE) {
 				const uint32_t kind = o.op == LOL_OP_SPHERE ? lol::MOP_SPHERE : o.op == LOL_OP_RBOX ? lol::MOP_RBOX : lol::MOP_PLANE;
-				for (int j = 0; j < 4; j++) m[lol::MOP_PARAMS + j] = fbits32(o.f[j]);
-				if (kind == lol::MOP_RBOX) {                 /* f = centre, b, r: b and r travel in a record of their own, in front */
-					uint32_t pre[lol::MOP_DWORDS] = { lol::MOPB_RBOX_PRE | lol::MOPB_NOT_SPHERE };
-					for (int j = 0; j < 4; j++) pre[lol::MOP_PARAMS + j] = fbits32(o.f[3 + j]);
-					out.insert(out.end(), pre, pre + lol::MOP_DWORDS);
-					m[lol::MOP_PARAMS + 3] = 0;
-				}
+				for (int j = 0; j < 7; j++) m[2 + j] = fbits32(o.f[j]);
 				const lol_op* nx = i + 1 < R.top ? &P.ops[i + 1] : nullptr;
 				if (nx && (nx->op == LOL_OP_SMIN || nx->op == LOL_OP_SMIN_R) && depth >= 1) {
 					m[0] = lol::mop_header(kind, nx->op == LOL_OP_SMIN ? lol::MOP_SMIN : lol::MOP_SMIN_X);
@@ -646,19 +639,20 @@ std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast, co
 					i++;                                /* the smooth min is part of this macro-op; depth unchanged */
 				} else {
 					m[0] = lol::mop_header(kind, depth == 0 ? lol::MOP_SET : lol::MOP_PUSH);
-					if (depth > 0) m[lol::MOP_SLOT_PUSH] = (uint32_t)(depth - 1);             /* the accumulator goes to this slot */
+					if (depth > 0) m[0] |= (uint32_t)(depth - 1) << lol::MOP_SLOT_SHIFT;      /* the accumulator goes to this slot */
 					depth++;
 				}
 			} else {                                     /* SMIN / SMIN_R on two computed operands */
 				m[0] = lol::mop_header(lol::MOP_POP, o.op == LOL_OP_SMIN ? lol::MOP_SMIN_X : lol::MOP_SMIN);
-				m[lol::MOP_SLOT_POP] = (uint32_t)(depth - 2);                                   /* the operand under the accumulator */
+				m[0] |= (uint32_t)(depth - 2) << lol::MOP_SLOT_SHIFT;                           /* the operand under the accumulator */
 				smin_fields(m, o);
 				depth--;
 			}
 			last = out.size();
 			out.insert(out.end(), m, m + lol::MOP_DWORDS);
 		}
-		out[last] |= lol::MOP_TOP | lol::MOPB_TAIL | (R.id < max_id_seen ? lol::MOP_TIE : 0u) | R.id << lol::MOP_ID_SHIFT;
+		out[last] |= lol::MOP_TOP | lol::MOPB_TAIL | (R.id < max_id_seen ? lol::MOP_TIE : 0u);
+		out[last + 1] = R.id;
 		if (R.id > max_id_seen) max_id_seen = R.id;
 		if (begins[oi + 1]) {
 			const bool group_here = group_first && oi + 1 == plan.n_unbounded;
@@ -1319,7 +1313,7 @@ int lol_gpu_create(int device, lol_gpu** out) {
 	for (int i = 0; i < 2 && e == hipSuccess; i++) {
 		e = hipMalloc(reinterpret_cast<void**>(&ctx->d_prog[i]), sizeof(lol_program));
 		/* macro-ops + test records <= 1.5 x ops */
-		if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_mops[i]), (size_t)(2 * 3 * LOL_MAX_OPS) * lol::MOP_DWORDS * 4);      /* two lists (lol_gpu_upload_program) */
+		if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_mops[i]), (size_t)(2 * 2 * LOL_MAX_OPS) * lol::MOP_DWORDS * 4);      /* two lists (lol_gpu_upload_program) */
 	}
 	if (e != hipSuccess) {
 		fprintf(stderr, "lol_gpu_create: %s\n", hipGetErrorString(e));
@@ -1490,7 +1484,7 @@ int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog) {
 	const CullPlan cull_plan = plan_culling(roots, culling_enabled(ctx->want_cull));
 	std::vector<uint32_t> mops = build_mops(*prog, &fast, roots, cull_plan, false);
 	const uint32_t n_mops = (uint32_t)(mops.size() / lol::MOP_DWORDS);
-	if (n_mops > 3 * LOL_MAX_OPS) return fail(ctx, LOL_GPU_ERR_UNSUPPORTED, "program exceeds interpreter limits");
+	if (n_mops > 2 * LOL_MAX_OPS) return fail(ctx, LOL_GPU_ERR_UNSUPPORTED, "program exceeds interpreter limits");
 	{
 		const std::vector<uint32_t> nofix = build_mops(*prog, &fast, roots, cull_plan, true);
 		mops.insert(mops.end(), nofix.begin(), nofix.end());

@@ -449,39 +449,38 @@ __device__ __forceinline__ float sd_round_box_fast(V3 p, float cx, float cy, flo
  * so a chain of smooth unions whose one child is a primitive never touches the stack, and scene4's ten
  * post-order ops are seven macro-ops.
  *
- * Record = one GRANULE of 8 dwords (32 bytes, one s_load_dwordx8): header bits + object id | 4 parameters (sphere: centre,
- * radius; plane: y; POP: the stack slot; round box: centre, b.x) | k, 2k, .5/k of the smooth min (PUSH, which has none: the
- * stack slot in k's place).  A round box is two records: MOPB_RBOX_PRE (b, r: into four scalar registers, acc untouched),
- * then the box itself (centre; a load inside the box's own branch made the compiler structurize the whole group of rare
- * kinds with flag registers and copies: +8 VALU, +6 SALU per plane / POP record, -8 % on C3).  Round 2's
- * records were 12 dwords for every kind; what a record costs is mostly its fetch (padding them to 16 dwords, ONE
- * s_load_dwordx16, cost 3.5 %), and most records are spheres.
+ * Record = 12 dwords: header bits | object id (TOP) | 7 primitive parameters | k, 2k, .5/k of the smooth min.
+ * (Round 3 tried 8-dword records — id in the header's upper bits, stack slots in unused words, a round box's b and r sent ahead
+ * in a record of their own: +0.6 % on scene4, -8 % on scene.lol, whose box then costs two records; a second granule loaded inside
+ * the box's branch made the compiler structurize the whole group of rare kinds: -8 % on scene4.  16 dwords in ONE
+ * s_load_dwordx16: -3.5 %.)
  * The records are wave-uniform data and are fetched with SCALAR loads straight into SGPRs
  * (constant address space, uniform index → s_load_dwordx4 through the scalar cache): measured on MI355X
  * (tools/salu_rate.hip) a scalar-cache dword costs ~2 cycles per SIMD against 8.6 for a ds_read_b32 in which all
  * 64 lanes read one LDS address, and it needs no LDS-address VGPR and no v_readfirstlane; the header word is
  * then already scalar, so the dispatch is s_cmp / s_cbranch.  This replaced the LDS-staged op list of round 1
  * (VALU 2.4x, SALU 11x the specialised kernel's; profiles/README.md). */
-constexpr int MOP_DWORDS = 8;
-constexpr u32 MOP_ID_SHIFT = 21u;    /* header bits 21-31: the object's id (TOP records; ids <= LOL_MAX_OPS = 1024) */
+constexpr int MOP_DWORDS = 12;
 enum { MOP_SPHERE = 0, MOP_RBOX = 1, MOP_PLANE = 2, MOP_POP = 3 };          /* what x is          */
 enum { MOP_SET = 0, MOP_PUSH = 1, MOP_SMIN = 2, MOP_SMIN_X = 3 };           /* how it is combined */
 /* header word: one bit per decision */
 constexpr u32 MOPB_SPHERE = 1u, MOPB_RBOX = 2u, MOPB_PLANE = 4u, MOPB_POP = 8u;
-constexpr u32 MOPB_RBOX_PRE = 16u;   /* the record in front of a round box: b, r — kept in scalar registers for the box that follows */
-constexpr u32 MOP_TOP = 32u;         /* acc is a finished top-level object: id in the header's upper bits          */
+constexpr u32 MOP_FASTDIV = 16u;     /* the smooth min's blend factor was proven for this k (word 9): words 10, 11 = 2k, .5/k */
+constexpr u32 MOP_TOP = 32u;         /* acc is a finished top-level object: id in word 1                           */
 constexpr u32 MOPB_PUSH = 64u, MOPB_SMIN = 128u, MOPB_X_IS_A = 256u;   /* SET = none of PUSH / SMIN */
 /* summary bits, so that the common record (a sphere, no push, not the end of an object) pays ONE s_bitcmp for each
  * group of rare cases instead of an s_and + s_cmp: */
-constexpr u32 MOPB_NOT_SPHERE = 512u;   /* = RBOX | PLANE | POP | RBOX_PRE */
+constexpr u32 MOPB_NOT_SPHERE = 512u;   /* = RBOX | PLANE | POP */
 constexpr u32 MOPB_TAIL = 1024u;        /* = PUSH | TOP (set by build_mops when it sets MOP_TOP) */
-/* which smooth min, one bit each (mop_smin_bits): */
-constexpr u32 MOPB_SMIN_AF = 2048u;     /* sminf_fastdiv<false>(acc, x): k proven without v_div_fixup_f32 as well, in a list built for that */
+/* which smooth min, one bit each (set by build_mops next to MOPB_SMIN / MOPB_X_IS_A / MOP_FASTDIV): */
+constexpr u32 MOPB_SMIN_AF = 2048u;     /* sminf_fastdiv<false>(acc, x): k proven without v_div_fixup_f32 as well (MOP_NOFIXUP: only in the list
+                                         * that lol_gpu.hip launches when every operand difference is finite) */
 constexpr u32 MOPB_SMIN_XF = 4096u;     /* sminf_fastdiv<false>(x, acc) */
 constexpr u32 MOPB_SMIN_EXACT = 8192u;  /* unproven k: sminf_ with the correctly rounded division, order by MOPB_X_IS_A */
 constexpr u32 MOPB_SMIN_REST = 131072u; /* = SMIN_AFX | SMIN_XFX | SMIN_EXACT: the two common smooth minima pay ONE test for these */
 constexpr u32 MOPB_SMIN_AFX = 262144u;  /* sminf_fastdiv<true>(acc, x): k proven only with the fixup */
 constexpr u32 MOPB_SMIN_XFX = 524288u;  /* sminf_fastdiv<true>(x, acc) */
+constexpr u32 MOP_NOFIXUP = 1u << 24;   /* with MOP_FASTDIV: the blend factor is also proven without v_div_fixup_f32 (smin_h_fast<false>) */
 /* Exact object culling (lol_gpu.hip, "exact culling") in the interpreter: a record that finishes a top-level object
  * (MOP_TOP) may carry MOPB_CULL_NEXT / MOPB_CULL_CHAIN — the NEXT record is then not a macro-op but a test's constants
  * {word 0 = CULLC_* flags, word 1 = how many records after it belong to the objects the test guards, f[2..4] = C,
@@ -495,15 +494,13 @@ constexpr u32 CULLC_NEXT = 1u, CULLC_AFTER = 2u;
 constexpr u32 MOP_TIE = 32768u;         /* with MOP_TOP: evaluated after an object that follows it in the file → ties go to the lower id */
 constexpr u32 CULL_COOLDOWN = 3u;       /* after a test that did not allow the skip, this many evaluations do not test */
 /* The operand stack under the accumulator is a set of numbered slots, and the slot a PUSH fills / a POP empties is known
- * when the list is built (the post-order depth): it travels in the record (MOP_SLOT_POP / MOP_SLOT_PUSH: a word the
- * record does not otherwise use), so the slots never move.  (As a shifting stack — s[j] = s[j - 1] — every record of the
- * general path paid four v_mov for values it did not touch: the loop-carried copies of the shifted registers; read off the ISA.) */
-constexpr int MOP_SLOT_POP = 1, MOP_SLOT_PUSH = 5;     /* word index: a POP has no primitive, a PUSH no smooth min */
-constexpr int MOP_PARAMS = 1, MOP_K = 5;               /* first primitive parameter; k, 2k, .5/k */
-/* fastdiv: the blend factor was proven for this k (words MOP_K + 1, + 2 = 2k, .5/k); nofixup: also without v_div_fixup_f32 */
-__host__ __device__ constexpr u32 mop_smin_bits(u32 hdr, bool fastdiv, bool nofixup) {
-	return !(hdr & MOPB_SMIN) ? 0u : !fastdiv ? (MOPB_SMIN_EXACT | MOPB_SMIN_REST)
-	     : nofixup ? ((hdr & MOPB_X_IS_A) ? MOPB_SMIN_XF : MOPB_SMIN_AF)
+ * when the list is built (the post-order depth): it travels in the record (bits 20-23), so the slots never move.  (As a
+ * shifting stack — s[j] = s[j - 1] — every record of the general path paid four v_mov for values it did not touch: the
+ * loop-carried copies of the shifted registers; read off the ISA.) */
+constexpr u32 MOP_SLOT_SHIFT = 20u, MOP_SLOT_MASK = 15u;
+__host__ __device__ constexpr u32 mop_smin_bits(u32 hdr) {
+	return !(hdr & MOPB_SMIN) ? 0u : !(hdr & MOP_FASTDIV) ? (MOPB_SMIN_EXACT | MOPB_SMIN_REST)
+	     : (hdr & MOP_NOFIXUP) ? ((hdr & MOPB_X_IS_A) ? MOPB_SMIN_XF : MOPB_SMIN_AF)
 	     : ((hdr & MOPB_X_IS_A) ? MOPB_SMIN_XFX : MOPB_SMIN_AFX) | MOPB_SMIN_REST;
 }
 __host__ __device__ constexpr u32 mop_header(u32 kind, u32 comb) {
@@ -537,7 +534,6 @@ struct Interp {
 		mop_ptr rec = (mop_ptr)(unsigned long long)mops;
 		Range r = rg;
 		u32 cl = cool;
-		u32 box0 = 0, box1 = 0, box2 = 0, box3 = 0;      /* b, r of the round box that follows (MOPB_RBOX_PRE) */
 		float s[SSIZE];
 #pragma unroll
 		for (int i = 0; i < SSIZE; i++) s[i] = 0.f;
@@ -548,13 +544,13 @@ struct Interp {
 		for (; rec != end; rec += MOP_DWORDS) {                           /* (the TAIL branch may jump further) */
 			/* the whole record at once, up here: read where they are used, the fields arrived in three or four
 			 * separate scalar loads per record, each with its own wait (the branches below are barriers for the
-			 * compiler's load merging) — ONE s_load_dwordx8 and one wait instead */
-			const u32 w0 = rec[0], w1 = rec[1], w2 = rec[2], w3 = rec[3], w4 = rec[4], w5 = rec[5], w6 = rec[6], w7 = rec[7];
-			asm volatile("" :: "s"(w0), "s"(w1), "s"(w2), "s"(w3), "s"(w4), "s"(w5), "s"(w6), "s"(w7));
+			 * compiler's load merging) — one s_load_dwordx8 + one x4 and ONE wait instead */
+			const u32 w0 = rec[0], w1 = rec[1], w2 = rec[2], w3 = rec[3], w4 = rec[4], w5 = rec[5], w6 = rec[6], w7 = rec[7],
+			          w8 = rec[8], w9 = rec[9], w10 = rec[10], w11 = rec[11];
+			asm volatile("" :: "s"(w0), "s"(w1), "s"(w2), "s"(w3), "s"(w4), "s"(w5), "s"(w6), "s"(w7), "s"(w8), "s"(w9), "s"(w10), "s"(w11));
 			const u32 hdr = w0;
-			const u32 wv[MOP_DWORDS] = { w0, w1, w2, w3, w4, w5, w6, w7 };
+			const u32 wv[MOP_DWORDS] = { w0, w1, w2, w3, w4, w5, w6, w7, w8, w9, w10, w11 };
 			auto F = [&](int j) { return __builtin_bit_cast(float, wv[j]); };
-			auto B = [](u32 v) { return __builtin_bit_cast(float, v); };
 			auto C = [&](int j) { return __builtin_bit_cast(float, rec[j]); };      /* a test's constants record, after rec has moved on to it */
 			/* one-hot header bits, tested one by one (s_bitcmp1 + s_cbranch each) with no else-chains: every `if`
 			 * is a plain skip-ahead, which the compiler lowers without the flag registers it needs for if / else-if */
@@ -568,22 +564,17 @@ struct Interp {
 #define LOL_OFTEN(c) __builtin_expect(!!(c), 1)
 			float x = 0.f;
 			if (LOL_OFTEN(hdr & MOPB_SPHERE))
-				x = KIND ? sd_sphere_fast<KIND ? KIND : 1>(p, F(1), F(2), F(3), F(4), r) : sd_sphere(p, F(1), F(2), F(3), F(4));
+				x = KIND ? sd_sphere_fast<KIND ? KIND : 1>(p, F(2), F(3), F(4), F(5), r) : sd_sphere(p, F(2), F(3), F(4), F(5));
 			if (LOL_RARE(hdr & MOPB_NOT_SPHERE)) {                   /* grouped: a sphere macro-op pays one test for these */
 				LOL_KEEP_BRANCH();
-				if (hdr & MOPB_RBOX_PRE) {                           /* SET with x = acc: nothing changes but the box registers */
-					LOL_KEEP_BRANCH();
-					box0 = w1; box1 = w2; box2 = w3; box3 = w4;
-					x = acc;
-				}
 				if (hdr & MOPB_RBOX)
-					x = KIND ? sd_round_box_fast<KIND ? KIND : 1>(p, F(1), F(2), F(3), B(box0), B(box1), B(box2), B(box3), r)
-					         : sd_round_box(p, F(1), F(2), F(3), B(box0), B(box1), B(box2), B(box3));
+					x = KIND ? sd_round_box_fast<KIND ? KIND : 1>(p, F(2), F(3), F(4), F(5), F(6), F(7), F(8), r)
+					         : sd_round_box(p, F(2), F(3), F(4), F(5), F(6), F(7), F(8));
 				if (hdr & MOPB_PLANE)
-					x = p.y - F(1);                              /* plane: (p - (0,y,0)).y */
+					x = p.y - F(2);                              /* plane: (p - (0,y,0)).y */
 				if (hdr & MOPB_POP) {
 					LOL_KEEP_BRANCH();
-					const u32 slot = wv[MOP_SLOT_POP];
+					const u32 slot = hdr >> MOP_SLOT_SHIFT & MOP_SLOT_MASK;
 					x = s[0];
 #pragma unroll
 					for (int j = 1; j < SSIZE; j++) x = slot == (u32)j ? s[j] : x;
@@ -593,16 +584,16 @@ struct Interp {
 				/* four independent skip-aheads (operand order x fast / exact blend factor), the common fast ones first:
 				 * a nested if / ?: here made the compiler hoist the FASTDIV test through a VGPR and add flag registers */
 				LOL_KEEP_BRANCH();
-				if (LOL_OFTEN(hdr & MOPB_SMIN_AF)) { LOL_KEEP_BRANCH(); x = sminf_fastdiv<false>(acc, x, F(5), F(6), F(7)); }
-				if (LOL_RARE(hdr & MOPB_SMIN_XF)) { LOL_KEEP_BRANCH(); x = sminf_fastdiv<false>(x, acc, F(5), F(6), F(7)); }
+				if (LOL_OFTEN(hdr & MOPB_SMIN_AF)) { LOL_KEEP_BRANCH(); x = sminf_fastdiv<false>(acc, x, F(9), F(10), F(11)); }
+				if (LOL_RARE(hdr & MOPB_SMIN_XF)) { LOL_KEEP_BRANCH(); x = sminf_fastdiv<false>(x, acc, F(9), F(10), F(11)); }
 				if (LOL_RARE(hdr & MOPB_SMIN_REST)) {                /* grouped, like the kinds above */
 					LOL_KEEP_BRANCH();
-					if (hdr & MOPB_SMIN_AFX) { LOL_KEEP_BRANCH(); x = sminf_fastdiv<true>(acc, x, F(5), F(6), F(7)); }
-					if (hdr & MOPB_SMIN_XFX) { LOL_KEEP_BRANCH(); x = sminf_fastdiv<true>(x, acc, F(5), F(6), F(7)); }
+					if (hdr & MOPB_SMIN_AFX) { LOL_KEEP_BRANCH(); x = sminf_fastdiv<true>(acc, x, F(9), F(10), F(11)); }
+					if (hdr & MOPB_SMIN_XFX) { LOL_KEEP_BRANCH(); x = sminf_fastdiv<true>(x, acc, F(9), F(10), F(11)); }
 					if (hdr & MOPB_SMIN_EXACT) {
 						LOL_KEEP_BRANCH();
-						if (!(hdr & MOPB_X_IS_A)) { LOL_KEEP_BRANCH(); x = sminf_(acc, x, F(5)); }
-						if (hdr & MOPB_X_IS_A) { LOL_KEEP_BRANCH(); x = sminf_(x, acc, F(5)); }
+						if (!(hdr & MOPB_X_IS_A)) { LOL_KEEP_BRANCH(); x = sminf_(acc, x, F(9)); }
+						if (hdr & MOPB_X_IS_A) { LOL_KEEP_BRANCH(); x = sminf_(x, acc, F(9)); }
 					}
 				}
 			}
@@ -610,13 +601,13 @@ struct Interp {
 				LOL_KEEP_BRANCH();
 				if (hdr & MOPB_PUSH) {
 					LOL_KEEP_BRANCH();
-					const u32 slot = wv[MOP_SLOT_PUSH];
+					const u32 slot = hdr >> MOP_SLOT_SHIFT & MOP_SLOT_MASK;
 #pragma unroll
 					for (int j = 0; j < SSIZE; j++) s[j] = slot == (u32)j ? acc : s[j];
 				}
 				if (hdr & MOP_TOP) {                                    /* (tests only follow finished objects) */
 					LOL_KEEP_BRANCH();
-					const u32 id = hdr >> MOP_ID_SHIFT;
+					const u32 id = w1;
 					bool take = x < best;
 					if (hdr & MOP_TIE) { LOL_KEEP_BRANCH(); take = take || (x == best && best_id > id); }
 					if (take) { best = x; best_id = id; }
