@@ -522,12 +522,13 @@ struct Interp {
 
 	/* Inlined into the march / normal / shadow loops: as a real (noinline) function it was 8 % slower — arguments
 	 * travel in VGPRs and need v_readfirstlane, plus call / return and the callee's register shuffling. */
-	/* The loops around this keep `alive` as a per-lane bool and vote on it themselves (MASKS = false): this kernel is
+	/* `care` stays a per-lane bool here and the loops around it vote on `alive` itself (MASKS = false): this kernel is
 	 * bound by its scalar side, where the mask bookkeeping of the other form costs more than the two vector
-	 * instructions per vote it saves (measured: -1.8 % with masks; the specialised kernel +4.1 %).  `care` is that vote,
-	 * the one the loop has just tested: the culling tests combine it with their own ballots on the scalar side. */
+	 * instructions per vote it saves (measured: -1.8 % with masks in round 2, -2 % in round 3; the specialised kernel +4.1 %).
+	 * (Handing the loop's own vote down as the mask: +0.5 % here, but the changed loop text cost the SPECIALISED kernel 2.4 %
+	 * on C2 — same instructions, another schedule.) */
 	static constexpr bool MASKS = false;
-	__device__ __forceinline__ void eval(V3 p, float& best_out, u32& id_out, u64 care = ~0ull) {
+	__device__ __forceinline__ void eval(V3 p, float& best_out, u32& id_out, bool care = true) {
 		/* everything the loop carries is a local: the trip count and the list pointer must stay provably
 		 * wave-uniform (scalar loop, scalar loads, scalar branches), which they do not when they live behind
 		 * `this` next to per-lane results written through references */
@@ -623,7 +624,7 @@ struct Interp {
 							const float u = (best + C(5)) * C(6);
 							/* any lane that cares and may not skip (skip = l2 > u*u && u > 0).  One ballot per comparison, combined
 							 * on the scalar side: the ballot of the compound condition went through a VGPR (v_cndmask + v_cmp_ne) */
-							const u64 needed = care & (vote(!(l2 > u * u)) | vote(!(u > 0.f)));
+							const u64 needed = vote(care) & (vote(!(l2 > u * u)) | vote(!(u > 0.f)));
 							cl = CULL_COOLDOWN + 1u;                        /* (one branch: `if (needed != 0)` after it cost a flag register) */
 							if (needed == 0) {
 								LOL_KEEP_BRANCH();
@@ -645,7 +646,7 @@ struct Interp {
 							const float cx = p.x - C(2), cy = p.y - C(3), cz = p.z - C(4);
 							const float l2 = (cx * cx + cy * cy) + cz * cz;
 							const float u = (best + C(5)) * C(6);
-							if ((care & (vote(!(l2 > u * u)) | vote(!(u > 0.f)))) == 0) {
+							if ((vote(care) & (vote(!(l2 > u * u)) | vote(!(u > 0.f)))) == 0) {
 								LOL_KEEP_BRANCH();
 								const u32 k = rec[1];
 								rec += k * MOP_DWORDS;
@@ -685,12 +686,11 @@ __device__ __forceinline__ Hit march(Sdf& sdf, V3 ro, V3 rd, int max_steps) {
 	bool alive = true;
 	u64 marching = vote(true);                    /* `alive` as a mask (see vote()); kept up only where Sdf::MASKS */
 	for (int i = 0; i < max_steps; i++) {
-		const u64 am = Sdf::MASKS ? marching : vote(alive);
-		if (am == 0) break;                                          /* every lane has hit or escaped */
+		if ((Sdf::MASKS ? marching : vote(alive)) == 0) break;       /* every lane has hit or escaped */
 		V3 p = add(ro, scale(rd, dist));
 		float d; u32 did;
 		/* lanes that are done do not care: they do not keep an object from being culled */
-		sdf.eval(p, d, did, am);
+		if constexpr (Sdf::MASKS) sdf.eval(p, d, did, marching); else sdf.eval(p, d, did, alive);
 		if (alive) {
 			dist += d;
 			id = did;
@@ -723,11 +723,10 @@ __device__ __forceinline__ float soft_shadow(Sdf& sdf, V3 p, V3 dir, float max_d
 	bool alive = needed;          /* a lane that does not need the factor never marches (returns 1) */
 	u64 marching = Sdf::MASKS ? vote(needed) : 0;
 	for (int i = 0; i < 128; i++) {
-		const u64 am = Sdf::MASKS ? marching : vote(alive);
-		if (am == 0) break;
+		if ((Sdf::MASKS ? marching : vote(alive)) == 0) break;
 		V3 q = add(ro, scale(dir, t));
 		float s; u32 sid;
-		sdf.eval(q, s, sid, am);
+		if constexpr (Sdf::MASKS) sdf.eval(q, s, sid, marching); else sdf.eval(q, s, sid, alive);
 		if (alive) {
 			res = minf_(res, 50.f * s / t);
 			t += s;

@@ -1,0 +1,5 @@
+# A/B of library builds on the specialised kernel over the BASELINE workloads on one box: every library under tools/ab/ and the in-tree one.
+R=${GRAFT_REPO_ROOT:?run on the GPU box}; cd $R
+for rep in 1 2 3; do for lib in loltracer_amd/lib/liblol_gpu.so tools/ab/*.so; do for w in c2 c3; do
+LOL_GPU_LIB=$R/$lib LOL_BENCH_HOST_SURFACE=0 timeout -k 10 200 python3 bench.py --no-cpu-baseline --steps 40 --workload $w 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$lib', '$w', d['value'], d['roofline']['kernel_ms_avg'], d['config']['kernel'])"
+done; done; done
