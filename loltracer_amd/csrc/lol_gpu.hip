@@ -598,6 +598,7 @@ std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast, co
 	};
 	/* LOL_GPU_INTERP_CULL_MIN_PRIMS: leave out the tests of runs with fewer primitives (measured: 1, i.e. keeping
 	 * every test, is fastest here too — a test is one turn of a scalar loop inside the rare TAIL branch). */
+	const bool fuse_pops = !(getenv("LOL_GPU_INTERP_FUSE_POPS") && getenv("LOL_GPU_INTERP_FUSE_POPS")[0] == '0');     /* A/B switch */
 	uint32_t min_prims = 1;
 	if (const char* e = getenv("LOL_GPU_INTERP_CULL_MIN_PRIMS")) min_prims = (uint32_t)std::max(1, atoi(e));
 	std::vector<CullInterval> ivs;
@@ -625,6 +626,7 @@ std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast, co
 			out.insert(out.end(), c, c + lol::MOP_DWORDS);
 		}
 		int depth = 0;                                   /* post-order stack depth before the current op */
+		bool emitted = false;                            /* this object has a record yet (`last` is one of its own) */
 		size_t last = 0;                                 /* start of the macro-op that produced the current acc */
 		for (uint32_t i = R.first; i < R.top; i++) {
 			const lol_op& o = P.ops[i];
@@ -643,12 +645,22 @@ std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast, co
 					depth++;
 				}
 			} else {                                     /* SMIN / SMIN_R on two computed operands */
+				/* ... rides on the record that has just finished the second operand when that record's own smooth min has the
+				 * same, proven k (the record's k words serve both; lol_kernel.h, MOPB_POST): one record less to fetch and dispatch */
+				if (fuse_pops && emitted && (out[last] & lol::MOPB_SMIN) && (out[last] & lol::MOP_FASTDIV) && !(out[last] & lol::MOPB_POST) &&
+				    out[last + 9] == fbits32(o.f[0])) {
+					out[last] |= lol::MOPB_POST | lol::MOPB_STACK | lol::MOPB_TAIL | (o.op == LOL_OP_SMIN ? lol::MOPB_POST_YA : 0u) |
+					             (uint32_t)(depth - 2) << lol::MOP_POST_SLOT_SHIFT;
+					depth--;
+					continue;
+				}
 				m[0] = lol::mop_header(lol::MOP_POP, o.op == LOL_OP_SMIN ? lol::MOP_SMIN_X : lol::MOP_SMIN);
 				m[0] |= (uint32_t)(depth - 2) << lol::MOP_SLOT_SHIFT;                           /* the operand under the accumulator */
 				smin_fields(m, o);
 				depth--;
 			}
 			last = out.size();
+			emitted = true;
 			out.insert(out.end(), m, m + lol::MOP_DWORDS);
 		}
 		out[last] |= lol::MOP_TOP | lol::MOPB_TAIL | (R.id < max_id_seen ? lol::MOP_TIE : 0u);

@@ -447,7 +447,7 @@ __device__ __forceinline__ float sd_round_box_fast(V3 p, float cx, float cy, flo
  *   comb  = SET (acc = x) | PUSH (push acc; acc = x) | SMIN (acc = sminf(acc, x)) | SMIN_X (acc = sminf(x, acc))
  *   top   : if (acc < best) { best = acc; best_id = id }            — sdf(), strict '<' (naive_renderer.c:39)
  * so a chain of smooth unions whose one child is a primitive never touches the stack, and scene4's ten
- * post-order ops are seven macro-ops.
+ * post-order ops are seven macro-ops (six with MOPB_POST, below).
  *
  * Record = 12 dwords: header bits | object id (TOP) | 7 primitive parameters | k, 2k, .5/k of the smooth min.
  * (Round 3 tried 8-dword records — id in the header's upper bits, stack slots in unused words, a round box's b and r sent ahead
@@ -471,7 +471,7 @@ constexpr u32 MOPB_PUSH = 64u, MOPB_SMIN = 128u, MOPB_X_IS_A = 256u;   /* SET = 
 /* summary bits, so that the common record (a sphere, no push, not the end of an object) pays ONE s_bitcmp for each
  * group of rare cases instead of an s_and + s_cmp: */
 constexpr u32 MOPB_NOT_SPHERE = 512u;   /* = RBOX | PLANE | POP */
-constexpr u32 MOPB_TAIL = 1024u;        /* = PUSH | TOP (set by build_mops when it sets MOP_TOP) */
+constexpr u32 MOPB_TAIL = 1024u;        /* = PUSH | TOP | POST (set by build_mops when it sets MOP_TOP / MOPB_POST) */
 /* which smooth min, one bit each (set by build_mops next to MOPB_SMIN / MOPB_X_IS_A / MOP_FASTDIV): */
 constexpr u32 MOPB_SMIN_AF = 2048u;     /* sminf_fastdiv<false>(acc, x): k proven without v_div_fixup_f32 as well (MOP_NOFIXUP: only in the list
                                          * that lol_gpu.hip launches when every operand difference is finite) */
@@ -480,6 +480,12 @@ constexpr u32 MOPB_SMIN_EXACT = 8192u;  /* unproven k: sminf_ with the correctly
 constexpr u32 MOPB_SMIN_REST = 131072u; /* = SMIN_AFX | SMIN_XFX | SMIN_EXACT: the two common smooth minima pay ONE test for these */
 constexpr u32 MOPB_SMIN_AFX = 262144u;  /* sminf_fastdiv<true>(acc, x): k proven only with the fixup */
 constexpr u32 MOPB_SMIN_XFX = 524288u;  /* sminf_fastdiv<true>(x, acc) */
+/* A smooth min of two finished sub-unions (a POP record of its own in round 2) rides on the record that finished the second
+ * one when both use the same, proven k: after that record's own combine, acc' = sminf(s[slot], acc') or sminf(acc', s[slot]).
+ * Lives in the TAIL group (ordinary records pay nothing); slot in bits 25-28. */
+constexpr u32 MOPB_POST = 1u << 29, MOPB_POST_YA = 1u << 30;      /* YA: the popped value is the smooth min's first operand */
+constexpr u32 MOP_POST_SLOT_SHIFT = 25u;
+constexpr u32 MOPB_STACK = 1u << 31;                              /* = POST | PUSH */
 constexpr u32 MOP_NOFIXUP = 1u << 24;   /* with MOP_FASTDIV: the blend factor is also proven without v_div_fixup_f32 (smin_h_fast<false>) */
 /* Exact object culling (lol_gpu.hip, "exact culling") in the interpreter: a record that finishes a top-level object
  * (MOP_TOP) may carry MOPB_CULL_NEXT / MOPB_CULL_CHAIN — the NEXT record is then not a macro-op but a test's constants
@@ -505,7 +511,7 @@ __host__ __device__ constexpr u32 mop_smin_bits(u32 hdr) {
 }
 __host__ __device__ constexpr u32 mop_header(u32 kind, u32 comb) {
 	return (1u << kind) | (kind != MOP_SPHERE ? MOPB_NOT_SPHERE : 0u) |
-	       (comb == MOP_PUSH ? (MOPB_PUSH | MOPB_TAIL) : comb == MOP_SMIN ? MOPB_SMIN : comb == MOP_SMIN_X ? (MOPB_SMIN | MOPB_X_IS_A) : 0u);
+	       (comb == MOP_PUSH ? (MOPB_PUSH | MOPB_TAIL | MOPB_STACK) : comb == MOP_SMIN ? MOPB_SMIN : comb == MOP_SMIN_X ? (MOPB_SMIN | MOPB_X_IS_A) : 0u);
 }
 
 /* scalar (constant address space) view of the list; loaded dword by dword — the compiler merges the loads into
@@ -601,11 +607,24 @@ struct Interp {
 			}
 			if (LOL_RARE(hdr & MOPB_TAIL)) {
 				LOL_KEEP_BRANCH();
-				if (hdr & MOPB_PUSH) {
+				if (hdr & MOPB_STACK) {                                 /* POST | PUSH: the end of an object pays one test for both */
 					LOL_KEEP_BRANCH();
-					const u32 slot = hdr >> MOP_SLOT_SHIFT & MOP_SLOT_MASK;
+					if (hdr & MOPB_POST) {
+						LOL_KEEP_BRANCH();
+						const u32 ps = hdr >> MOP_POST_SLOT_SHIFT & MOP_SLOT_MASK;
+						float y = s[0];
 #pragma unroll
-					for (int j = 0; j < SSIZE; j++) s[j] = slot == (u32)j ? acc : s[j];
+						for (int j = 1; j < SSIZE; j++) y = ps == (u32)j ? s[j] : y;
+						const bool ya = (hdr & MOPB_POST_YA) != 0u;
+						const float a = ya ? y : x, b = ya ? x : y;
+						x = sminf_fastdiv<true>(a, b, F(9), F(10), F(11));      /* (one body for both orders and both lists: the form with the fixup) */
+					}
+					if (hdr & MOPB_PUSH) {
+						LOL_KEEP_BRANCH();
+						const u32 slot = hdr >> MOP_SLOT_SHIFT & MOP_SLOT_MASK;
+#pragma unroll
+						for (int j = 0; j < SSIZE; j++) s[j] = slot == (u32)j ? acc : s[j];
+					}
 				}
 				if (hdr & MOP_TOP) {                                    /* (tests only follow finished objects) */
 					LOL_KEEP_BRANCH();

@@ -166,6 +166,42 @@ def test_large_scenes_are_specialised_too(torch_cuda, monkeypatch, n_unions, inl
     r.close()
 
 
+def test_unions_of_unions_with_one_smoothness(torch_cuda, monkeypatch):
+    """Random trees whose smooth unions all share one k: the interpreter then folds every "smooth min of two finished sub-unions"
+    into the record that finished the second one (lol_gpu.hip build_mops, MOPB_POST) — chains of them, at every stack depth,
+    with round boxes and planes in between.  Against the oracle, and against the same frames with the folding switched off."""
+    rng = np.random.default_rng(2024)
+
+    def tree(d, k):
+        if d == 0 or rng.random() < 0.2:
+            return rand_leaf(rng)
+        a, b = tree(d - 1, k), tree(int(rng.integers(0, d)), k)
+        if rng.random() < 0.5:
+            a, b = b, a
+        return "smooth_union { smoothness = %s, a = %s, b = %s }" % (num(k), a, b)
+    mats = ("materials { { shininess = 2, diffuse = (0,0,0), specular = (0,0,0), ambient = (.02,.02,.02) },"
+            " { shininess = 8, diffuse = (.5,.4,.3), specular = (.2,.2,.2), ambient = (.1,.1,.1) } }\n")
+    for n in range(10):
+        k = float(rng.choice([0.5, 1, 3, 0.25]))
+        objs = []
+        for _ in range(int(rng.integers(1, 4))):
+            head, rest = tree(int(rng.integers(2, 6)), k).split("{", 1)
+            objs.append("%s{ material = #1,%s" % (head, rest))
+        text = mats + ("scene { camera { point = (0, 2, 3), direction = (0, -0.2, -1), fov = 110 },"
+                       " point_light { point = (1,9,0), diffuse_intensity = (2,2,2), specular_intensity = (1,1,1) }, "
+                       + ", ".join(objs) + " }")
+        sc = S.Scene.parse_string(text)
+        frames = []
+        for fuse in ("1", "0"):
+            monkeypatch.setenv("LOL_GPU_INTERP_FUSE_POPS", fuse)
+            r = gpu.Renderer(0, specialize=4)
+            g = gpu_render(torch_cuda, r, sc, 48, 24)
+            check_against_oracle(g, sc, 48, 24)
+            frames.append(g["xrgb"])
+            r.close()
+        assert np.array_equal(frames[0], frames[1]), "scene %d" % n
+
+
 def test_deep_tree_needs_the_big_operand_stack(torch_cuda):
     """A perfectly balanced smooth-union tree of 512 spheres (1024 ops): operand stack depth 10 — the interpreter's
     largest instantiation and the out-of-line specialised SDF; both against the oracle."""
