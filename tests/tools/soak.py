@@ -1,4 +1,4 @@
-"""Soak: many random scenes, GPU (spec + interp) vs the CPU oracle.  python tests/tools/soak.py [n] [seed] [stress]"""
+"""Soak: many random scenes, GPU (spec + interp) vs the CPU oracle.  python tests/tools/soak.py [n] [seed] [stress | onek]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -10,6 +10,7 @@ from loltracer_amd import gpu, scene as S
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 stress = len(sys.argv) > 3 and sys.argv[3] == "stress"
+onek = len(sys.argv) > 3 and sys.argv[3] == "onek"      # every smooth union of a scene shares one k: the interpreter folds its pops (MOPB_POST)
 rng = np.random.default_rng(seed)
 
 
@@ -48,6 +49,10 @@ rs = {m: gpu.Renderer(0, specialize=m) for m in (1, 4)}
 bad = 0
 for i in range(n):
     text = stress_scene(rng) if stress else F.rand_scene(rng)
+    if onek:
+        import re
+        k = F.num(rng.choice([0.5, 1, 2, 3, 0.25, 7.5, 0.01, 20]))
+        text = re.sub(r"smoothness = [^,]+,", "smoothness = %s," % k, text)
     sc = S.Scene.parse_string(text)
     w, h = int(rng.integers(17, 90)), int(rng.integers(9, 60))
     for m, r in rs.items():
