@@ -1499,6 +1499,7 @@ int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog) {
 	if (n_mops > 2 * LOL_MAX_OPS) return fail(ctx, LOL_GPU_ERR_UNSUPPORTED, "program exceeds interpreter limits");
 	{
 		const std::vector<uint32_t> nofix = build_mops(*prog, &fast, roots, cull_plan, true);
+		if (nofix.size() != mops.size()) return fail(ctx, LOL_GPU_ERR_UNSUPPORTED, "interpreter lists differ in length");      /* (same records by construction) */
 		mops.insert(mops.end(), nofix.begin(), nofix.end());
 	}
 	const int next = ctx->cur ^ 1;
