@@ -1121,6 +1121,10 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
 		/* ... and no post-RA scheduling pass: it re-orders the ILP-friendly schedule after register allocation and
 		 * costs 10 % on C3 (4650 -> 5150 Mpixels/s without it, same box and call; nothing on the large scenes) */
 		opts.push_back("-mllvm"); opts.push_back("-enable-post-misched=0");
+		/* ... and SimplifyCFG may turn small two-sided branches into selects more readily (default threshold 2): the per-lane
+		 * `if (alive) { ... }` updates around the SDF become straight-line code for the ILP scheduler.  Sweep of 3 ... 64 on one
+		 * box (tools/rtc_flag_sweep.sh phi): from 4 upwards C2 +1.5 ... 2.5 %, C3 +0.2 %, the large scenes +-3 %; same bits. */
+		opts.push_back("-mllvm"); opts.push_back("-phi-node-folding-threshold=8");
 	}
 	char d0[32], d1[32], d2[32];
 	if (shape) {
