@@ -9,6 +9,16 @@ run() { # $1 = LOL_GPU_SCHED value ("" = library default), rest = extra flags
 	done
 	echo "| sched=${s:-lib} $*"
 }
+if [ "$1" = ifcvt ]; then for rep in 1 2; do
+run ""
+run "" -mllvm -amdgpu-early-ifcvt=1
+run "" -mllvm -simplifycfg-branch-fold-threshold=4
+run "" -mllvm -amdgpu-disable-unclustered-high-rp-reschedule=1
+run "" -mllvm -amdgpu-set-wave-priority=1
+run "" -mllvm -phi-node-folding-threshold=8 -mllvm -amdgpu-early-ifcvt=1
+run "" -mllvm -enable-shrink-wrap=0
+run "" -mllvm -amdgpu-atomic-optimizer-strategy=None
+done; exit 0; fi
 if [ "$1" = phi ]; then for rep in 1 2 3; do
 run ""
 for t in 3 4 6 8 12 16 32 64; do run "" -mllvm -phi-node-folding-threshold=$t; done
