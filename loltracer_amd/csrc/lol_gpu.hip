@@ -574,14 +574,17 @@ CullPlan plan_culling(const std::vector<RootBound>& roots, bool enabled) {
  *                                           combine is sminf(acc, x); SMIN_R (top is a) gives sminf(x, acc);
  *   primitive otherwise                   → SET when nothing is on the stack yet, else PUSH (acc goes under);
  *   SMIN / SMIN_R after a non-primitive   → x = the popped entry under acc: SMIN has a = x, b = acc → sminf(x, acc);
- *                                           SMIN_R has a = acc, b = x → sminf(acc, x);
+ *                                           SMIN_R has a = acc, b = x → sminf(acc, x) — a POP record of its own, unless the
+ *                                           record before it has a smooth min of the same, proven k: then it rides on that
+ *                                           record (MOPB_POST: after the record's own combine);
  *   TOP                                   → a flag on the macro-op that produced the value (+ MOP_TIE where the
  *                                           object is evaluated after one that follows it in the file).
  * The objects come in the order of `plan` (unbounded ones first).  Every test of the plan becomes a constants
  * record in front of the first object of its run (outer runs first); the macro-op that finishes the object before
  * it gets MOPB_CULL_NEXT (the run of all bounded objects) and / or MOPB_CULL_CHAIN (inner runs), and the
  * CULLC_NEXT / CULLC_AFTER flags chain test records that follow one another directly.
- * `fast` lists the smoothness constants whose fast blend factor was proven on the device.
+ * `fast` lists the smoothness constants whose fast blend factor was proven on the device; allow_nofixup: this list may use the
+ * form without v_div_fixup where that was proven too (the caller builds both lists: same records, other smooth-min bits).
  */
 std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast, const std::vector<RootBound>& roots,
                                  const CullPlan& plan, bool allow_nofixup) {
