@@ -37,7 +37,7 @@ def main():
     hit = g["id"] != 0
     out = dict(scene=os.path.basename(a.scene), size=a.size, march_steps_per_pixel=march.mean(), shadow_steps_per_pixel=shadow.mean(),
                hit_fraction=float(hit.mean()))
-    for pw, ph in ((16, 4), (8, 8), (32, 2), (64, 1), (4, 4), (2, 2), (1, 1)):
+    for pw, ph in ((16, 4), (8, 8), (4, 16), (2, 32), (32, 2), (64, 1), (4, 4), (2, 2), (1, 1)):
         pm, ps, phit = patches(march, pw, ph), patches(shadow, pw, ph), patches(hit.astype(np.float64), pw, ph)
         lanes = pw * ph
         # what the wave executes: max over lanes of march steps; the 4 normal taps if any lane hit; shadow: the kernel marches
