@@ -64,6 +64,23 @@ def test_pmc_traffic_is_only_quoted_for_the_code_it_was_measured_on():
     assert spec["counters_avg_per_dispatch"]["SQ_INSTS_SALU"] != interp["counters_avg_per_dispatch"]["SQ_INSTS_SALU"]
 
 
+def test_pmc_summary_reports_the_common_value_and_lists_stray_dispatches(tmp_path):
+    """A deterministic kernel's instruction counters are the same for every dispatch; a dispatch that comes back with another
+    kernel's work counted in must not shift the summary (tools/pmc_summary.py), while cycle counters stay averages."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_summary
+    rows = ["Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp"]
+    for d in range(100):
+        rows.append(f"{d},lol_render_spec,SQ_INSTS_SALU,{371313520 if d != 7 else 373803700},{d * 10},{d * 10 + 5}")
+        rows.append(f"{d},lol_render_spec,GRBM_GUI_ACTIVE,{20000000 + d},{d * 10},{d * 10 + 5}")
+        rows.append(f"{d},other_kernel,SQ_INSTS_SALU,1,{d * 10},{d * 10 + 5}")
+    f = tmp_path / "pass.csv"
+    f.write_text("\n".join(rows) + "\n")
+    c, n, _ = pmc_summary.summarise([str(f)], "lol_render_spec")
+    assert c["SQ_INSTS_SALU"] == 371313520.0 and n["_dispatches_off_the_common_value"] == {"SQ_INSTS_SALU": 1}
+    assert abs(c["GRBM_GUI_ACTIVE"] - 20000049.5) < 1e-6 and n["SQ_INSTS_SALU"] == 100
+
+
 def test_root_share_candidates_are_one_launch_splits():
     from loltracer_amd import multi
     for world in (2, 4, 8):
