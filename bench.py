@@ -527,6 +527,34 @@ def main():
     for i in range(prewarm):
         step(i, False)
     fence()
+    # Set-up: the order in which a launch hands out its tiles (lol_gpu_set_tile_order).  Same pixels; which order is faster depends
+    # on the scene and the frame, so `auto` measures, like for the split above: rows, columns, rows, columns —
+    # a dozen frames each on warm clocks, the slowest rank's time, the better order if it is better by more than 1 %.
+    order_trials = None
+    want_order = os.environ.get("LOL_BENCH_TILE_ORDER", "auto")
+    if want_order in ("rows", "cols"):
+        r.set_tile_order(want_order == "cols")
+        tile_order = want_order
+    else:
+        best_ms = {"rows": float("inf"), "cols": float("inf")}
+        n_t = 12 if not orbit else min(12, len(cams))
+        for _round in range(2):
+            for o in ("rows", "cols"):
+                r.set_tile_order(o == "cols")
+                for i in range(3):
+                    step(i, False)
+                fence()
+                t0 = time.perf_counter()
+                for i in range(n_t):
+                    step(i, False)
+                fence()
+                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+                if world > 1:
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                best_ms[o] = min(best_ms[o], float(t.item()) / n_t * 1e3)
+        tile_order = "cols" if best_ms["cols"] < 0.99 * best_ms["rows"] else "rows"      # (all-reduced: every rank decides alike)
+        r.set_tile_order(tile_order == "cols")
+        order_trials = {k: round(v, 4) for k, v in best_ms.items()}
     for i in range(args.warmup):
         step(i, False)
     fence()
@@ -600,6 +628,8 @@ def main():
             "gather_ms": gather_ms,
             "partition": P.describe() if P is not None else None,
             "root_share_trials": trials or None,
+            # lol_gpu_set_tile_order: what the set-up measured (ms per frame, slowest rank, best of two rounds) and took
+            "tile_order": tile_order, "tile_order_trials_ms": order_trials,
             "assembly": None if pipe is None else ("lol_gpu_assemble_parts_at (library kernel, own stream)" if assembler else "torch index_select"),
             "host_issue_us_per_frame": round(host_s / max(steps, 1) * 1e6, 1),
             "prewarm_frames": prewarm,            # untimed set-up frames before the W warm-up steps (clock ramp)

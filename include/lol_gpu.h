@@ -225,6 +225,13 @@ int         lol_gpu_miss_skip_active(const lol_gpu* ctx);
  * On by default; set_cull(ctx, 0) before the upload or LOL_GPU_CULL=0 turn it off.
  */
 int         lol_gpu_set_cull(lol_gpu* ctx, int enable);
+/*
+ * The order in which a launch hands out its tiles of 16x4 pixels: 0 = row by row (the default), 1 = column by column (the launch
+ * grid transposed).  Same pixels either way; which is faster depends on the scene and the frame (scene4 at 4K: columns +2.4 %,
+ * scene.lol at 1080p: columns -7 %), so a host that cares times a few frames of each, as bench.py does at set-up.
+ * Takes effect at the next frame.  The reference has no counterpart: its thread pool claims pixels one by one (naive_renderer.c:216).
+ */
+int         lol_gpu_set_tile_order(lol_gpu* ctx, int columns);
 /* The bound behind that test for top-level object `root` (0-based, file order); no device needed.  Returns 1 and
  * the bounding sphere (centre, inflated radius R') when the object has one, 0 when it has none (planes, unions
  * with a plane or with smoothness <= 0, non-finite fields) and is therefore never culled. */

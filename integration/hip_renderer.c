@@ -17,7 +17,8 @@
  *                   these GPUs, each writing its bands into the surface,
  *                   include/lol_gpu.h lol_gpu_multi_*), --parts-per-device N,
  *                   --root-band-rows N (the first device's smaller share),
- *                   --max-steps N, and
+ *                   --max-steps N, --tile-columns (one GPU: tiles handed out column by
+ *                   column, lol_gpu_set_tile_order: faster on some scenes, slower on others), and
  *                   --dump-kernel BASE, the counterpart of the JIT renderer's
  *                   -j/--jitdump (tracing_jit_renderer.dasc:424-433): writes the
  *                   scene-specialised kernel as BASE.hip (generated source) and
@@ -77,7 +78,7 @@ void render_prepare(struct render_data* data, int argc, const char* argv[]) {
 	struct hip_renderer* r = calloc(1, sizeof *r);
 	int device = 0;
 	int devices[LOL_GPU_MULTI_MAX_DEVICES], n_devices = 0;
-	int parts_per_device = 0, root_band = -1;
+	int parts_per_device = 0, root_band = -1, tile_columns = 0;
 	const char* dump = NULL;
 	HOST_PRIVATE(data) = r;
 	if (!r) { fprintf(stderr, "hip_renderer: out of memory\n"); return; }
@@ -87,6 +88,7 @@ void render_prepare(struct render_data* data, int argc, const char* argv[]) {
 		const int is_steps = !strcmp(argv[i], "--max-steps"), is_dump = !strcmp(argv[i], "--dump-kernel");
 		const int is_ppd = !strcmp(argv[i], "--parts-per-device"), is_root = !strcmp(argv[i], "--root-band-rows");
 		if (!strcmp(argv[i], "--pipeline")) { r->pipeline = 1; continue; }
+		if (!strcmp(argv[i], "--tile-columns")) { tile_columns = 1; continue; }
 		if (!(is_device || is_devices || is_steps || is_dump || is_ppd || is_root)) continue;      /* the host's own flags */
 		if (i + 1 >= argc) { fprintf(stderr, "hip_renderer: %s needs a value, ignored\n", argv[i]); break; }
 		const char* v = argv[++i];
@@ -136,6 +138,7 @@ void render_prepare(struct render_data* data, int argc, const char* argv[]) {
 		if (st != LOL_GPU_OK) { fprintf(stderr, "hip_renderer: no usable HIP device %d (status %d)\n", device, st); return; }
 		st = lol_gpu_upload_program(r->gpu, &r->program);
 		if (st != LOL_GPU_OK) { fprintf(stderr, "hip_renderer: %s\n", lol_gpu_error(r->gpu)); return; }
+		if (tile_columns) (void)lol_gpu_set_tile_order(r->gpu, 1);
 	}
 	r->ready = 1;
 }

@@ -91,6 +91,7 @@ struct lol_gpu {
 	std::vector<DivProof> div_verified;  /* per smoothness constant: smin_h_fast proven / proven without v_div_fixup too */
 	unsigned long long* d_bad = nullptr; /* mismatch counter of the verification kernels */
 	int          wave_w = LOL_WAVE_W, wave_h = LOL_WAVE_H, waves_x = LOL_WAVES_X;   /* footprint of the spec kernel */
+	bool         tile_cols = false;      /* tiles handed out column by column (lol_gpu_set_tile_order) */
 	char         err[512] = { 0 };
 	char         kernel_name[64] = "render_interp";
 };
@@ -1425,6 +1426,12 @@ int lol_gpu_cull_bounds_clusters(const lol_program* prog, uint32_t root, float o
 	return n;
 }
 
+int lol_gpu_set_tile_order(lol_gpu* ctx, int columns) {
+	if (!ctx) return LOL_GPU_ERR_ARG;
+	ctx->tile_cols = columns != 0;
+	return LOL_GPU_OK;
+}
+
 int lol_gpu_set_cull(lol_gpu* ctx, int enable) {
 	if (!ctx) return LOL_GPU_ERR_ARG;
 	ctx->want_cull = enable ? 1 : 0;          /* takes effect at the next lol_gpu_upload_program */
@@ -1573,7 +1580,7 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	L.root_material = reinterpret_cast<const uint32_t*>(base + offsetof(lol_program, root_material));
 	L.ambient[0] = P.ambient_color.x; L.ambient[1] = P.ambient_color.y; L.ambient[2] = P.ambient_color.z;
 	L.flags = (ctx->miss_skip ? lol::FLAG_MISS_SKIP : 0u) | (ctx->dark_skip ? lol::FLAG_DARK_SKIP : 0u) |
-	          (ctx->shadow_settle && camera_sane(*cam) ? lol::FLAG_SHADOW_SETTLED : 0u);
+	          (ctx->shadow_settle && camera_sane(*cam) ? lol::FLAG_SHADOW_SETTLED : 0u) | (ctx->tile_cols ? lol::FLAG_TILE_COLS : 0u);
 	L.dst = static_cast<uint32_t*>(dst);
 	L.pitch_px = (uint32_t)(pitch_bytes / 4);
 	L.fmt_shift = ctx->fmt_shift; L.fmt_loss = ctx->fmt_loss; L.fmt_amask = ctx->fmt_amask;
@@ -1586,6 +1593,7 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	const int tile_w = spec ? ctx->wave_w * ctx->waves_x : lol::TILE_W, tile_h = spec ? ctx->wave_h : lol::TILE_H;
 	const int block = tile_w * tile_h;
 	dim3 grid((w + tile_w - 1) / tile_w, (n_rows + tile_h - 1) / tile_h);
+	if (ctx->tile_cols) { const unsigned t = grid.x; grid.x = grid.y; grid.y = t; }      /* (both stay far below the 65535 blocks a grid may have in y) */
 	size_t common = (size_t)(lol::common_lds_dwords(P.n_lights, P.n_materials, P.n_roots) - lol::TILE_W * lol::TILE_H + block) * 4;
 	hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;      /* LOL_GPU_STREAM_DEFAULT == hipStreamLegacy */
 	LOL_HIP(ctx, hipSetDevice(ctx->device));

@@ -66,6 +66,7 @@ constexpr int LIGHT_DWORDS = 9, MATERIAL_DWORDS = 10;
 /* Launch.flags */
 constexpr u32 FLAG_MISS_SKIP = 1u;   /* a wave whose rays all escaped may skip normal + lights (see shade_pixel) */
 constexpr u32 FLAG_DARK_SKIP = 2u;   /* lanes whose diffuse incidence for a light is exactly 0 need no shadow march for it */
+constexpr u32 FLAG_TILE_COLS = 8u;   /* the launch grid is transposed: tiles are handed out column by column (lol_gpu_set_tile_order) */
 constexpr u32 FLAG_SHADOW_SETTLED = 4u;   /* a shadow march ends as soon as its factor can only be 0 (soft_shadow) */
 
 /* = lol_frame_camera */
@@ -810,8 +811,9 @@ __device__ __forceinline__ Pixel shade_pixel(const Launch& L, Sdf& sdf, const u3
 	/* lane → pixel: wave k covers a WAVE_W x WAVE_H patch of the block's tile */
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int tx = wave * WAVE_W + (lane % WAVE_W), ty = lane / WAVE_W;
-	int x = blockIdx.x * TILE_W + tx;
-	int r = blockIdx.y * TILE_H + ty;                     /* local row */
+	const bool cols = (L.flags & FLAG_TILE_COLS) != 0u;
+	int x = (cols ? blockIdx.y : blockIdx.x) * TILE_W + tx;
+	int r = (cols ? blockIdx.x : blockIdx.y) * TILE_H + ty;                     /* local row */
 	/* out-of-frame lanes shade a clamped pixel and skip the store: keeps the wave uniform */
 	x = x < L.w ? x : L.w - 1;
 	r = r < L.n_rows ? r : L.n_rows - 1;
@@ -902,7 +904,9 @@ __device__ __forceinline__ void store_pixel(const Launch& L, const Pixel& P, u32
 	u32* l_tile = lds + L.n_lights * LIGHT_DWORDS + L.n_materials * MATERIAL_DWORDS + L.n_roots;
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int tx = wave * WAVE_W + (lane % WAVE_W), ty = lane / WAVE_W;
-	const int gx = blockIdx.x * TILE_W + tx, gr = blockIdx.y * TILE_H + ty;
+	const bool cols = (L.flags & FLAG_TILE_COLS) != 0u;
+	const int bx = cols ? blockIdx.y : blockIdx.x, by = cols ? blockIdx.x : blockIdx.y;
+	const int gx = bx * TILE_W + tx, gr = by * TILE_H + ty;
 	if (gx < L.w && gr < L.n_rows) {
 		unsigned long long o = (unsigned long long)gr * L.w + gx;
 		if (T.dbg_rgb) { T.dbg_rgb[o * 3 + 0] = P.rgb.x; T.dbg_rgb[o * 3 + 1] = P.rgb.y; T.dbg_rgb[o * 3 + 2] = P.rgb.z; }
@@ -914,7 +918,7 @@ __device__ __forceinline__ void store_pixel(const Launch& L, const Pixel& P, u32
 	l_tile[ty * TILE_W + tx] = px;
 	__syncthreads();
 	const int sx = threadIdx.x % TILE_W, sy = threadIdx.x / TILE_W;
-	const int ox = blockIdx.x * TILE_W + sx, orow = blockIdx.y * TILE_H + sy;
+	const int ox = bx * TILE_W + sx, orow = by * TILE_H + sy;
 	if (ox < L.w && orow < L.n_rows)
 		T.dst[(unsigned long long)orow * T.pitch_px + ox] = l_tile[sy * TILE_W + sx];
 }

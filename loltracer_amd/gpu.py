@@ -153,6 +153,8 @@ def gpu_lib() -> C.CDLL:
         lib.lol_gpu_cull_bounds_clusters.restype = C.c_int
         lib.lol_gpu_set_cull.argtypes = [vp, C.c_int]
         lib.lol_gpu_set_cull.restype = C.c_int
+        lib.lol_gpu_set_tile_order.argtypes = [vp, C.c_int]
+        lib.lol_gpu_set_tile_order.restype = C.c_int
         lib.lol_gpu_device.argtypes = [vp]
         lib.lol_gpu_device.restype = C.c_int
         # several devices (include/lol_gpu.h, "Several devices behind the same boundary")
@@ -209,7 +211,7 @@ EXPORTED_SYMBOLS = [
     "lol_gpu_part_rows", "lol_gpu_render_device", "lol_gpu_render_host", "lol_gpu_sync", "lol_gpu_malloc",
     "lol_gpu_free", "lol_gpu_memcpy_d2h", "lol_gpu_kernel_name", "lol_gpu_set_specialize",
     "lol_gpu_specialize_log", "lol_gpu_compile_offline", "lol_gpu_verify_fast_paths", "lol_gpu_verify_smin_no_fixup", "lol_gpu_set_miss_skip",
-    "lol_gpu_miss_skip_active", "lol_gpu_set_exact_skips", "lol_gpu_powf_batch", "lol_gpu_device", "lol_gpu_sdf_batch", "lol_gpu_set_cull", "lol_gpu_cull_bounds", "lol_gpu_cull_bounds_clusters",
+    "lol_gpu_miss_skip_active", "lol_gpu_set_exact_skips", "lol_gpu_powf_batch", "lol_gpu_device", "lol_gpu_sdf_batch", "lol_gpu_set_cull", "lol_gpu_set_tile_order", "lol_gpu_cull_bounds", "lol_gpu_cull_bounds_clusters",
     "lol_gpu_render_host_begin", "lol_gpu_render_host_end", "lol_gpu_render_host_pending",
     "lol_gpu_multi_create", "lol_gpu_multi_destroy", "lol_gpu_multi_error", "lol_gpu_multi_device_count",
     "lol_gpu_multi_context", "lol_gpu_multi_upload_program", "lol_gpu_choose_band_rows", "lol_gpu_multi_set_band_rows",
@@ -365,6 +367,10 @@ class Renderer:
     def set_cull(self, enable: bool):
         """Exact bounding-sphere culling of top-level objects in the specialised kernel; takes effect at the next prepare()."""
         self._check(self._lib.lol_gpu_set_cull(self._ctx, 1 if enable else 0))
+
+    def set_tile_order(self, columns: bool):
+        """Tiles handed out column by column instead of row by row from the next frame on (same pixels; lol_gpu.h)."""
+        self._check(self._lib.lol_gpu_set_tile_order(self._ctx, 1 if columns else 0))
 
     def set_miss_skip(self, enable: bool):
         self._check(self._lib.lol_gpu_set_miss_skip(self._ctx, 1 if enable else 0))

@@ -48,6 +48,8 @@ def test_default_line_carries_roofline_cpu_baseline_and_both_kernels():
     ks = out["kernels"]
     assert ks["lol_render_spec"]["mpixels_per_s"] > 0 and ks["render_interp"]["mpixels_per_s"] > 0
     assert ks["render_interp"]["frame_equal_to_spec"] is True
+    # the set-up timed both tile orders and says which one the timed frames used
+    assert out["tile_order"] in ("rows", "cols") and set(out["tile_order_trials_ms"]) == {"rows", "cols"}
 
 
 def test_the_real_backends_chatter_stays_off_stdout():

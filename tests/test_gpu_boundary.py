@@ -215,7 +215,7 @@ def read_frames(prefix, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("flags", [[], ["--pipeline"], ["--devices", "0", "--parts-per-device", "3"]])
+@pytest.mark.parametrize("flags", [[], ["--pipeline"], ["--devices", "0", "--parts-per-device", "3"], ["--pipeline", "--tile-columns"]])
 def test_c_host_resizes_between_frames(tmp_path, scenes, flags):
     """main.c:182-187 through render_thread: grow, shrink, grow again on ONE context; every surface the host sees equals
     the oracle's frame of that size (static camera, so the pipelined mode's one-frame lag shows the same picture)."""

@@ -179,6 +179,28 @@ def test_moved_camera(torch_cuda, renderer, scenes):
     check_against_oracle(g, sc, w, h, camera=cam)
 
 
+def test_tile_order_does_not_change_a_bit(torch_cuda, renderer, scenes):
+    """lol_gpu_set_tile_order: tiles handed out column by column (the launch grid transposed) — whole frames whose size is not a
+    multiple of the tile, a pitched destination, and a band partition, all equal to the row-by-row frames and to the oracle."""
+    sc = scenes["scene4"]
+    w, h = 83, 45
+    try:
+        renderer.set_tile_order(False)
+        rows = gpu_render(torch_cuda, renderer, sc, w, h, pitch_px=w + 5)
+        renderer.set_tile_order(True)
+        cols = gpu_render(torch_cuda, renderer, sc, w, h, pitch_px=w + 5)
+        check_against_oracle(cols, sc, w, h)
+        for k in ("xrgb", "rgb", "dist", "id", "steps"):
+            assert np.array_equal(rows[k], cols[k]), k
+        part = gpu.Rows(4, 12, 4)                     # the middle band of three
+        a = gpu_render(torch_cuda, renderer, sc, w, h, rows=part)
+        renderer.set_tile_order(False)
+        b = gpu_render(torch_cuda, renderer, sc, w, h, rows=part)
+        assert np.array_equal(a["xrgb"], b["xrgb"]) and np.array_equal(a["steps"], b["steps"])
+    finally:
+        renderer.set_tile_order(False)
+
+
 def test_camera_beyond_the_sane_range(torch_cuda, renderer, scenes):
     """A camera 10^16 away is not "sane" (lol_gpu.hip, camera_sane): the shadow marches run to the reference's own end and the
     interpreter walks its list WITH v_div_fixup (the proof of the shorter blend factor covers finite operands only)."""
