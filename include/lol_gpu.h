@@ -312,6 +312,7 @@ int  lol_gpu_multi_render_host(lol_gpu_multi* m, const lol_frame_camera* cam, in
                                void* host_pixels, size_t pitch_bytes);
 int  lol_gpu_multi_set_host_via_root(lol_gpu_multi* m, int enable);
 int  lol_gpu_multi_set_pixel_format(lol_gpu_multi* m, const lol_gpu_pixel_format* fmt);
+int  lol_gpu_multi_set_tile_order(lol_gpu_multi* m, int columns);       /* lol_gpu_set_tile_order on every device */
 /* Parts per device (default 1): the frame is cut into n * parts parts, part p belonging to device p % n, each part one
  * launch.  Finer interleaving of the rows, and the way a single-GPU machine exercises the multi-part code paths.
  * n * parts <= 64. */

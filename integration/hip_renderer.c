@@ -17,7 +17,7 @@
  *                   these GPUs, each writing its bands into the surface,
  *                   include/lol_gpu.h lol_gpu_multi_*), --parts-per-device N,
  *                   --root-band-rows N (the first device's smaller share),
- *                   --max-steps N, --tile-columns (one GPU: tiles handed out column by
+ *                   --max-steps N, --tile-columns (tiles handed out column by
  *                   column, lol_gpu_set_tile_order: faster on some scenes, slower on others), and
  *                   --dump-kernel BASE, the counterpart of the JIT renderer's
  *                   -j/--jitdump (tracing_jit_renderer.dasc:424-433): writes the
@@ -131,6 +131,7 @@ void render_prepare(struct render_data* data, int argc, const char* argv[]) {
 			fprintf(stderr, "hip_renderer: --parts-per-device %d refused\n", parts_per_device);
 		if (root_band >= 0 && lol_gpu_multi_set_root_band_rows(r->multi, root_band) != LOL_GPU_OK)
 			fprintf(stderr, "hip_renderer: --root-band-rows %d refused\n", root_band);
+		if (tile_columns) (void)lol_gpu_multi_set_tile_order(r->multi, 1);
 		st = lol_gpu_multi_upload_program(r->multi, &r->program);
 		if (st != LOL_GPU_OK) { fprintf(stderr, "hip_renderer: %s\n", lol_gpu_multi_error(r->multi)); return; }
 	} else {

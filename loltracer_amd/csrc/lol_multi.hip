@@ -471,6 +471,15 @@ int lol_gpu_multi_set_pixel_format(lol_gpu_multi* m, const lol_gpu_pixel_format*
 	return LOL_GPU_OK;
 }
 
+int lol_gpu_multi_set_tile_order(lol_gpu_multi* m, int columns) {
+	if (!m) return LOL_GPU_ERR_ARG;
+	for (int i = 0; i < m->n; i++) {
+		int st = lol_gpu_set_tile_order(m->dev[i].ctx, columns);
+		if (st != LOL_GPU_OK) return mfail(m, st, "lol_gpu_set_tile_order", lol_gpu_error(m->dev[i].ctx));
+	}
+	return LOL_GPU_OK;
+}
+
 /* RCCL on first use: load the library, one communicator per device */
 static int ensure_comms(lol_gpu_multi* m) {
 	if (m->comms_up) return LOL_GPU_OK;

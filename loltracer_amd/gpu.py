@@ -202,6 +202,8 @@ def gpu_lib() -> C.CDLL:
         lib.lol_gpu_multi_set_root_band_rows.restype = C.c_int
         lib.lol_gpu_multi_set_pixel_format.argtypes = [vp, P(PixelFormat)]
         lib.lol_gpu_multi_set_pixel_format.restype = C.c_int
+        lib.lol_gpu_multi_set_tile_order.argtypes = [vp, C.c_int]
+        lib.lol_gpu_multi_set_tile_order.restype = C.c_int
         _lib = lib
     return _lib
 
@@ -221,7 +223,7 @@ EXPORTED_SYMBOLS = [
     "lol_gpu_set_pixel_format",
     "lol_gpu_render_host_pending_size", "lol_gpu_render_host_discard", "lol_gpu_kernel_key", "lol_gpu_roctx_ranges",
     "lol_gpu_assemble_parts_at", "lol_gpu_split_rows", "lol_gpu_multi_set_root_band_rows",
-    "lol_gpu_multi_set_pixel_format",
+    "lol_gpu_multi_set_pixel_format", "lol_gpu_multi_set_tile_order",
 ]
 
 
@@ -442,6 +444,9 @@ class MultiRenderer:
         if isinstance(fmt, str):
             fmt = PIXEL_FORMATS[fmt]
         self._check(self._lib.lol_gpu_multi_set_pixel_format(self._m, C.byref(fmt) if fmt is not None else None))
+
+    def set_tile_order(self, columns: bool):
+        self._check(self._lib.lol_gpu_multi_set_tile_order(self._m, 1 if columns else 0))
 
     def render_into(self, dst_ptr: int, w: int, h: int, max_steps: int = 256, camera: S.Camera | None = None,
                     pitch_bytes: int | None = None, frame_camera: S.FrameCamera | None = None):

@@ -154,6 +154,12 @@ def test_multi_path_on_one_device_equals_the_single_device_frame(scenes):
         m.render_into(got.data_ptr(), w, h)
         m.sync()
         assert torch.equal(got, want), (w, h)
+        m.set_tile_order(True)                        # tiles column by column on every device: the same frame
+        got.zero_()
+        m.render_into(got.data_ptr(), w, h)
+        m.sync()
+        assert torch.equal(got, want), (w, h, "columns")
+        m.set_tile_order(False)
     # two frames in flight (double-buffered parts), different cameras, different destinations
     sc = scenes["scene4"]
     cams = []
