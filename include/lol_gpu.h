@@ -31,6 +31,15 @@
 extern "C" {
 #endif
 
+/*
+ * Version of this binary interface.  It changes whenever an entry point changes its arguments or a structure its layout
+ * (4: lol_program carries pointers + counts instead of fixed-capacity arrays; lol_gpu_render_host_end takes the surface's
+ * size; lol_gpu_rows is {band, cycle, offset}).  A host compiled against another version must not run: hip_renderer.c
+ * and the Python mirror compare lol_gpu_abi_version() of the library they loaded with the macro they were built with.
+ */
+#define LOL_GPU_ABI_VERSION 4
+int lol_gpu_abi_version(void);
+
 typedef struct lol_gpu lol_gpu;      /* one renderer context = one device + one scene */
 
 enum lol_gpu_status {
@@ -112,7 +121,8 @@ int lol_gpu_part_rows(int h, const lol_gpu_rows* rows);
  *   cam       per-frame camera constants (lol_frame_camera_init)
  *   w, h      frame size in pixels; max_steps = MAX_STEPS of the primary march
  *   rows      partition (NULL = whole frame)
- *   dst       DEVICE pointer, XRGB8888 (r<<16|g<<8|b), `pitch_bytes` per local row
+ *   dst       DEVICE pointer to 32-bit pixels in the format of lol_gpu_set_pixel_format (default XRGB8888 =
+ *             r<<16|g<<8|b), `pitch_bytes` per local row
  *   dbg       optional diagnostics (NULL in production)
  *   stream    hipStream_t to launch on, as void*; NULL = the context's own stream (see LOL_GPU_STREAM_DEFAULT)
  */
@@ -162,9 +172,10 @@ int lol_gpu_memcpy_d2h(lol_gpu* ctx, void* host, const void* dev, size_t bytes);
 /* Name of the kernel a launch uses (for matching rocprofv3 kernel-trace rows):
  * "lol_render_spec" (scene-specialised, compiled by hipRTC at upload) or "render_interp". */
 const char* lol_gpu_kernel_name(const lol_gpu* ctx);
-/* Identity of the code that kernel is: 16 hex digits — FNV-1a of the hipRTC code object for "lol_render_spec", of the
- * pipeline source this library was built from for "render_interp".  Profiles record it (profiles/pmc_traffic.json) so
- * that a counter figure is only ever quoted for the code it was measured on. */
+/* Identity of the code that kernel is: 16 hex digits — FNV-1a of the hipRTC code object for "lol_render_spec"; for
+ * "render_interp" of {this library's build id (a digest of its sources and compiler flags), the uploaded macro-op lists,
+ * the square-root variant}: everything that decides which instructions the interpreter executes.  Profiles record it
+ * (profiles/pmc_traffic.json) so that a counter figure is only ever quoted for the code it was measured on. */
 const char* lol_gpu_kernel_key(const lol_gpu* ctx);
 /* Frame ranges pushed to roctx so far by this process (LOL_GPU_ROCTX=1 marks every frame launch for
  * `rocprofv3 --marker-trace`, the counterpart of the reference's -j/--jitdump aid); 0 when not asked for, -1 when asked

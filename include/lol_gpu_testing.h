@@ -1,0 +1,31 @@
+/*
+ * lol_gpu_testing.h — fault injection and geometry switches for the TEST SUITE (tests/test_gpu_boundary.py,
+ * tests/test_multi_device.py).  Not part of the drop-in boundary: a renderer.h host never calls these, and nothing in
+ * the library reads the environment for them (rounds 2-3 used getenv(): an inherited variable could change production
+ * behaviour).  Each switch lives in the context it is set on and dies with it.
+ */
+#ifndef LOL_GPU_TESTING_H
+#define LOL_GPU_TESTING_H
+
+#include "lol_gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* The next `n` lol_gpu_upload_program calls on this context fail at their copy step (as a failed hipMemcpy would), after
+ * every check has passed: exercises the all-or-nothing upload. */
+int lol_gpu_testing_fail_uploads(lol_gpu* ctx, int n);
+
+/* Every `stride`-th PART gets the root's band height (lol_gpu_multi_set_root_band_rows) even on ONE device, so that a
+ * one-GPU box runs bands of unequal height through split, launches, exchange, assembly and host copies.  0 = off. */
+int lol_gpu_multi_testing_root_stride(lol_gpu_multi* m, int stride);
+
+/* lol_gpu_multi_render_host issues every device's copies from that device's own host thread even when there is only one
+ * device (which otherwise copies inline): the code every real multi-GPU host runs, reachable on a one-GPU box. */
+int lol_gpu_multi_testing_force_copier_threads(lol_gpu_multi* m, int enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOL_GPU_TESTING_H */

@@ -82,6 +82,12 @@ void render_prepare(struct render_data* data, int argc, const char* argv[]) {
 	const char* dump = NULL;
 	HOST_PRIVATE(data) = r;
 	if (!r) { fprintf(stderr, "hip_renderer: out of memory\n"); return; }
+	/* a liblol_gpu.so of another interface version would take this file's structures for something else */
+	if (lol_gpu_abi_version() != LOL_GPU_ABI_VERSION) {
+		fprintf(stderr, "hip_renderer: built for lol_gpu ABI %d, the loaded library speaks %d: not rendering\n",
+		        LOL_GPU_ABI_VERSION, lol_gpu_abi_version());
+		return;
+	}
 	r->max_steps = 256;
 	for (int i = 3; i < argc; i++) {
 		const int is_device = !strcmp(argv[i], "--device"), is_devices = !strcmp(argv[i], "--devices");

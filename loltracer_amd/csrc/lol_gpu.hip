@@ -17,6 +17,7 @@
  *    keep the interpreter).
  */
 #include "lol_gpu.h"
+#include "lol_gpu_testing.h"
 #include "lol_kernel.h"
 
 #include <hip/hip_runtime.h>
@@ -41,6 +42,9 @@
 
 /* lol_kernel.h's text, embedded at build time (csrc/Makefile: lol_kernel_src.inc) for hipRTC */
 #include "lol_kernel_src.inc"
+/* LOL_BUILD_ID: a digest of this library's sources and compiler flags (csrc/Makefile: lol_build_id.inc) — the identity
+ * of the ahead-of-time kernels (lol_gpu_kernel_key) */
+#include "lol_build_id.inc"
 
 static_assert(sizeof(lol_light) == lol::LIGHT_DWORDS * 4, "lol_light layout");
 static_assert(sizeof(lol_material) == lol::MATERIAL_DWORDS * 4, "lol_material layout");
@@ -77,6 +81,8 @@ struct lol_gpu {
 	hipFunction_t spec_sdf_fn = nullptr; /* lol_sdf_spec of the same module (lol_gpu_sdf_batch) */
 	std::string  spec_log;
 	std::string  spec_key;               /* FNV-1a of the code object the frames run (lol_gpu_kernel_key) */
+	std::string  interp_key;             /* ... and of {this build, the uploaded macro-op lists} for the interpreter */
+	int          fail_uploads = 0;       /* lol_gpu_testing_fail_uploads: that many uploads still fail at the copy */
 	int          want_fast = 1;          /* allow the proven-exact shortcuts in the specialised kernel */
 	unsigned     want_skips = 7;         /* exact skips allowed when the program qualifies: bit 0 escaped waves, 1 zero incidence, 2 settled shadows */
 	int          want_cull = 1;          /* allow the exact culling of top-level objects (plan_culling) */
@@ -170,8 +176,11 @@ bool dark_skip_ok(const lol_program& P) {
 
 /* Conditions for FLAG_SHADOW_SETTLED (lol_kernel.h, soft_shadow): nothing a shadow march can compute overflows or turns
  * NaN, so that a factor that has reached 0 stays there.  Every number of the scene finite and below 10^15 in magnitude
- * (positions, radii, box sizes, smoothness, light positions): 128 steps of at most the scene's extent keep every
- * coordinate below 10^18 and every squared length below 10^36 < FLT_MAX.  The camera is checked per frame (launch). */
+ * (positions, radii, box sizes, smoothness, light positions).  What bounds the march is its own `t > L` exit, not the
+ * step count: t starts at 0 and stays in [0, L] up to the step that ends the march — a step with s < 0 either ends it
+ * (res = 50 s / t < -1) or has |s| <= t / 50 and leaves t positive — with L = |light - p| and |p| <= |camera| + 100 + one
+ * step of the primary march, all below 10^16; the last step adds one SDF value at such a point.  So every coordinate
+ * stays below 10^17 and every squared length below 10^35 < FLT_MAX.  The camera is checked per frame (launch). */
 bool shadow_settle_ok(const lol_program& P) {
 	auto sane = [](float v) { return v - v == 0.0f && fabsf(v) < 1e15f; };
 	for (uint32_t i = 0; i < P.n_ops; i++) {
@@ -1181,10 +1190,14 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
 		std::vector<const char*> plain;
 		for (size_t i = 0; i < opts.size(); i++) {
 			if (!strcmp(opts[i], "-mllvm") && i + 1 < opts.size() &&
-			    (!strcmp(opts[i + 1], "-amdgpu-sched-strategy=max-ilp") || !strcmp(opts[i + 1], "-enable-post-misched=0"))) { i++; continue; }
+			    (!strcmp(opts[i + 1], "-amdgpu-sched-strategy=max-ilp") || !strcmp(opts[i + 1], "-enable-post-misched=0") ||
+			     !strcmp(opts[i + 1], "-phi-node-folding-threshold=8"))) { i++; continue; }
 			plain.push_back(opts[i]);
 		}
 		if (plain.size() != opts.size()) {
+			/* what comes out now was NOT compiled under the options the key lists: it serves this process (the retry would
+			 * give the same again) but never goes to disk under that key */
+			options_dropped = true;
 			hiprtcDestroyProgram(&prog);
 			prog = nullptr;
 			if (hiprtcCreateProgram(&prog, src.c_str(), "lol_render_spec.hip", 1, hdr_src, hdr_name) != HIPRTC_SUCCESS) {
@@ -1517,8 +1530,9 @@ int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog) {
 		mops.insert(mops.end(), nofix.begin(), nofix.end());
 	}
 	const int next = ctx->cur ^ 1;
-	hipError_t e = getenv("LOL_GPU_TEST_FAIL_UPLOAD") ? hipErrorOutOfMemory      /* fault injection for tests/test_gpu_resize.py */
-	                                                  : hipMemcpy(ctx->d_prog[next], prog, sizeof *prog, hipMemcpyHostToDevice);
+	const bool injected = ctx->fail_uploads > 0;      /* lol_gpu_testing_fail_uploads (tests/test_gpu_boundary.py) */
+	if (injected) ctx->fail_uploads--;
+	hipError_t e = injected ? hipErrorOutOfMemory : hipMemcpy(ctx->d_prog[next], prog, sizeof *prog, hipMemcpyHostToDevice);
 	if (e == hipSuccess && !mops.empty())
 		e = hipMemcpy(ctx->d_mops[next], mops.data(), mops.size() * 4, hipMemcpyHostToDevice);
 	if (e != hipSuccess) return fail(ctx, LOL_GPU_ERR_HIP, "hipMemcpy(program)", e);
@@ -1529,6 +1543,11 @@ int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog) {
 	ctx->n_mops = n_mops;
 	ctx->finite_scene = shadow_settle_ok(*prog);
 	ctx->interp_sqrt_kind = fast.sqrt_kind == 3 ? 3 : 0;
+	{
+		/* what render_interp executes = this build's code (lol_kernel.h AND this file: record layout, flags) + the lists */
+		std::string id = std::string(LOL_BUILD_ID) + "|" + fnv_hex(mops.data(), mops.size() * 4) + "|" + std::to_string(ctx->interp_sqrt_kind);
+		ctx->interp_key = fnv_hex(id.data(), id.size());
+	}
 	resolve_skips(ctx);
 	specialise(ctx);          /* a failed specialisation is not an error: the interpreter renders the new scene */
 	return LOL_GPU_OK;
@@ -1794,9 +1813,16 @@ long lol_gpu_roctx_ranges(void) {
 }
 
 const char* lol_gpu_kernel_key(const lol_gpu* ctx) {
-	static const std::string aot = fnv_hex(LOL_KERNEL_H_TEXT, sizeof LOL_KERNEL_H_TEXT);
 	if (!ctx) return "";
-	return ctx->spec_fn ? ctx->spec_key.c_str() : aot.c_str();
+	return ctx->spec_fn ? ctx->spec_key.c_str() : ctx->interp_key.c_str();
+}
+
+int lol_gpu_abi_version(void) { return LOL_GPU_ABI_VERSION; }
+
+int lol_gpu_testing_fail_uploads(lol_gpu* ctx, int n) {
+	if (!ctx || n < 0) return LOL_GPU_ERR_ARG;
+	ctx->fail_uploads = n;
+	return LOL_GPU_OK;
 }
 
 int lol_gpu_powf_batch(lol_gpu* ctx, const float* x_dev, const float* y_dev, float* out_dev, size_t n, void* stream) {

@@ -31,6 +31,7 @@
  * single-GPU box exercises every multi-part code path — tests/test_multi_device.py.
  */
 #include "lol_gpu.h"
+#include "lol_gpu_testing.h"
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -89,8 +90,10 @@ struct Worker {
 	std::function<hipError_t()> job;
 	bool busy = false, quit = false;
 	hipError_t result = hipSuccess;
-	void start() {
-		if (th.joinable()) return;
+	/* false: the thread could not be started (std::thread throws std::system_error; nothing may cross the C ABI) */
+	bool start() {
+		if (th.joinable()) return true;
+		try {
 		th = std::thread([this] {
 			std::unique_lock<std::mutex> lock(mu);
 			for (;;) {
@@ -106,13 +109,16 @@ struct Worker {
 				cv.notify_all();
 			}
 		});
+		} catch (...) { return false; }
+		return true;
 	}
-	void submit(std::function<hipError_t()> j) {
-		start();
+	bool submit(std::function<hipError_t()> j) {
+		if (!start()) return false;
 		std::lock_guard<std::mutex> lock(mu);
 		job = std::move(j);
 		busy = true;
 		cv.notify_all();
+		return true;
 	}
 	hipError_t wait() {
 		std::unique_lock<std::mutex> lock(mu);
@@ -209,6 +215,8 @@ struct lol_gpu_multi {
 	int       root_band = 0;                           /* band height of the root's parts (0 = like the others) */
 	int       per_dev = 1;                             /* parts per device: part p belongs to device p % n */
 	int       host_via_root = 0;                       /* render_host: assemble on the root first (RCCL) instead of direct copies */
+	int       test_root_stride = 0;                    /* lol_gpu_multi_testing_root_stride */
+	int       test_force_threads = 0;                  /* lol_gpu_multi_testing_force_copier_threads */
 	uint32_t* staging[SLOTS] = { nullptr, nullptr };   /* root: every part of a frame, device by device */
 	size_t    staging_bytes = 0;
 	hipEvent_t done[SLOTS] = { nullptr, nullptr };     /* root: frame of this slot assembled (staging free again) */
@@ -456,6 +464,20 @@ int lol_gpu_multi_set_parts_per_device(lol_gpu_multi* m, int parts) {
 	return LOL_GPU_OK;
 }
 
+int lol_gpu_multi_testing_root_stride(lol_gpu_multi* m, int stride) {
+	if (!m || stride < 0) return LOL_GPU_ERR_ARG;
+	int st = lol_gpu_multi_sync(m);
+	if (st != LOL_GPU_OK) return st;
+	m->test_root_stride = stride;
+	return LOL_GPU_OK;
+}
+
+int lol_gpu_multi_testing_force_copier_threads(lol_gpu_multi* m, int enable) {
+	if (!m) return LOL_GPU_ERR_ARG;
+	m->test_force_threads = enable ? 1 : 0;
+	return LOL_GPU_OK;
+}
+
 int lol_gpu_multi_set_host_via_root(lol_gpu_multi* m, int enable) {
 	if (!m) return LOL_GPU_ERR_ARG;
 	m->host_via_root = enable ? 1 : 0;
@@ -506,12 +528,11 @@ struct Split {
 static int split_frame(lol_gpu_multi* m, int h, Split& S) {
 	S.n_parts = m->n * m->per_dev;
 	const int band = m->band_override > 0 ? m->band_override : lol_gpu_choose_band_rows(h, S.n_parts);
-	/* the root's lighter bands only when there is someone else to take the rest.  (LOL_GPU_MULTI_TEST_ROOT_STRIDE=k, a test
-	 * hook: every k-th PART gets the root's band height even on one device, so that a one-GPU box runs unequal bands
-	 * through this very path — split, launches, exchange, assembly, host copies; tests/test_multi_device.py.) */
+	/* the root's lighter bands only when there is someone else to take the rest.  (lol_gpu_multi_testing_root_stride(m, k),
+	 * a test switch: every k-th PART gets the root's band height even on one device, so that a one-GPU box runs unequal
+	 * bands through this very path — split, launches, exchange, assembly, host copies; tests/test_multi_device.py.) */
 	int root_band = m->n > 1 ? m->root_band : 0, root_stride = m->n;
-	if (const char* e = getenv("LOL_GPU_MULTI_TEST_ROOT_STRIDE"))
-		if (atoi(e) > 1 && m->root_band > 0) { root_band = m->root_band; root_stride = atoi(e); }
+	if (m->test_root_stride > 1 && m->root_band > 0) { root_band = m->root_band; root_stride = m->test_root_stride; }
 	if (lol_gpu_split_rows(S.n_parts, band, root_band, root_stride, S.rows) != LOL_GPU_OK || !table_from_rows(S.tab, S.rows, S.n_parts))
 		return mfail(m, LOL_GPU_ERR_ARG, "bad row partition");
 	uint32_t row = 0;
@@ -673,12 +694,17 @@ int lol_gpu_multi_render_host(lol_gpu_multi* m, const lol_frame_camera* cam, int
 		return e;
 	};
 	hipError_t worst = hipSuccess;
-	if (m->n == 1) {
+	if (m->n == 1 && !m->test_force_threads) {
 		worst = copy_device(0);
 	} else {
-		for (int d = 0; d < m->n; d++) m->dev[d].copier.submit([copy_device, d] { return copy_device(d); });
+		bool started[LOL_GPU_MULTI_MAX_DEVICES] = { false };
 		for (int d = 0; d < m->n; d++) {
-			const hipError_t e = m->dev[d].copier.wait();
+			try { started[d] = m->dev[d].copier.submit([copy_device, d] { return copy_device(d); }); }
+			catch (...) { started[d] = false; }                 /* (std::function may allocate) */
+		}
+		for (int d = 0; d < m->n; d++) {
+			/* a device whose thread could not be started is copied from here, after the others were set going */
+			const hipError_t e = started[d] ? m->dev[d].copier.wait() : copy_device(d);
 			if (e != hipSuccess) worst = e;
 		}
 	}

@@ -16,6 +16,7 @@ import os
 from . import scene as S
 
 LOL_GPU_OK = 0
+LOL_GPU_ABI_VERSION = 4          # include/lol_gpu.h
 _STATUS = {0: "ok", -1: "no HIP device", -2: "HIP runtime error", -3: "bad argument",
            -4: "no scene program uploaded", -5: "unsupported"}
 
@@ -84,6 +85,11 @@ def gpu_lib() -> C.CDLL:
         lib = C.CDLL(path)
         P = C.POINTER
         vp = C.c_void_p
+        lib.lol_gpu_abi_version.argtypes = []
+        lib.lol_gpu_abi_version.restype = C.c_int
+        if lib.lol_gpu_abi_version() != LOL_GPU_ABI_VERSION:
+            raise RuntimeError(f"{path} speaks ABI version {lib.lol_gpu_abi_version()}, this mirror {LOL_GPU_ABI_VERSION}: "
+                               "rebuild (__graft_entry__.build())")
         lib.lol_gpu_device_count.argtypes = []
         lib.lol_gpu_device_count.restype = C.c_int
         lib.lol_gpu_create.argtypes = [C.c_int, P(vp)]
@@ -204,12 +210,22 @@ def gpu_lib() -> C.CDLL:
         lib.lol_gpu_multi_set_pixel_format.restype = C.c_int
         lib.lol_gpu_multi_set_tile_order.argtypes = [vp, C.c_int]
         lib.lol_gpu_multi_set_tile_order.restype = C.c_int
+        # include/lol_gpu_testing.h
+        lib.lol_gpu_testing_fail_uploads.argtypes = [vp, C.c_int]
+        lib.lol_gpu_testing_fail_uploads.restype = C.c_int
+        lib.lol_gpu_multi_testing_root_stride.argtypes = [vp, C.c_int]
+        lib.lol_gpu_multi_testing_root_stride.restype = C.c_int
+        lib.lol_gpu_multi_testing_force_copier_threads.argtypes = [vp, C.c_int]
+        lib.lol_gpu_multi_testing_force_copier_threads.restype = C.c_int
         _lib = lib
     return _lib
 
 
+TESTING_SYMBOLS = ["lol_gpu_testing_fail_uploads", "lol_gpu_multi_testing_root_stride",
+                   "lol_gpu_multi_testing_force_copier_threads"]          # include/lol_gpu_testing.h
+
 EXPORTED_SYMBOLS = [
-    "lol_gpu_device_count", "lol_gpu_create", "lol_gpu_destroy", "lol_gpu_error", "lol_gpu_upload_program",
+    "lol_gpu_abi_version", "lol_gpu_device_count", "lol_gpu_create", "lol_gpu_destroy", "lol_gpu_error", "lol_gpu_upload_program",
     "lol_gpu_part_rows", "lol_gpu_render_device", "lol_gpu_render_host", "lol_gpu_sync", "lol_gpu_malloc",
     "lol_gpu_free", "lol_gpu_memcpy_d2h", "lol_gpu_kernel_name", "lol_gpu_set_specialize",
     "lol_gpu_specialize_log", "lol_gpu_compile_offline", "lol_gpu_verify_fast_paths", "lol_gpu_verify_smin_no_fixup", "lol_gpu_set_miss_skip",
@@ -338,6 +354,10 @@ class Renderer:
     def kernel_key(self) -> str:
         return self._lib.lol_gpu_kernel_key(self._ctx).decode()
 
+    def testing_fail_uploads(self, n: int):
+        """include/lol_gpu_testing.h: the next n uploads fail at their copy step."""
+        self._check(self._lib.lol_gpu_testing_fail_uploads(self._ctx, n))
+
     def sync(self):
         self._check(self._lib.lol_gpu_sync(self._ctx))
 
@@ -435,6 +455,14 @@ class MultiRenderer:
 
     def set_host_via_root(self, enable: bool):
         self._check(self._lib.lol_gpu_multi_set_host_via_root(self._m, 1 if enable else 0))
+
+    def testing_root_stride(self, stride: int):
+        """include/lol_gpu_testing.h: every stride-th part gets the root's band height, even on one device."""
+        self._check(self._lib.lol_gpu_multi_testing_root_stride(self._m, stride))
+
+    def testing_force_copier_threads(self, enable: bool):
+        """include/lol_gpu_testing.h: host-surface copies through the per-device threads even with one device."""
+        self._check(self._lib.lol_gpu_multi_testing_force_copier_threads(self._m, 1 if enable else 0))
 
     def set_root_band_rows(self, rows: int):
         """Band height of the root's parts (0 = like the others): its smaller share of the rows."""

@@ -22,6 +22,27 @@ def test_lol_gpu_exports_every_declared_symbol():
         assert getattr(lib, n) is not None
 
 
+def test_lol_gpu_testing_header_is_exported_too():
+    lib = C.CDLL(os.path.join(S.LIB_DIR, "liblol_gpu.so"))
+    names = declared("lol_gpu_testing.h")
+    assert set(names) == set(gpu.TESTING_SYMBOLS)
+    for n in names:
+        assert getattr(lib, n) is not None
+
+
+def test_abi_version_of_the_library_is_the_headers():
+    text = open(os.path.join(ROOT, "include", "lol_gpu.h")).read()
+    want = int(re.search(r"#define\s+LOL_GPU_ABI_VERSION\s+(\d+)", text).group(1))
+    assert gpu.gpu_lib().lol_gpu_abi_version() == want == gpu.LOL_GPU_ABI_VERSION
+
+
+def test_no_test_switch_is_read_from_the_environment():
+    """Fault injection and test geometry are per-context setters (include/lol_gpu_testing.h), never ambient variables."""
+    for f in ("lol_gpu.hip", "lol_multi.hip"):
+        src = open(os.path.join(ROOT, "loltracer_amd", "csrc", f)).read()
+        assert not re.search(r'getenv\("LOL_GPU[A-Z_]*TEST', src), f
+
+
 def test_lol_scene_exports_every_declared_symbol():
     lib = C.CDLL(os.path.join(S.LIB_DIR, "liblol_scene.so"))
     names = declared("lol_scene.h")

@@ -289,10 +289,9 @@ def test_rejected_upload_leaves_the_previous_scene_rendering(torch_cuda, scenes,
             r._check(r._lib.lol_gpu_upload_program(r._ctx, C.byref(bad)))
         assert np.array_equal(frame(), want_a), breaker
     # 2. a device-side failure in the middle of the upload (injected)
-    monkeypatch.setenv("LOL_GPU_TEST_FAIL_UPLOAD", "1")
+    r.testing_fail_uploads(1)                                      # include/lol_gpu_testing.h
     with pytest.raises(gpu.GpuError):
         r._check(r._lib.lol_gpu_upload_program(r._ctx, C.byref(b.flatten())))
-    monkeypatch.delenv("LOL_GPU_TEST_FAIL_UPLOAD")
     assert np.array_equal(frame(), want_a)
     assert r.kernel_name() == ("lol_render_spec" if specialize else "render_interp")
     # 3. a good upload switches over
@@ -313,8 +312,17 @@ def test_kernel_key_names_the_code(torch_cuda, scenes):
     assert len(k4) == 16 and k4 != k1 and r.kernel_key() == k4
     ri = gpu.Renderer(0, specialize=0)
     ri.prepare(scenes["scene4"])
-    assert len(ri.kernel_key()) == 16 and ri.kernel_key() != k4
-    r.close(); ri.close()
+    i4 = ri.kernel_key()
+    assert len(i4) == 16 and i4 != k4
+    # the interpreter's key names this build AND the uploaded macro-op lists (what render_interp executes depends on both)
+    ri.prepare(scenes["scene"])
+    assert ri.kernel_key() != i4
+    ri.prepare(scenes["scene4"])
+    assert ri.kernel_key() == i4
+    rf = gpu.Renderer(0, specialize=4)                   # interpreter + proven fast paths: other records, other key
+    rf.prepare(scenes["scene4"])
+    assert rf.kernel_name() == "render_interp" and rf.kernel_key() != i4
+    r.close(); ri.close(); rf.close()
 
 
 ROCTX_SCRIPT = r"""

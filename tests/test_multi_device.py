@@ -222,17 +222,17 @@ def test_host_surface_with_several_parts_per_device(scenes, parts, band, w, h, v
 @pytest.mark.gpu
 @pytest.mark.parametrize("w,h,parts,band,root,stride", [(640, 360, 8, 12, 10, 8), (333, 181, 6, 8, 5, 3), (1280, 720, 8, 16, 15, 8)])
 def test_unequal_bands_through_the_multi_device_path(scenes, monkeypatch, w, h, parts, band, root, stride):
-    """The root's lighter bands (lol_gpu_multi_set_root_band_rows) need a second device to mean anything; the test hook
-    LOL_GPU_MULTI_TEST_ROOT_STRIDE gives every stride-th PART of ONE device the root's band height instead, so that bands of
+    """The root's lighter bands (lol_gpu_multi_set_root_band_rows) need a second device to mean anything; the test switch
+    lol_gpu_multi_testing_root_stride gives every stride-th PART of ONE device the root's band height instead, so that bands of
     unequal height go through the real split, the per-part launches, the RCCL exchange, the assembly kernel and the strided
     host copies: device-resident frame and host surface equal the single-launch frame."""
     import torch
-    monkeypatch.setenv("LOL_GPU_MULTI_TEST_ROOT_STRIDE", str(stride))
     single = gpu.Renderer(0)
     single.prepare(scenes["scene4"])
     want = _frame(single, torch, w, h).cpu().numpy().view(np.uint32)
     m = gpu.MultiRenderer([0])
     m.prepare(scenes["scene4"])
+    m.testing_root_stride(stride)
     m.set_parts_per_device(parts)
     m.set_band_rows(band)
     m.set_root_band_rows(root)
@@ -248,6 +248,36 @@ def test_unequal_bands_through_the_multi_device_path(scenes, monkeypatch, w, h, 
         host = np.full((h, pitch // 4), 0xDEADBEEF, dtype=np.uint32)
         m.render_host(host.ctypes.data, w, h, pitch_bytes=pitch)
         assert np.array_equal(host[:, :w], want) and (host[:, w:] == 0xDEADBEEF).all()
+    m.close()
+    single.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("parts,band,w,h", [(1, 0, 640, 360), (3, 4, 333, 181), (8, 12, 1920, 1080)])
+def test_host_copies_issued_by_the_per_device_threads(scenes, parts, band, w, h):
+    """With several devices every device's copies into the host surface are issued by a host thread of its own
+    (lol_multi.hip, Worker: submit / wait / stop, hipSetDevice inside the thread, errors merged); one device copies
+    inline.  lol_gpu_multi_testing_force_copier_threads sends the one device of this box down the threaded path:
+    same frames, repeatedly (the thread is reused), after a resize, and the context shuts its thread down cleanly."""
+    import torch
+    single = gpu.Renderer(0)
+    single.prepare(scenes["scene4"])
+    m = gpu.MultiRenderer([0])
+    m.prepare(scenes["scene4"])
+    m.testing_force_copier_threads(True)
+    m.set_parts_per_device(parts)
+    m.set_band_rows(band)
+    for (fw, fh) in [(w, h), (w // 2 + 1, h // 2 + 3), (w, h)]:
+        want = _frame(single, torch, fw, fh).cpu().numpy().view(np.uint32)
+        pitch = (fw + 3) * 4
+        for _ in range(3):
+            host = np.full((fh, pitch // 4), 0xDEADBEEF, dtype=np.uint32)
+            m.render_host(host.ctypes.data, fw, fh, pitch_bytes=pitch)
+            assert np.array_equal(host[:, :fw], want) and (host[:, fw:] == 0xDEADBEEF).all()
+    m.testing_force_copier_threads(False)                       # and back to the inline copy on the same context
+    host = np.zeros((h, w), dtype=np.uint32)
+    m.render_host(host.ctypes.data, w, h)
+    assert np.array_equal(host, _frame(single, torch, w, h).cpu().numpy().view(np.uint32))
     m.close()
     single.close()
 
