@@ -24,8 +24,16 @@ XRGB8888) rendered from the scene already resident on the device, into a device 
 The JSON line carries `roofline` (HBM-write roofline named by BASELINE.json: 4 B per pixel over the
 render kernel's average launch duration measured with HIP events on the launch stream) and
 `cpu_baseline` (the CPU oracle — a bit-faithful port of naive_renderer.c — on the host cores, on a
-bounded row sample of the same frame).  This path is VALU-bound, not HBM-bound; `valu` gives the
-fraction of the unfused-FP32 issue peak, with flops/pixel counted by the oracle on sample rows.
+bounded row sample of the same frame).  This path is VALU-bound, not HBM-bound; `valu` describes the
+MACHINE: the share of the SIMDs' raw issue rate the kernel reaches (2 cycles per wave64 VALU instruction
+÷ the measured cycles per instruction), VALU instructions per pixel, and the lane efficiency of the wave
+footprint — plus, without a fraction, what the measured rate is worth in the REFERENCE's unfused flops.
+
+N > 1 (either transport): after the timed region the assembled frame is compared with a single-launch
+render of the same frame (`frame_equal_to_single_launch`; LOL_BENCH_CHECK=0 skips it), and one all-gather
+brings every rank's rows, kernel times, wall time per frame and tile order into `per_rank`, so that a poor
+scaling curve can be read from the one run the driver makes.  The orbit compares every rank's first and
+last frame with rank 0's render of the same cameras (`frames_equal_to_rank0_render`).
 """
 from __future__ import annotations
 
@@ -40,6 +48,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# RCCL (and any sharing of device memory between processes) needs dmabuf IPC on this pool: the host driver refuses the legacy
+# mode with `hipIpcGetMemHandle: invalid argument`.  Set HERE, in every process that runs this file — the launcher, and the
+# ranks whoever started them (the driver starts them itself with torch.distributed.run) — before torch is imported, i.e.
+# before the first HIP call.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -47,7 +61,6 @@ import torch.distributed as dist
 from loltracer_amd import gpu, multi, scene as S
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s spec
-VALU_PEAK_TOPS = 78.6           # 157.3 TFLOP/s FMA peak / 2: unfused FP32 ops (no FMA in this path)
 BYTES_PER_PIXEL = 4             # one XRGB8888 store per pixel
 
 WORKLOADS = {
@@ -96,6 +109,129 @@ def pmc_traffic(kernel: str, workload: str, pixels_per_launch: int, kernel_key: 
                       f"{kernel_key}: not quoted (re-run tools/final_profile.sh)")
     return rec["traffic_bytes"], ("profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command on this kernel code, "
                                   "tools/pmc_summary.py; not re-measured in this run)")
+
+
+def pmc_issue(kernel: str, workload: str, pixels_per_launch: int, kernel_key: str):
+    """The issue view of the same committed PMC passes, under the same rule as pmc_traffic (only for the code it was
+    measured on): cycles per wave64 VALU instruction per SIMD, VALU instructions per pixel, transcendental share."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"].get(kernel)
+    except (OSError, ValueError, KeyError):
+        return None
+    if (not rec or rec.get("workload") != workload or rec.get("pixels_per_launch") != pixels_per_launch
+            or rec.get("kernel_key") != kernel_key or "cycles_per_valu_instruction_per_simd" not in rec):
+        return None
+    return {"cycles_per_valu_instruction": rec["cycles_per_valu_instruction_per_simd"],
+            "valu_instructions_per_pixel": rec["valu_instructions_per_pixel"],
+            "transcendental_share_of_valu": rec.get("transcendental_share_of_valu")}
+
+
+def lane_efficiency_model(workload: str):
+    """Lane efficiency of the 16x4 wave footprint on this workload: needed SDF evaluations / evaluations the waves execute
+    (a wave runs the maximum over its 64 lanes), from the oracle's per-pixel step counts (tools/divergence.py; the PMC cannot
+    see it: finished lanes are predicated, not masked).  The newest profiles/r*_divergence.json of this workload."""
+    import glob
+    size = "%dx%d" % (WORKLOADS[workload]["w"], WORKLOADS[workload]["h"])
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_divergence*.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if d.get("scene") == WORKLOADS[workload]["scene"] + ".lol" and d.get("size") == size and "16x4" in d:
+            return {"lane_efficiency": round(d["16x4"]["lane_efficiency"], 4), "march_only": round(d["16x4"]["march_only"], 4),
+                    "shadow_only": round(d["16x4"]["shadow_only"], 4), "source": "profiles/" + os.path.basename(path)}
+    return None
+
+
+def valu_fields(kernel: str, workload: str, px_per_launch: int, kernel_key: str, kernel_mpix: float, ctr, flops_sdf: float) -> dict:
+    """`valu`: the machine first — issue_frac = 2.0 cycles (a SIMD issues one wave64 VALU instruction per 2 cycles at best:
+    32 lanes per cycle) / the cycles per VALU instruction the PMC passes measured on THIS kernel code; VALU instructions
+    per pixel; lane efficiency of the wave footprint — then, without any fraction, what the measured rate is worth in the
+    reference's unfused flops (the kernel skips about a third of that work exactly, so a ratio to a peak would say nothing
+    about the machine)."""
+    out = {"bound": "fp32 VALU issue", "issue_peak_cycles_per_instruction": 2.0}
+    issue = pmc_issue(kernel, workload, px_per_launch, kernel_key)
+    if issue:
+        out.update(issue_frac=round(2.0 / issue["cycles_per_valu_instruction"], 4),
+                   cycles_per_valu_instruction=round(issue["cycles_per_valu_instruction"], 4),
+                   valu_instructions_per_pixel=round(issue["valu_instructions_per_pixel"], 1),
+                   transcendental_share_of_valu=issue["transcendental_share_of_valu"],
+                   issue_source="profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command on this kernel code: "
+                                "SQ_INSTS_VALU over GRBM_GUI_ACTIVE / 8 XCDs / 1024 SIMDs)")
+    else:
+        out.update(issue_frac=None, cycles_per_valu_instruction=None, valu_instructions_per_pixel=None,
+                   issue_source="profiles/pmc_traffic.json holds no PMC passes of this kernel code / workload: not quoted "
+                                "(re-run tools/final_profile.sh)")
+    lane = lane_efficiency_model(workload)
+    out["lane_efficiency"] = lane["lane_efficiency"] if lane else None
+    out["lane_efficiency_detail"] = lane
+    if ctr is not None and ctr.pixels:
+        fpp = (ctr.sdf_evals * flops_sdf + ctr.march_steps * 9 + ctr.shadow_steps * 12) / ctr.pixels
+        out["reference_flops_per_pixel"] = round(fpp, 1)
+        out["reference_sdf_evals_per_pixel"] = round(ctr.sdf_evals / ctr.pixels, 2)
+        out["reference_equivalent_tops"] = round(kernel_mpix * 1e6 * fpp / 1e12, 3)
+        out["reference_equivalent_note"] = ("the oracle's unfused FP32 operations per pixel x the measured Mpixels/s: what a renderer "
+                                            "that did ALL of naive_renderer.c's arithmetic would have to issue at this rate; the kernel "
+                                            "skips part of it exactly (DESIGN.md §3.6-3.7), so this is not a utilisation")
+    return out
+
+
+# ---- N > 1: what every rank did, on rank 0's line -----------------------------------------------------------------
+RANK_STATS = ("rows", "frames", "kernel_ms_avg", "kernel_ms_min", "kernel_ms_max", "wall_ms_per_frame",
+              "host_issue_us_per_frame", "tile_order_cols", "tile_rows_ms", "tile_cols_ms", "tile_deciding")
+
+
+def gather_rank_stats(local: dict, device) -> list:
+    """One all_gather (a float64 tensor of RANK_STATS per rank; gloo on CPU tensors, RCCL on device tensors) after the
+    timed loop: every rank's row in rank order, on every rank."""
+    if dist.is_initialized() and dist.get_backend() == "gloo":
+        device = "cpu"                                # (gloo gathers host tensors; RCCL wants them on the device)
+    mine = torch.tensor([float(local[k]) for k in RANK_STATS], dtype=torch.float64, device=device)
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        rows = [mine]
+    else:
+        rows = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(rows, mine)
+    return [dict(zip(RANK_STATS, (float(v) for v in r.cpu()))) for r in rows]
+
+
+def gather_checksums(mine: list, device) -> list:
+    """every rank's list of 64-bit frame checksums (same length on every rank), in rank order"""
+    if dist.is_initialized() and dist.get_backend() == "gloo":
+        device = "cpu"
+    t = torch.tensor(mine, dtype=torch.int64, device=device)
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [[int(v) for v in t.cpu()]]
+    rows = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(rows, t)
+    return [[int(v) for v in r.cpu()] for r in rows]
+
+
+def frame_checksum(frame) -> int:
+    """position-weighted sum of the pixels modulo 2^64 (two frames that differ in one pixel differ in it)"""
+    v = frame.reshape(-1).to(torch.int64)
+    return int((v * (torch.arange(v.numel(), device=v.device, dtype=torch.int64) % 1000003 + 1)).sum().item())
+
+
+def per_rank_fields(stats: list, ms_per_step: float) -> dict:
+    """The N>1 part of the record from the gathered rows.  exposed_ms_per_frame = a rank's wall time per frame minus its
+    own kernel time per frame: what was NOT hidden under its rendering — for rank 0 the part of gather + assembly that
+    did not overlap the next frame's kernel, for the others the time they waited for the root."""
+    per_rank = []
+    for i, s in enumerate(stats):
+        frames = max(s["frames"], 1.0)
+        per_rank.append({"rank": i, "rows": int(s["rows"]), "frames": int(s["frames"]),
+                         "kernel_ms_avg": round(s["kernel_ms_avg"], 4), "kernel_ms_min": round(s["kernel_ms_min"], 4),
+                         "kernel_ms_max": round(s["kernel_ms_max"], 4), "wall_ms_per_frame": round(s["wall_ms_per_frame"], 4),
+                         "exposed_ms_per_frame": round(s["wall_ms_per_frame"] - s["kernel_ms_avg"], 4),
+                         "host_issue_us_per_frame": round(s["host_issue_us_per_frame"], 1),
+                         "tile_order": "cols" if s["tile_order_cols"] else "rows", "tile_order_deciding": bool(s["tile_deciding"]),
+                         "tile_trial_ms": {"rows": round(s["tile_rows_ms"], 4), "cols": round(s["tile_cols_ms"], 4)}})
+    k = [r["kernel_ms_avg"] for r in per_rank]
+    return {"per_rank": per_rank,
+            "kernel_ms": {"min": min(k), "max": max(k), "rank0": k[0], "slowest_rank": k.index(max(k))},
+            "gather_exposed_ms": per_rank[0]["exposed_ms_per_frame"],
+            "ms_per_step_over_slowest_kernel": round(ms_per_step / max(max(k), 1e-9), 4)}
 
 
 def cpu_baseline(sc: S.Scene, cfg: dict, target_s: float = 15.0, gpu_frame=None):
@@ -301,6 +437,8 @@ def run_cabi(args, record_fd):
 
     per_dev = int(os.environ.get("LOL_BENCH_PARTS_PER_DEVICE", "1"))
     m.set_parts_per_device(per_dev)
+    want_order = os.environ.get("LOL_BENCH_TILE_ORDER", "auto")      # the library's own choice unless pinned (A/B runs)
+    m.set_tile_order(want_order)
     trials = []
     cands = root_share_candidates(n, h)
     best = cands[0]
@@ -313,13 +451,15 @@ def run_cabi(args, record_fd):
         best = min(zip(cands, trials), key=lambda ct: ct[1]["ms_per_frame"])[0]
     if n > 1:
         m.set_band_rows(best[0]); m.set_root_band_rows(best[1])
-    run({"c2": 400, "c3": 100, "c4": 32}[name])
+    run(max({"c2": 400, "c3": 100, "c4": 32}[name], gpu.TILE_TRIAL_FRAMES + 10))
     run(args.warmup)
     t0 = time.perf_counter()
     run(args.steps)
     dt = time.perf_counter() - t0
+    # outside the timed region, by default (LOL_BENCH_CHECK=0 skips it): the frame assembled from every device's bands must
+    # equal ONE launch of the whole frame on device 0
     check = None
-    if os.environ.get("LOL_BENCH_CHECK") == "1":
+    if os.environ.get("LOL_BENCH_CHECK", "1") != "0":
         r1 = gpu.Renderer(0)
         r1.prepare(sc)
         ref = torch.zeros((h, w), dtype=torch.int32, device="cuda:0")
@@ -328,7 +468,7 @@ def run_cabi(args, record_fd):
         check = bool(torch.equal(ref, frames[(args.steps - 1) % 2]))
         print(f"[check] assembled {n}-device frame == single-launch frame: {check}", file=sys.stderr, flush=True)
         r1.close()
-        assert check
+    tiles = [m.tile_order(i) for i in range(n)]
     out = {
         "metric": f"Mpixels/s at {w}x{h}, <={max_steps} march steps; max |pixel delta| vs naive_renderer.c",
         "value": round(args.steps * w * h / dt / 1e6, 2), "unit": "Mpixels/s", "n_gpus": n, "steps": args.steps,
@@ -340,9 +480,14 @@ def run_cabi(args, record_fd):
                    "parts_per_device": per_dev, "band_rows": best[0] if n > 1 else h, "root_band_rows": (best[1] or best[0]) if n > 1 else h,
                    "kernel": m.kernel_name()},
         "root_share_trials": trials or None, "frame_equal_to_single_launch": check,
+        # lol_gpu_set_tile_order(AUTO) decides per device, on that device's own launches
+        "per_device": [{"device": i, "tile_order": t["order"], "tile_order_deciding": t["deciding"], "tile_trial_ms": t["trial_ms"]}
+                       for i, t in enumerate(tiles)],
     }
     os.write(record_fd, (json.dumps(out) + "\n").encode())
     m.close()
+    if check is False:
+        raise SystemExit("bench.py: the assembled frame differs from the single-launch render (record printed above)")
 
 
 def main():
@@ -523,41 +668,23 @@ def main():
     # Set-up, not measurement: keep the device busy for about a quarter of a second so that the clocks have ramped before
     # the W warm-up steps — the timed region of the default run is only ~40 ms, and a cold start moved it by several %.
     # A fixed frame count per workload (every rank issues the same number of gathers), none for the 256-frame orbit.
-    prewarm = 0 if orbit else {"c2": 400, "c3": 100, "c4": 32 * max(world, emulate)}[name]
+    # The order in which a launch hands out its tiles is the LIBRARY's decision (lol_gpu_set_tile_order, AUTO by default: it
+    # times both orders on the first frames of a scene / size / partition with its own events and keeps the faster), so the
+    # rate reported here is the rate a host gets through the boundary with no tuning of its own.  LOL_BENCH_TILE_ORDER =
+    # rows | cols pins it (A/B runs).  The set-up frames below are more than the gpu.TILE_TRIAL_FRAMES the decision takes.
+    want_order = os.environ.get("LOL_BENCH_TILE_ORDER", "auto")
+    if want_order not in ("rows", "cols", "auto"):
+        raise SystemExit(f"LOL_BENCH_TILE_ORDER={want_order}: want rows, cols or auto")
+    r.set_tile_order(want_order)
+    prewarm = {"c2": 400, "c3": 100, "c4": 32 * max(world, emulate), "orbit": gpu.TILE_TRIAL_FRAMES + 10}[name]
+    prewarm = max(prewarm, gpu.TILE_TRIAL_FRAMES + 10)
     for i in range(prewarm):
         step(i, False)
     fence()
-    # Set-up: the order in which a launch hands out its tiles (lol_gpu_set_tile_order).  Same pixels; which order is faster depends
-    # on the scene and the frame, so `auto` measures, like for the split above: rows, columns, rows, columns —
-    # a dozen frames each on warm clocks, the slowest rank's time, the better order if it is better by more than 1 %.
-    order_trials = None
-    want_order = os.environ.get("LOL_BENCH_TILE_ORDER", "auto")
-    if want_order in ("rows", "cols"):
-        r.set_tile_order(want_order == "cols")
-        tile_order = want_order
-    else:
-        best_ms = {"rows": float("inf"), "cols": float("inf")}
-        n_t = 12 if not orbit else min(12, len(cams))
-        for _round in range(2):
-            for o in ("rows", "cols"):
-                r.set_tile_order(o == "cols")
-                for i in range(3):
-                    step(i, False)
-                fence()
-                t0 = time.perf_counter()
-                for i in range(n_t):
-                    step(i, False)
-                fence()
-                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-                if world > 1:
-                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                best_ms[o] = min(best_ms[o], float(t.item()) / n_t * 1e3)
-        tile_order = "cols" if best_ms["cols"] < 0.99 * best_ms["rows"] else "rows"      # (all-reduced: every rank decides alike)
-        r.set_tile_order(tile_order == "cols")
-        order_trials = {k: round(v, 4) for k, v in best_ms.items()}
     for i in range(args.warmup):
         step(i, False)
     fence()
+    tile = r.tile_order()                             # everything issued so far has finished: the trials are in
     host_s = 0.0
     t0 = time.perf_counter()
     for i in range(steps):
@@ -565,23 +692,47 @@ def main():
         step(i, True)
         host_s += time.perf_counter() - th            # host time spent issuing the frame (launches, gather, assembly)
     fence()
-    dt = time.perf_counter() - t0
+    dt_local = dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if force_pipe and world == 1 and rank == 0:
         print("[force-pipe] 1-rank nccl gather path completed", file=sys.stderr, flush=True)
-    if os.environ.get("LOL_BENCH_CHECK") == "1" and pipe is not None and not emulate:
-        # correctness rehearsal: the assembled frame on rank 0 must equal a single-launch render of the frame
+    # ---- everything below is outside the timed region ----
+    # Correctness of what was just timed, by default (LOL_BENCH_CHECK=0 skips it; the driver's plain `bench.py --gpus N` gets it):
+    # partitioned frames: the frame assembled on rank 0 from every rank's bands == ONE launch of the whole frame on rank 0;
+    # the orbit: every rank's first and last frame == rank 0's own render of the same cameras (compared by checksum).
+    check_on = os.environ.get("LOL_BENCH_CHECK", "1") != "0"
+    frame_equal = frames_equal = None
+    if check_on and pipe is not None and not pipe.single and not emulate:
         final = pipe.drain()
         if rank == 0:
             ref = torch.zeros((h, w), dtype=torch.int32, device=dev)
             r.render_into(ref.data_ptr(), w, h, max_steps, stream=stream, frame_camera=cams[0])
             torch.cuda.synchronize()
-            same = bool(torch.equal(final, ref))
-            print(f"[check] assembled {world}-rank frame == single-launch frame: {same}", file=sys.stderr, flush=True)
-            assert same
+            frame_equal = bool(torch.equal(final, ref))
+            print(f"[check] assembled {world}-rank frame == single-launch frame: {frame_equal}", file=sys.stderr, flush=True)
+    if check_on and orbit and world > 1:
+        probe = torch.zeros((h, w), dtype=torch.int32, device=dev)
+        mine = []
+        for k in (0, len(cams) - 1):
+            r.render_into(probe.data_ptr(), w, h, max_steps, stream=stream, frame_camera=cams[k])
+            torch.cuda.synchronize()
+            mine.append(frame_checksum(probe))
+        sums = gather_checksums(mine, dev)
+        if rank == 0:
+            frames_equal, compared = True, 0
+            for rk in range(world):
+                theirs = list(range(rk, cfg["frames"], world))
+                for k, got in zip((theirs[0], theirs[-1]), sums[rk]):
+                    r.render_into(probe.data_ptr(), w, h, max_steps, stream=stream,
+                                  frame_camera=sc.frame_camera(w, h, orbit_camera(k, cfg["frames"])))
+                    torch.cuda.synchronize()
+                    frames_equal = frames_equal and frame_checksum(probe) == got
+                    compared += 1
+            print(f"[check] {compared} orbit frames of {world} ranks == rank 0's render of the same cameras: {frames_equal}",
+                  file=sys.stderr, flush=True)
 
     # the exchange step on its own (outside the timed region): barrier, gather this rank's last part to rank 0,
     # un-interleave there, wait — best of 3.  In the timed loop it overlaps the next frame's kernel.
@@ -599,6 +750,13 @@ def main():
     k_ms = [a.elapsed_time(b) for a, b in kernel_ms]
     k_avg = sum(k_ms) / max(len(k_ms), 1)
     px_per_launch = (P.rank_rows[rank] if P is not None else h) * w      # pixels this rank renders per frame
+    # what every rank did: one all_gather after the timed loop (a rank's wall time is its own, before the max over ranks)
+    rank_stats = gather_rank_stats({
+        "rows": P.rank_rows[rank] if P is not None else h, "frames": steps,
+        "kernel_ms_avg": k_avg, "kernel_ms_min": min(k_ms) if k_ms else 0.0, "kernel_ms_max": max(k_ms) if k_ms else 0.0,
+        "wall_ms_per_frame": dt_local / max(steps, 1) * 1e3, "host_issue_us_per_frame": host_s / max(steps, 1) * 1e6,
+        "tile_order_cols": tile["order"] == "cols", "tile_rows_ms": tile["trial_ms"]["rows"], "tile_cols_ms": tile["trial_ms"]["cols"],
+        "tile_deciding": tile["deciding"]}, dev)
     if orbit:
         total_px = cfg["frames"] * w * h              # all ranks together render each frame once
         steps_reported = cfg["frames"]
@@ -628,8 +786,9 @@ def main():
             "gather_ms": gather_ms,
             "partition": P.describe() if P is not None else None,
             "root_share_trials": trials or None,
-            # lol_gpu_set_tile_order: what the set-up measured (ms per frame, slowest rank, best of two rounds) and took
-            "tile_order": tile_order, "tile_order_trials_ms": order_trials,
+            # lol_gpu_set_tile_order(AUTO): what the LIBRARY measured on its first frames (typical frame of each order) and took
+            "tile_order": tile["order"], "tile_order_mode": tile["mode"], "tile_order_trials_ms": tile["trial_ms"],
+            "tile_order_decided_by": "liblol_gpu (lol_gpu_set_tile_order AUTO)" if tile["mode"] == "auto" else "LOL_BENCH_TILE_ORDER",
             "assembly": None if pipe is None else ("lol_gpu_assemble_parts_at (library kernel, own stream)" if assembler else "torch index_select"),
             "host_issue_us_per_frame": round(host_s / max(steps, 1) * 1e6, 1),
             "prewarm_frames": prewarm,            # untimed set-up frames before the W warm-up steps (clock ramp)
@@ -642,6 +801,12 @@ def main():
                          "bytes_per_pixel": BYTES_PER_PIXEL,
                          "note": "north_star names the HBM-write roofline; the path is FP32-VALU-bound, see `valu`"},
         }
+        if world > 1 or (pipe is not None and not pipe.single):
+            out.update(per_rank_fields(rank_stats, dt / max(steps, 1) * 1e3))
+            if orbit:
+                out["frames_equal_to_rank0_render"] = frames_equal
+            else:
+                out["frame_equal_to_single_launch"] = frame_equal
         if emulate:
             # not a benchmark line: ONE GPU playing rank 0 of an N-rank run.  `ms_per_step` is the root's cadence —
             # its share of the kernels + the gather through RCCL (1 rank: the self-copy) + the whole-frame assembly.
@@ -657,16 +822,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not orbit and local is not None:
             base, ctr = cpu_baseline(sc, cfg, gpu_frame=local.cpu().numpy().view(np.uint32))
             out["cpu_baseline"] = base
-            fpp = (ctr.sdf_evals * flops_per_sdf(r.program) + ctr.march_steps * 9 + ctr.shadow_steps * 12) / ctr.pixels
-            kernel_mpix = px_per_launch / (k_avg * 1e-3) / 1e6
-            tops = kernel_mpix * 1e6 * fpp / 1e12
-            out["valu"] = {"flops_per_pixel": round(fpp, 1), "sdf_evals_per_pixel": round(ctr.sdf_evals / ctr.pixels, 2),
-                           "achieved": round(tops, 3), "peak": VALU_PEAK_TOPS, "unit": "Tops/s (unfused FP32)",
-                           "frac": round(tops / VALU_PEAK_TOPS, 4),
-                           "note": "REFERENCE-counted work: the oracle's unfused flops per pixel x the measured Mpixels/s.  The kernel "
-                                   "skips part of that work exactly (culled objects, dark / escaped lanes, settled shadow marches: "
-                                   "DESIGN.md §3.6-3.7), so this can exceed 1; what it really issues is in profiles/pmc_traffic.json "
-                                   "(VALU instructions per pixel, cycles per VALU instruction)"}
+            out["valu"] = valu_fields(r.kernel_name(), name, px_per_launch, r.kernel_key(), px_per_launch / (k_avg * 1e-3) / 1e6,
+                                      ctr, flops_per_sdf(r.program))
         if world == 1 and local is not None and os.environ.get("LOL_BENCH_HOST_SURFACE", "1") != "0":
             torch.cuda.synchronize()
             hs_cams = [orbit_camera(i, 256) for i in range(0, 256, 16)] if orbit else None
@@ -677,6 +834,8 @@ def main():
     r.close()
     if dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0 and (frame_equal is False or frames_equal is False):
+        raise SystemExit("bench.py: the frames of the partitioned run differ from the single-launch render (record printed above)")
 
 
 if __name__ == "__main__":

@@ -237,12 +237,27 @@ int         lol_gpu_miss_skip_active(const lol_gpu* ctx);
  */
 int         lol_gpu_set_cull(lol_gpu* ctx, int enable);
 /*
- * The order in which a launch hands out its tiles of 16x4 pixels: 0 = row by row (the default), 1 = column by column (the launch
- * grid transposed).  Same pixels either way; which is faster depends on the scene and the frame (scene4 at 4K: columns +2.4 %,
- * scene.lol at 1080p: columns -7 %), so a host that cares times a few frames of each, as bench.py does at set-up.
- * Takes effect at the next frame.  The reference has no counterpart: its thread pool claims pixels one by one (naive_renderer.c:216).
+ * The order in which a launch hands out its tiles of 16x4 pixels: LOL_GPU_TILES_ROWS = row by row, LOL_GPU_TILES_COLS = column
+ * by column (the launch grid transposed).  Same pixels either way; which is faster depends on the scene and the frame (scene4
+ * at 4K: columns +2.4 %, scene.lol at 1080p: columns -7 %), so the default is LOL_GPU_TILES_AUTO: the library
+ * measures.  The first frames of a (scene, frame size, row partition, max_steps) are launched in both orders alternately, each
+ * between two HIP events on its launch stream (LOL_GPU_TILE_TRIALS frames per order after a few untimed ones; nothing ever
+ * waits: finished trials are collected, without blocking, by the frames that follow), and the order whose typical frame
+ * is faster by more than 1 % is kept — rows otherwise — until the scene, the size or the partition changes (a resized window
+ * decides again).  Every trial frame is an ordinary frame.  Takes effect at the next frame.  The reference has no
+ * counterpart: its thread pool claims pixels one by one (naive_renderer.c:216).
  */
-int         lol_gpu_set_tile_order(lol_gpu* ctx, int columns);
+enum { LOL_GPU_TILES_ROWS = 0, LOL_GPU_TILES_COLS = 1, LOL_GPU_TILES_AUTO = 2 };
+#define LOL_GPU_TILE_TRIALS 16
+int         lol_gpu_set_tile_order(lol_gpu* ctx, int order);
+/* What the context is doing about it: mode = what was asked for; order = the order of the next frame outside a trial
+ * (LOL_GPU_TILES_ROWS until AUTO has decided); deciding != 0 while trials are still being launched or collected;
+ * rows_ms / cols_ms = the typical trial frame of each order behind the last decision (0 before one). */
+typedef struct lol_gpu_tile_order_info {
+	int32_t mode, order, deciding, decisions;
+	float   rows_ms, cols_ms;
+} lol_gpu_tile_order_info;
+int         lol_gpu_tile_order(lol_gpu* ctx, lol_gpu_tile_order_info* out);
 /* The bound behind that test for top-level object `root` (0-based, file order); no device needed.  Returns 1 and
  * the bounding sphere (centre, inflated radius R') when the object has one, 0 when it has none (planes, unions
  * with a plane or with smoothness <= 0, non-finite fields) and is therefore never culled. */
@@ -323,7 +338,7 @@ int  lol_gpu_multi_render_host(lol_gpu_multi* m, const lol_frame_camera* cam, in
                                void* host_pixels, size_t pitch_bytes);
 int  lol_gpu_multi_set_host_via_root(lol_gpu_multi* m, int enable);
 int  lol_gpu_multi_set_pixel_format(lol_gpu_multi* m, const lol_gpu_pixel_format* fmt);
-int  lol_gpu_multi_set_tile_order(lol_gpu_multi* m, int columns);       /* lol_gpu_set_tile_order on every device */
+int  lol_gpu_multi_set_tile_order(lol_gpu_multi* m, int order);         /* lol_gpu_set_tile_order on every device (each decides for itself under AUTO) */
 /* Parts per device (default 1): the frame is cut into n * parts parts, part p belonging to device p % n, each part one
  * launch.  Finer interleaving of the rows, and the way a single-GPU machine exercises the multi-part code paths.
  * n * parts <= 64. */

@@ -97,7 +97,21 @@ struct lol_gpu {
 	std::vector<DivProof> div_verified;  /* per smoothness constant: smin_h_fast proven / proven without v_div_fixup too */
 	unsigned long long* d_bad = nullptr; /* mismatch counter of the verification kernels */
 	int          wave_w = LOL_WAVE_W, wave_h = LOL_WAVE_H, waves_x = LOL_WAVES_X;   /* footprint of the spec kernel */
-	bool         tile_cols = false;      /* tiles handed out column by column (lol_gpu_set_tile_order) */
+	/* lol_gpu_set_tile_order.  AUTO: the first frames of a (scene, size, partition) alternate between the two orders, each
+	 * between two events on its launch stream; later frames collect the finished ones without waiting (tile_auto_*) */
+	struct TileAuto {
+		int   mode = LOL_GPU_TILES_AUTO;
+		int   chosen = LOL_GPU_TILES_ROWS;       /* order outside trials */
+		bool  deciding = false;
+		int   key[6] = { 0, 0, 0, 0, 0, 0 };    /* w, h, max_steps, band_rows, cycle_rows, program generation */
+		int   issued = 0, harvested = 0, decisions = 0;
+		static constexpr int SKIP = 6, TOTAL = SKIP + 2 * LOL_GPU_TILE_TRIALS;
+		hipEvent_t ev[2 * TOTAL] = {};          /* start / end of trial frame i at [2i], [2i + 1]; created on first use */
+		bool  have_events = false;
+		float ms[TOTAL] = {};
+		float typical[2] = { 0.f, 0.f };
+	} tiles;
+	int          generation = 0;         /* uploads so far */
 	char         err[512] = { 0 };
 	char         kernel_name[64] = "render_interp";
 };
@@ -1375,6 +1389,7 @@ void lol_gpu_destroy(lol_gpu* ctx) {
 	}
 
 	if (ctx->d_bad) (void)hipFree(ctx->d_bad);
+	if (ctx->tiles.have_events) for (hipEvent_t e : ctx->tiles.ev) (void)hipEventDestroy(e);
 	delete ctx;
 }
 
@@ -1439,9 +1454,76 @@ int lol_gpu_cull_bounds_clusters(const lol_program* prog, uint32_t root, float o
 	return n;
 }
 
-int lol_gpu_set_tile_order(lol_gpu* ctx, int columns) {
-	if (!ctx) return LOL_GPU_ERR_ARG;
-	ctx->tile_cols = columns != 0;
+int lol_gpu_set_tile_order(lol_gpu* ctx, int order) {
+	if (!ctx || order < LOL_GPU_TILES_ROWS || order > LOL_GPU_TILES_AUTO) return LOL_GPU_ERR_ARG;
+	lol_gpu::TileAuto& T = ctx->tiles;
+	T.mode = order;
+	T.deciding = false;                      /* a running series of trials is abandoned (its events are simply reused) */
+	T.key[0] = 0;                            /* ... and AUTO starts afresh at the next frame */
+	T.chosen = order == LOL_GPU_TILES_COLS ? LOL_GPU_TILES_COLS : LOL_GPU_TILES_ROWS;
+	return LOL_GPU_OK;
+}
+
+/* AUTO: collect the trial frames that have finished (never waits) and decide once all of them have */
+static void tile_auto_harvest(lol_gpu* ctx) {
+	lol_gpu::TileAuto& T = ctx->tiles;
+	if (!T.deciding) return;
+	while (T.harvested < T.issued) {
+		const int i = T.harvested;
+		if (hipEventQuery(T.ev[2 * i + 1]) != hipSuccess) { (void)hipGetLastError(); return; }      /* (hipErrorNotReady is not an error) */
+		float ms = 0.f;
+		if (hipEventElapsedTime(&ms, T.ev[2 * i], T.ev[2 * i + 1]) != hipSuccess) { (void)hipGetLastError(); ms = 0.f; }
+		T.ms[i] = ms;
+		T.harvested++;
+	}
+	if (T.harvested < lol_gpu::TileAuto::TOTAL) return;
+	/* the typical frame of each order: the mean of the faster half of its trials (a frame that shared the device with
+	 * something else, or ran before the clocks had settled, does not vote) */
+	for (int o = 0; o < 2; o++) {
+		float v[LOL_GPU_TILE_TRIALS];
+		int n = 0;
+		for (int i = lol_gpu::TileAuto::SKIP + o; i < lol_gpu::TileAuto::TOTAL; i += 2) if (T.ms[i] > 0.f) v[n++] = T.ms[i];
+		std::sort(v, v + n);
+		const int half = n > 1 ? n / 2 : n;
+		float sum = 0.f;
+		for (int i = 0; i < half; i++) sum += v[i];
+		T.typical[o] = half ? sum / (float)half : 0.f;
+	}
+	T.chosen = (T.typical[0] > 0.f && T.typical[1] > 0.f && T.typical[1] < 0.99f * T.typical[0]) ? LOL_GPU_TILES_COLS : LOL_GPU_TILES_ROWS;
+	T.deciding = false;
+	T.decisions++;
+}
+
+/* the order of the frame about to be launched; *trial = the trial slot whose events bracket it, or -1.  Device is current. */
+static int tile_order_for_frame(lol_gpu* ctx, int w, int h, int max_steps, const lol_gpu_rows* R, bool diagnostics, int* trial) {
+	lol_gpu::TileAuto& T = ctx->tiles;
+	*trial = -1;
+	if (T.mode != LOL_GPU_TILES_AUTO) return T.chosen;
+	const int key[6] = { w, h, max_steps, R->band_rows, R->cycle_rows, ctx->generation };
+	if (memcmp(key, T.key, sizeof key) != 0) {          /* another scene, size or partition: measure again */
+		memcpy(T.key, key, sizeof key);
+		if (!T.have_events) {
+			bool ok = true;
+			for (hipEvent_t& e : T.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+			if (!ok) { (void)hipGetLastError(); for (hipEvent_t& e : T.ev) { if (e) (void)hipEventDestroy(e); e = nullptr; } T.mode = LOL_GPU_TILES_ROWS; return T.chosen; }
+			T.have_events = true;
+		}
+		T.deciding = true;
+		T.issued = T.harvested = 0;
+		T.chosen = LOL_GPU_TILES_ROWS;
+	}
+	tile_auto_harvest(ctx);
+	if (!T.deciding || T.issued >= lol_gpu::TileAuto::TOTAL || diagnostics) return T.chosen;
+	*trial = T.issued++;
+	return *trial < lol_gpu::TileAuto::SKIP ? LOL_GPU_TILES_ROWS : ((*trial - lol_gpu::TileAuto::SKIP) & 1);
+}
+
+int lol_gpu_tile_order(lol_gpu* ctx, lol_gpu_tile_order_info* out) {
+	if (!ctx || !out) return LOL_GPU_ERR_ARG;
+	LOL_HIP(ctx, hipSetDevice(ctx->device));
+	tile_auto_harvest(ctx);
+	const lol_gpu::TileAuto& T = ctx->tiles;
+	*out = { T.mode, T.chosen, T.deciding ? 1 : 0, T.decisions, T.typical[0], T.typical[1] };
 	return LOL_GPU_OK;
 }
 
@@ -1537,6 +1619,7 @@ int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog) {
 		e = hipMemcpy(ctx->d_mops[next], mops.data(), mops.size() * 4, hipMemcpyHostToDevice);
 	if (e != hipSuccess) return fail(ctx, LOL_GPU_ERR_HIP, "hipMemcpy(program)", e);
 	/* commit */
+	ctx->generation++;
 	ctx->cur = next;
 	ctx->h_prog = *prog;
 	ctx->have_prog = true;
@@ -1599,7 +1682,7 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	L.root_material = reinterpret_cast<const uint32_t*>(base + offsetof(lol_program, root_material));
 	L.ambient[0] = P.ambient_color.x; L.ambient[1] = P.ambient_color.y; L.ambient[2] = P.ambient_color.z;
 	L.flags = (ctx->miss_skip ? lol::FLAG_MISS_SKIP : 0u) | (ctx->dark_skip ? lol::FLAG_DARK_SKIP : 0u) |
-	          (ctx->shadow_settle && camera_sane(*cam) ? lol::FLAG_SHADOW_SETTLED : 0u) | (ctx->tile_cols ? lol::FLAG_TILE_COLS : 0u);
+	          (ctx->shadow_settle && camera_sane(*cam) ? lol::FLAG_SHADOW_SETTLED : 0u);
 	L.dst = static_cast<uint32_t*>(dst);
 	L.pitch_px = (uint32_t)(pitch_bytes / 4);
 	L.fmt_shift = ctx->fmt_shift; L.fmt_loss = ctx->fmt_loss; L.fmt_amask = ctx->fmt_amask;
@@ -1612,11 +1695,16 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	const int tile_w = spec ? ctx->wave_w * ctx->waves_x : lol::TILE_W, tile_h = spec ? ctx->wave_h : lol::TILE_H;
 	const int block = tile_w * tile_h;
 	dim3 grid((w + tile_w - 1) / tile_w, (n_rows + tile_h - 1) / tile_h);
-	if (ctx->tile_cols) { const unsigned t = grid.x; grid.x = grid.y; grid.y = t; }      /* (both stay far below the 65535 blocks a grid may have in y) */
 	size_t common = (size_t)(lol::common_lds_dwords(P.n_lights, P.n_materials, P.n_roots) - lol::TILE_W * lol::TILE_H + block) * 4;
 	hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;      /* LOL_GPU_STREAM_DEFAULT == hipStreamLegacy */
 	LOL_HIP(ctx, hipSetDevice(ctx->device));
+	int trial = -1;
+	if (tile_order_for_frame(ctx, w, h, max_steps, R, dbg != nullptr, &trial) == LOL_GPU_TILES_COLS) {
+		L.flags |= lol::FLAG_TILE_COLS;
+		const unsigned t = grid.x; grid.x = grid.y; grid.y = t;      /* (both stay far below the 65535 blocks a grid may have in y) */
+	}
 	hipError_t e;
+	if (trial >= 0) LOL_HIP(ctx, hipEventRecord(ctx->tiles.ev[2 * trial], s));
 	g_roctx.init();
 	if (g_roctx.push) {
 		char label[96];
@@ -1637,6 +1725,7 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	}
 	if (g_roctx.pop) g_roctx.pop();
 	if (e != hipSuccess) return fail(ctx, LOL_GPU_ERR_HIP, "kernel launch", e);
+	if (trial >= 0) LOL_HIP(ctx, hipEventRecord(ctx->tiles.ev[2 * trial + 1], s));
 	return LOL_GPU_OK;
 }
 

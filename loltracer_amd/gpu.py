@@ -51,6 +51,23 @@ PIXEL_FORMATS = {
 }
 
 
+class TileOrderInfo(C.Structure):
+    """lol_gpu_tile_order_info: what lol_gpu_set_tile_order(AUTO) measured and took."""
+    _fields_ = [("mode", C.c_int32), ("order", C.c_int32), ("deciding", C.c_int32), ("decisions", C.c_int32),
+                ("rows_ms", C.c_float), ("cols_ms", C.c_float)]
+
+
+TILES_ROWS, TILES_COLS, TILES_AUTO = 0, 1, 2
+TILE_TRIALS = 16                     # LOL_GPU_TILE_TRIALS: trial frames per order (after 6 untimed ones)
+TILE_TRIAL_FRAMES = 6 + 2 * TILE_TRIALS
+
+
+def _tile_order_arg(order) -> int:
+    if isinstance(order, str):
+        return {"rows": TILES_ROWS, "cols": TILES_COLS, "columns": TILES_COLS, "auto": TILES_AUTO}[order]
+    return int(order)                # False / True = rows / columns (the round-3 meaning of the argument), 2 = auto
+
+
 class Debug(C.Structure):
     _fields_ = [("rgb", C.c_void_p), ("hit_dist", C.c_void_p), ("hit_id", C.c_void_p), ("steps", C.c_void_p)]
 
@@ -161,6 +178,8 @@ def gpu_lib() -> C.CDLL:
         lib.lol_gpu_set_cull.restype = C.c_int
         lib.lol_gpu_set_tile_order.argtypes = [vp, C.c_int]
         lib.lol_gpu_set_tile_order.restype = C.c_int
+        lib.lol_gpu_tile_order.argtypes = [vp, P(TileOrderInfo)]
+        lib.lol_gpu_tile_order.restype = C.c_int
         lib.lol_gpu_device.argtypes = [vp]
         lib.lol_gpu_device.restype = C.c_int
         # several devices (include/lol_gpu.h, "Several devices behind the same boundary")
@@ -229,7 +248,7 @@ EXPORTED_SYMBOLS = [
     "lol_gpu_part_rows", "lol_gpu_render_device", "lol_gpu_render_host", "lol_gpu_sync", "lol_gpu_malloc",
     "lol_gpu_free", "lol_gpu_memcpy_d2h", "lol_gpu_kernel_name", "lol_gpu_set_specialize",
     "lol_gpu_specialize_log", "lol_gpu_compile_offline", "lol_gpu_verify_fast_paths", "lol_gpu_verify_smin_no_fixup", "lol_gpu_set_miss_skip",
-    "lol_gpu_miss_skip_active", "lol_gpu_set_exact_skips", "lol_gpu_powf_batch", "lol_gpu_device", "lol_gpu_sdf_batch", "lol_gpu_set_cull", "lol_gpu_set_tile_order", "lol_gpu_cull_bounds", "lol_gpu_cull_bounds_clusters",
+    "lol_gpu_miss_skip_active", "lol_gpu_set_exact_skips", "lol_gpu_powf_batch", "lol_gpu_device", "lol_gpu_sdf_batch", "lol_gpu_set_cull", "lol_gpu_set_tile_order", "lol_gpu_tile_order", "lol_gpu_cull_bounds", "lol_gpu_cull_bounds_clusters",
     "lol_gpu_render_host_begin", "lol_gpu_render_host_end", "lol_gpu_render_host_pending",
     "lol_gpu_multi_create", "lol_gpu_multi_destroy", "lol_gpu_multi_error", "lol_gpu_multi_device_count",
     "lol_gpu_multi_context", "lol_gpu_multi_upload_program", "lol_gpu_choose_band_rows", "lol_gpu_multi_set_band_rows",
@@ -390,9 +409,18 @@ class Renderer:
         """Exact bounding-sphere culling of top-level objects in the specialised kernel; takes effect at the next prepare()."""
         self._check(self._lib.lol_gpu_set_cull(self._ctx, 1 if enable else 0))
 
-    def set_tile_order(self, columns: bool):
-        """Tiles handed out column by column instead of row by row from the next frame on (same pixels; lol_gpu.h)."""
-        self._check(self._lib.lol_gpu_set_tile_order(self._ctx, 1 if columns else 0))
+    def set_tile_order(self, order):
+        """0 / False / "rows", 1 / True / "cols", 2 / "auto" (the default: the library times both on the first frames of a
+        scene and size and keeps the faster) — same pixels either way (lol_gpu.h)."""
+        self._check(self._lib.lol_gpu_set_tile_order(self._ctx, _tile_order_arg(order)))
+
+    def tile_order(self) -> dict:
+        """lol_gpu_tile_order: mode asked for, order in use, whether trials are still running, the two typical trial frames."""
+        info = TileOrderInfo()
+        self._check(self._lib.lol_gpu_tile_order(self._ctx, C.byref(info)))
+        names = {TILES_ROWS: "rows", TILES_COLS: "cols", TILES_AUTO: "auto"}
+        return {"mode": names[info.mode], "order": names[info.order], "deciding": bool(info.deciding), "decisions": info.decisions,
+                "trial_ms": {"rows": round(info.rows_ms, 4), "cols": round(info.cols_ms, 4)}}
 
     def set_miss_skip(self, enable: bool):
         self._check(self._lib.lol_gpu_set_miss_skip(self._ctx, 1 if enable else 0))
@@ -473,8 +501,18 @@ class MultiRenderer:
             fmt = PIXEL_FORMATS[fmt]
         self._check(self._lib.lol_gpu_multi_set_pixel_format(self._m, C.byref(fmt) if fmt is not None else None))
 
-    def set_tile_order(self, columns: bool):
-        self._check(self._lib.lol_gpu_multi_set_tile_order(self._m, 1 if columns else 0))
+    def set_tile_order(self, order):
+        self._check(self._lib.lol_gpu_multi_set_tile_order(self._m, _tile_order_arg(order)))
+
+    def tile_order(self, i: int = 0) -> dict:
+        """lol_gpu_tile_order of device index i's context."""
+        info = TileOrderInfo()
+        st = self._lib.lol_gpu_tile_order(self._lib.lol_gpu_multi_context(self._m, i), C.byref(info))
+        if st != LOL_GPU_OK:
+            raise GpuError(st, "lol_gpu_tile_order")
+        names = {TILES_ROWS: "rows", TILES_COLS: "cols", TILES_AUTO: "auto"}
+        return {"mode": names[info.mode], "order": names[info.order], "deciding": bool(info.deciding), "decisions": info.decisions,
+                "trial_ms": {"rows": round(info.rows_ms, 4), "cols": round(info.cols_ms, 4)}}
 
     def render_into(self, dst_ptr: int, w: int, h: int, max_steps: int = 256, camera: S.Camera | None = None,
                     pitch_bytes: int | None = None, frame_camera: S.FrameCamera | None = None):

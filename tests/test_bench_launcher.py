@@ -91,3 +91,110 @@ def test_root_share_candidates_are_one_launch_splits():
             assert sum(P.rank_rows) == 4320 and P.rank_rows[0] <= min(P.rank_rows[1:])
             assert max(P.rank_rows[1:]) - min(P.rank_rows[1:]) <= band
     assert bench.root_share_candidates(1, 2160) == [(2160, 0)] or bench.root_share_candidates(1, 2160)[0][1] == 0
+
+
+def test_rank_processes_set_the_rccl_ipc_mode_themselves():
+    """RCCL needs dmabuf IPC on this pool (HSA_ENABLE_IPC_MODE_LEGACY=0).  The driver starts the ranks itself with
+    torch.distributed.run, so the launcher's environment is not enough: importing bench.py — what every rank does before
+    its first HIP call — must set it, without overriding a value the caller chose."""
+    code = "import os, sys; sys.path.insert(0, %r); os.environ.pop('HSA_ENABLE_IPC_MODE_LEGACY', None); import bench; print(os.environ['HSA_ENABLE_IPC_MODE_LEGACY'])" % ROOT
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+    assert p.returncode == 0 and p.stdout.strip() == "0", p.stderr[-1500:]
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.index('os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")') < src.index("import torch")
+    code = "import os, sys; sys.path.insert(0, %r); os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '1'; import bench; print(os.environ['HSA_ENABLE_IPC_MODE_LEGACY'])" % ROOT
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+    assert p.stdout.strip() == "1"
+
+
+def test_multi_rank_record_schema():
+    """What an N>1 line must carry so that the one run the driver makes explains itself: every rank's rows, kernel times, wall
+    time, exposed (non-overlapped) time and tile order; min / max / rank-0 kernel time; the root's exposed gather time."""
+    stats = []
+    for rank in range(8):
+        row = dict.fromkeys(bench.RANK_STATS, 0.0)
+        row.update(rows=512 if rank == 0 else 544, frames=20, kernel_ms_avg=0.55 + 0.01 * rank, kernel_ms_min=0.54, kernel_ms_max=0.7,
+                   wall_ms_per_frame=0.68 if rank == 0 else 0.66, host_issue_us_per_frame=85.0, tile_order_cols=rank % 2,
+                   tile_rows_ms=0.6, tile_cols_ms=0.58, tile_deciding=0)
+        stats.append(row)
+    f = bench.per_rank_fields(stats, 0.68)
+    assert set(f) >= {"per_rank", "kernel_ms", "gather_exposed_ms", "ms_per_step_over_slowest_kernel"}
+    assert len(f["per_rank"]) == 8 and [r["rank"] for r in f["per_rank"]] == list(range(8))
+    for r in f["per_rank"]:
+        assert set(r) >= {"rank", "rows", "frames", "kernel_ms_avg", "kernel_ms_min", "kernel_ms_max", "wall_ms_per_frame",
+                          "exposed_ms_per_frame", "host_issue_us_per_frame", "tile_order", "tile_trial_ms"}
+    assert f["per_rank"][0]["rows"] == 512 and f["per_rank"][3]["tile_order"] == "cols"
+    assert f["kernel_ms"] == {"min": 0.55, "max": 0.62, "rank0": 0.55, "slowest_rank": 7}
+    assert abs(f["gather_exposed_ms"] - 0.13) < 1e-9 and abs(f["per_rank"][0]["exposed_ms_per_frame"] - 0.13) < 1e-9
+    # the names the record uses for the checks (bench.py main / run_cabi)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for name in ('"frame_equal_to_single_launch"', '"frames_equal_to_rank0_render"', 'os.environ.get("LOL_BENCH_CHECK", "1") != "0"'):
+        assert name in src
+
+
+def _stats_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mine = dict.fromkeys(bench.RANK_STATS, 0.0)
+        mine.update(rows=100 + rank, frames=5, kernel_ms_avg=1.0 + rank, kernel_ms_min=0.9 + rank, kernel_ms_max=1.2 + rank,
+                    wall_ms_per_frame=1.5 + rank, tile_order_cols=rank == 1)
+        stats = bench.gather_rank_stats(mine, torch.device("cpu"))
+        sums = bench.gather_checksums([rank * 7 + 1, -(2 ** 62) - rank], torch.device("cpu"))
+        q.put((rank, stats, sums))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank_stats_and_checksums_reach_every_rank_over_gloo():
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_stats_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, stats, sums in got:
+        assert [s["rows"] for s in stats] == [100.0, 101.0, 102.0] and [s["kernel_ms_avg"] for s in stats] == [1.0, 2.0, 3.0]
+        assert [bool(s["tile_order_cols"]) for s in stats] == [False, True, False]
+        assert sums == [[1, -(2 ** 62)], [8, -(2 ** 62) - 1], [15, -(2 ** 62) - 2]]
+    fields = bench.per_rank_fields(got[0][1], 3.6)
+    assert fields["kernel_ms"]["slowest_rank"] == 2 and fields["per_rank"][1]["tile_order"] == "cols"
+
+
+def test_frame_checksum_sees_single_pixels_and_their_position():
+    a = torch.zeros((5, 7), dtype=torch.int32)
+    b = a.clone(); b[2, 3] = 1
+    c = a.clone(); c[2, 4] = 1
+    assert len({bench.frame_checksum(a), bench.frame_checksum(b), bench.frame_checksum(c)}) == 3
+    neg = torch.full((3, 3), -1, dtype=torch.int32)              # XRGB with alpha set reads as a negative int32: still well defined
+    assert bench.frame_checksum(neg) == bench.frame_checksum(neg.clone())
+
+
+def test_valu_record_describes_the_machine_and_has_no_fraction_above_one():
+    import json
+    rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]["lol_render_spec"]
+
+    class Ctr:
+        pixels, sdf_evals, march_steps, shadow_steps = 1000, 97000, 21900, 71500
+    v = bench.valu_fields("lol_render_spec", rec["workload"], rec["pixels_per_launch"], rec["kernel_key"], 7800.0, Ctr, 107.0)
+    assert abs(v["issue_frac"] - 2.0 / rec["cycles_per_valu_instruction_per_simd"]) < 1e-3 and 0 < v["issue_frac"] <= 1
+    assert abs(v["valu_instructions_per_pixel"] - rec["valu_instructions_per_pixel"]) < 0.1
+    assert 0 < v["lane_efficiency"] <= 1
+    assert "frac" not in v and v["reference_equivalent_tops"] > 0
+    for k, x in v.items():
+        if k.endswith("frac") and x is not None:
+            assert x <= 1.0
+    # another kernel code: the issue figures are withheld, never quoted stale
+    w = bench.valu_fields("lol_render_spec", rec["workload"], rec["pixels_per_launch"], "0" * 16, 7800.0, Ctr, 107.0)
+    assert w["issue_frac"] is None and w["valu_instructions_per_pixel"] is None and "not quoted" in w["issue_source"]

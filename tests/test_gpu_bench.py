@@ -3,7 +3,8 @@
 `python bench.py --gpus 2` must start two ranks by itself and print ONE JSON line.  A 1-GPU box has one
 device, so the ranks share it and talk gloo (LOL_BENCH_REHEARSE=1) — the partition, the pipelined gather,
 the assembly and the timing protocol are the real ones; only the transport differs from the 8-GPU run.
-LOL_BENCH_CHECK=1 makes rank 0 compare the assembled frame with a single-launch render.
+Rank 0 compares the assembled frame with a single-launch render by default (LOL_BENCH_CHECK=0 skips it) and the record
+carries every rank's rows, kernel times, wall time and tile order.
 """
 import json
 import os
@@ -28,12 +29,27 @@ def _bench(args, **env):
 
 
 def test_gpus_2_self_launches_and_assembles_the_frame():
-    out, err = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1"], LOL_BENCH_REHEARSE="1", LOL_BENCH_CHECK="1")
+    out, err = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1"], LOL_BENCH_REHEARSE="1")       # the check is on by default
     assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["backend"] == "gloo"
     assert out["config"]["width"] == 7680 and out["config"]["height"] == 4320
     assert "[check] assembled 2-rank frame == single-launch frame: True" in err
+    assert out["frame_equal_to_single_launch"] is True
     assert out["gather_ms"] is not None and out["gather_ms"] > 0
     assert out["value"] > 0 and out["scaling"] == "strong"
+    # what every rank did, from the one all_gather after the timed loop
+    pr = out["per_rank"]
+    assert [r["rank"] for r in pr] == [0, 1] and sum(r["rows"] for r in pr) == 4320 and all(r["frames"] == 3 for r in pr)
+    assert all(0 < r["kernel_ms_min"] <= r["kernel_ms_avg"] <= r["kernel_ms_max"] for r in pr)
+    assert all(r["wall_ms_per_frame"] > 0 and r["tile_order"] in ("rows", "cols") and not r["tile_order_deciding"] for r in pr)
+    assert out["kernel_ms"]["rank0"] == pr[0]["kernel_ms_avg"] and out["kernel_ms"]["max"] >= out["kernel_ms"]["min"] > 0
+    assert abs(out["gather_exposed_ms"] - (pr[0]["wall_ms_per_frame"] - pr[0]["kernel_ms_avg"])) < 1e-3
+
+
+def test_orbit_over_two_ranks_checks_frames_against_rank_0():
+    out, err = _bench(["--gpus", "2", "--workload", "orbit", "--warmup", "1"], LOL_BENCH_REHEARSE="1")
+    assert out["scaling"] == "weak" and out["steps"] == 256 and out["n_ranks_seen"] == 2
+    assert out["frames_equal_to_rank0_render"] is True and "[check] 4 orbit frames of 2 ranks" in err
+    assert [r["frames"] for r in out["per_rank"]] == [128, 128] and all(r["rows"] == 2160 for r in out["per_rank"])
 
 
 def test_default_line_carries_roofline_cpu_baseline_and_both_kernels():
@@ -48,8 +64,13 @@ def test_default_line_carries_roofline_cpu_baseline_and_both_kernels():
     ks = out["kernels"]
     assert ks["lol_render_spec"]["mpixels_per_s"] > 0 and ks["render_interp"]["mpixels_per_s"] > 0
     assert ks["render_interp"]["frame_equal_to_spec"] is True
-    # the set-up timed both tile orders and says which one the timed frames used
-    assert out["tile_order"] in ("rows", "cols") and set(out["tile_order_trials_ms"]) == {"rows", "cols"}
+    # the LIBRARY timed both tile orders on its first frames and says which one the timed frames used
+    assert out["tile_order"] in ("rows", "cols") and out["tile_order_mode"] == "auto" and out["tile_order_decided_by"].startswith("liblol_gpu")
+    assert set(out["tile_order_trials_ms"]) == {"rows", "cols"} and all(v > 0 for v in out["tile_order_trials_ms"].values())
+    # `valu` describes the machine; nothing in it called a fraction exceeds 1
+    v = out["valu"]
+    assert "frac" not in v and v["reference_equivalent_tops"] > 0 and 0 < v["lane_efficiency"] <= 1
+    assert v["issue_frac"] is None or 0 < v["issue_frac"] <= 1
 
 
 def test_the_real_backends_chatter_stays_off_stdout():
@@ -63,8 +84,9 @@ def test_in_process_transport_and_root_emulation():
     """--transport cabi: the frame through lol_gpu_multi_* in ONE process (one device here: RCCL self-exchange + assembly) equals
     the single launch; --emulate-root-of 8: one GPU plays rank 0 of an 8-rank run (its band of every cycle, 1-rank RCCL gather,
     whole-frame assembly) and reports the root's cadence."""
-    out, err = _bench(["--transport", "cabi", "--gpus", "1", "--workload", "c4", "--steps", "3", "--warmup", "1"], LOL_BENCH_CHECK="1")
+    out, err = _bench(["--transport", "cabi", "--gpus", "1", "--workload", "c4", "--steps", "3", "--warmup", "1"])
     assert out["config"]["transport"] == "cabi" and out["frame_equal_to_single_launch"] is True and out["value"] > 0
+    assert out["per_device"][0]["tile_order"] in ("rows", "cols") and not out["per_device"][0]["tile_order_deciding"]
     out, err = _bench(["--emulate-root-of", "8", "--steps", "5", "--warmup", "1", "--no-cpu-baseline"], LOL_BENCH_ROOT_SHARE="16,15")
     assert out["metric"].startswith("EMULATION") and out["unit"] == "ms/frame" and out["emulated_world"] == 8
     assert out["partition"]["rows_per_rank"][0] == 512 and out["backend"] == "nccl"

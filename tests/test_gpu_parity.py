@@ -201,6 +201,57 @@ def test_tile_order_does_not_change_a_bit(torch_cuda, renderer, scenes):
         renderer.set_tile_order(False)
 
 
+def test_tile_order_auto_decides_inside_the_library(torch_cuda, scenes):
+    """lol_gpu_set_tile_order(AUTO), the default: the first frames of a (scene, size) alternate between the two orders between
+    the library's own events; once they have all finished one order is kept; a resize or a new scene decides again; a pinned
+    order stops the trials.  Every frame on the way — trial or not — is the same frame."""
+    torch = torch_cuda
+    sc = scenes["scene4"]
+    r = gpu.Renderer(0)
+    r.prepare(sc)
+    info = r.tile_order()
+    assert info["mode"] == "auto" and info["decisions"] == 0 and not info["deciding"]
+    w, h = 320, 180
+    want = None
+    buf = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    for i in range(gpu.TILE_TRIAL_FRAMES + 4):
+        buf.zero_()
+        r.render_into(buf.data_ptr(), w, h)
+        r.sync()
+        got = buf.clone()
+        want = got if want is None else want
+        assert torch.equal(got, want), i                       # rows, columns, rows, columns ...: one frame
+        if i < gpu.TILE_TRIAL_FRAMES - 1:
+            assert r.tile_order()["deciding"]
+    info = r.tile_order()
+    assert not info["deciding"] and info["decisions"] == 1 and info["order"] in ("rows", "cols")
+    assert info["trial_ms"]["rows"] > 0 and info["trial_ms"]["cols"] > 0
+    ox, _, _ = O.render(sc, w, h, threads=4)
+    assert np.array_equal(want.cpu().numpy().view(np.uint32), ox)
+    # the window is resized: another size, another decision
+    w2, h2 = 200, 120
+    buf2 = torch.zeros((h2, w2), dtype=torch.int32, device="cuda")
+    r.render_into(buf2.data_ptr(), w2, h2)
+    assert r.tile_order()["deciding"]
+    for _ in range(gpu.TILE_TRIAL_FRAMES + 2):
+        r.render_into(buf2.data_ptr(), w2, h2)
+    r.sync()
+    assert r.tile_order()["decisions"] == 2 and not r.tile_order()["deciding"]
+    # a new scene: again
+    r.prepare(scenes["scene"])
+    r.render_into(buf2.data_ptr(), w2, h2)
+    assert r.tile_order()["deciding"]
+    # pinned: no trials, whatever was in flight is dropped
+    r.set_tile_order("cols")
+    info = r.tile_order()
+    assert info["mode"] == "cols" and info["order"] == "cols" and not info["deciding"]
+    r.render_into(buf2.data_ptr(), w2, h2)
+    r.sync()
+    ox2, _, _ = O.render(scenes["scene"], w2, h2, threads=4)
+    assert np.array_equal(buf2.cpu().numpy().view(np.uint32), ox2)
+    r.close()
+
+
 def test_camera_beyond_the_sane_range(torch_cuda, renderer, scenes):
     """A camera 10^16 away is not "sane" (lol_gpu.hip, camera_sane): the shadow marches run to the reference's own end and the
     interpreter walks its list WITH v_div_fixup (the proof of the shorter blend factor covers finite operands only)."""
