@@ -317,6 +317,47 @@ def both_kernels(r, sc, spec_frame, w, h, max_steps, fc, stream, spec_ms, px, fr
     return out
 
 
+def startup_times(sc: S.Scene, w: int, h: int, max_steps: int, device: int) -> dict:
+    """Tiered start-up (lol_gpu_upload_program), on contexts of their own BEFORE anything else has compiled
+    this scene in this process: how long render_prepare's part takes with the scene compiler really running (disk cache
+    switched off for it), when the first frame is there (it renders on the interpreter), when the scene's own kernel takes
+    over — and the same for a second context of the same scene (code object in the process's cache)."""
+    buf = torch.zeros((h, w), dtype=torch.int32, device=f"cuda:{device}")
+    torch.cuda.synchronize()
+    out = {}
+    saved = os.environ.get("LOL_GPU_CACHE_DIR")
+    os.environ["LOL_GPU_CACHE_DIR"] = ""
+    try:
+        for tag in ("cold", "cached"):
+            t0 = time.perf_counter()
+            r0 = gpu.Renderer(device)
+            t1 = time.perf_counter()
+            r0.prepare(sc, wait=False)                    # = render_prepare: flatten + upload; returns with the compiler at work
+            t2 = time.perf_counter()
+            r0.render_into(buf.data_ptr(), w, h, max_steps)
+            r0.sync()
+            t3 = time.perf_counter()
+            first_kernel = r0.kernel_name()
+            r0.specialize_wait()
+            t4 = time.perf_counter()
+            out[f"create_ms_{tag}"] = round((t1 - t0) * 1e3, 2)
+            out[f"prepare_ms_{tag}"] = round((t2 - t1) * 1e3, 2)
+            out[f"first_frame_ms_{tag}"] = round((t3 - t1) * 1e3, 2)          # from the start of prepare to the first frame finished
+            out[f"first_frame_kernel_{tag}"] = first_kernel
+            out[f"scene_kernel_ready_ms_{tag}"] = round((t4 - t1) * 1e3, 2)
+            out[f"scene_compiler_ms_{tag}"] = round(r0.specialize_state()[1], 2)
+            r0.close()
+    finally:
+        if saved is None:
+            os.environ.pop("LOL_GPU_CACHE_DIR", None)
+        else:
+            os.environ["LOL_GPU_CACHE_DIR"] = saved
+    out["note"] = ("prepare = lol_scene_flatten + lol_gpu_upload_program (tables, interpreter lists, on-device proofs of the fast paths; "
+                   "hipRTC runs on a host thread); cold = first context of the process, disk cache off; cached = a second context, "
+                   "code object in the process's cache")
+    return out
+
+
 def launcher_command(n: int, argv: list, port: int) -> list:
     """The command `python bench.py --gpus N` runs for N > 1: one rank per GPU under torch.distributed.run
     (the same form the driver uses), rendezvous on 127.0.0.1."""
@@ -551,8 +592,11 @@ def main():
     cfg = WORKLOADS[name]
     w, h, max_steps = cfg["w"], cfg["h"], cfg["max_steps"]
     sc = S.Scene.parse_file(os.path.join(ROOT, "tests", "golden", "scenes", cfg["scene"] + ".lol"))
+    startup = None
+    if world == 1 and not emulate and os.environ.get("LOL_BENCH_STARTUP", "1") != "0":
+        startup = startup_times(sc, w, h, max_steps, local_rank)      # before this process has compiled the scene
     r = gpu.Renderer(local_rank)
-    r.prepare(sc)                                     # render_prepare: flatten + upload once
+    r.prepare(sc)                                     # render_prepare: flatten + upload once; waits for the scene's own kernel
     # A side stream: its handle is non-NULL (NULL means "the context's own stream" in lol_gpu.h), and
     # torch.cuda.Event / the nccl gather below are ordered on whatever stream is current.
     side = torch.cuda.Stream(device=dev)
@@ -824,6 +868,8 @@ def main():
             out["cpu_baseline"] = base
             out["valu"] = valu_fields(r.kernel_name(), name, px_per_launch, r.kernel_key(), px_per_launch / (k_avg * 1e-3) / 1e6,
                                       ctr, flops_per_sdf(r.program))
+        if startup is not None:
+            out["startup"] = startup
         if world == 1 and local is not None and os.environ.get("LOL_BENCH_HOST_SURFACE", "1") != "0":
             torch.cuda.synchronize()
             hs_cams = [orbit_camera(i, 256) for i in range(0, 256, 16)] if orbit else None

@@ -105,8 +105,17 @@ int  lol_gpu_device(const lol_gpu* ctx);          /* the HIP device ordinal of a
 /* Copy the flattened scene (lol_scene_flatten) to the device.  May be called
  * again at any time (it first waits for everything queued on the device);
  * frames issued afterwards use the new program.  All or nothing: when it fails
- * (malformed or oversized program, a failed copy) the context keeps rendering
- * the scene it had. */
+ * (malformed program, a failed allocation or copy) the context keeps rendering
+ * the scene it had.  The program is copied: the caller may free it on return.
+ *
+ * Returns as soon as the scene can be rendered — like the reference's
+ * render_prepare (naive_renderer.c:242-244 does nothing; the JIT's takes
+ * milliseconds, tracing_jit_renderer.dasc:416-434): the tables and the
+ * interpreter's lists are on the device, and the scene's own kernel is being
+ * compiled by hipRTC on a host thread (0.6 s for scene4, half a minute for
+ * 5000 ops).  Frames render on the interpreter kernel meanwhile and switch to
+ * the scene's kernel at the first frame boundary after the compiler is done —
+ * same pixels on both.  lol_gpu_specialize_wait() blocks until then. */
 int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog);
 
 /* Pixel format of every frame launched afterwards (NULL = XRGB8888).  LOL_GPU_ERR_UNSUPPORTED for palettised or
@@ -193,6 +202,13 @@ long lol_gpu_roctx_ranges(void);
  * 3 = specialise without them; 4 = interpreter with them.  Takes effect at the next lol_gpu_upload_program. */
 int         lol_gpu_set_specialize(lol_gpu* ctx, int enable);
 const char* lol_gpu_specialize_log(const lol_gpu* ctx);
+/* Tiered start-up (lol_gpu_upload_program): wait for the scene compiler and switch to its kernel now (returns at once when
+ * nothing is being compiled).  For tests and benchmarks that want to time or inspect one particular kernel. */
+int         lol_gpu_specialize_wait(lol_gpu* ctx);
+/* 0 = no scene kernel (switched off, or the scene is above LOL_GPU_SPEC_MAX_OPS), 1 = being compiled, 3 = compiled, takes over
+ * at the next frame, 2 = in use, -1 = the compiler failed (the interpreter renders; reason in lol_gpu_specialize_log).
+ * *compile_ms (may be NULL) = what the scene compiler's last finished run took. */
+int         lol_gpu_specialize_state(lol_gpu* ctx, double* compile_ms);
 /*
  * The specialised kernel may replace sqrt and the smooth-min division x/k by cheaper sequences
  * (lol_kernel.h "fast exact paths").  Each is used only after the device has run ALL 2^32 float
@@ -313,8 +329,10 @@ const char* lol_gpu_multi_error(const lol_gpu_multi* m);
 int  lol_gpu_multi_device_count(const lol_gpu_multi* m);
 /* the single-device context of device index i (to set its switches before the upload, read its logs) */
 lol_gpu* lol_gpu_multi_context(lol_gpu_multi* m, int i);
-/* render_prepare: the flattened scene goes to every device (14 KB each; the specialised kernel is compiled once) */
+/* render_prepare: the flattened scene goes to every device; the scene's kernel is compiled once, in the background
+ * (lol_gpu_upload_program), and every device switches to it at its own next frame; _specialize_wait waits on all. */
 int  lol_gpu_multi_upload_program(lol_gpu_multi* m, const lol_program* prog);
+int  lol_gpu_multi_specialize_wait(lol_gpu_multi* m);
 /* Band height used for frames of height h over n parts: the largest multiple of the 4-row wave patch <= 16
  * that gives equal parts, else the tallest one that still gives every part at least eight bands, else 4.
  * lol_gpu_multi_set_band_rows(m, b > 0) overrides. */

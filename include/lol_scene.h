@@ -101,7 +101,7 @@ enum lol_status {
 	LOL_ERR_COMPONENT   = 5,   /* "Unknown scene object" for a nested non-object (scene.c:277-279) */
 	LOL_ERR_MATERIAL    = 6,   /* lol_scene_validate_materials failed */
 	LOL_ERR_NOMEM       = 7,
-	LOL_ERR_UNSUPPORTED = 8    /* program too large for the GPU interpreter limits */
+	LOL_ERR_UNSUPPORTED = 8    /* beyond the sanity caps below (LOL_MAX_*), or an unknown node type */
 };
 
 /*
@@ -149,35 +149,42 @@ typedef struct lol_op {
 	uint32_t _pad;   /* keeps the record at 40 B = 10 dwords */
 } lol_op;
 
-/* Capacity of one program.  The reference's scene vectors grow without bound (vector.h:16-66); here a scene
- * beyond these limits is refused loudly by lol_scene_flatten (LOL_ERR_UNSUPPORTED) — nothing is truncated.
- * 1024 ops = e.g. 340 smooth-unioned primitives in one object, or 512 flat objects; a stack of 12 covers any
- * tree of that size (children are emitted deeper-first, so depth d needs 2^(d-1) primitives). */
-#define LOL_MAX_OPS        1024
-#define LOL_MAX_LIGHTS     64
-#define LOL_MAX_MATERIALS  256
-#define LOL_MAX_STACK      12
+/*
+ * A program is as large as its scene: the reference's objects, lights and materials are growable vectors and
+ * get_obj_dist recurses without a limit (vector.h:16-66, scene.c:18-29,240-259, naive_renderer.c:11-28), so the four
+ * tables are a pointer + a count each (rounds 1-3 had fixed arrays of 1024 ops / 64 lights / 256 materials and refused
+ * anything larger).  The LOL_MAX_* below are SANITY caps — a count beyond them is taken for corruption, not for a scene
+ * (2^20 ops = half a million primitives) — and are checked wherever a program crosses the C ABI.  The operand stack:
+ * children are emitted deeper-first, so a stack of d needs 2^(d-1) primitives; 64 covers anything memory can hold.
+ */
+#define LOL_MAX_OPS        (1u << 20)
+#define LOL_MAX_LIGHTS     (1u << 16)
+#define LOL_MAX_MATERIALS  (1u << 20)
+#define LOL_MAX_STACK      64
 
 typedef struct lol_program {
-	uint32_t     n_ops;
-	uint32_t     n_lights;
-	uint32_t     n_materials;
-	uint32_t     n_roots;
-	uint32_t     max_stack;                      /* peak operand-stack depth of `ops` */
-	lol_v3       ambient_color;
-	lol_op       ops[LOL_MAX_OPS];
-	lol_light    lights[LOL_MAX_LIGHTS];
-	lol_material materials[LOL_MAX_MATERIALS];
-	uint32_t     root_material[LOL_MAX_OPS];     /* material index of object id i+1 */
+	uint32_t      n_ops;
+	uint32_t      n_lights;
+	uint32_t      n_materials;
+	uint32_t      n_roots;
+	uint32_t      max_stack;                     /* peak operand-stack depth of `ops` */
+	lol_v3        ambient_color;
+	lol_op*       ops;                           /* n_ops */
+	lol_light*    lights;                        /* n_lights */
+	lol_material* materials;                     /* n_materials (>= 1: material #0 shades escaped rays) */
+	uint32_t*     root_material;                 /* n_roots: material index of object id i+1 */
 } lol_program;
 
 /*
  * Lower the scene graph to a program.  Children of a smooth_union are emitted
  * deeper-subtree-first (Sethi–Ullman order) so chains need a 2-entry stack.
- * Returns LOL_ERR_UNSUPPORTED when a limit above is exceeded and
- * LOL_ERR_MATERIAL when a top-level material index is out of range.
+ * The four tables are allocated here (release them with lol_program_free; `out` itself is the caller's).
+ * Returns LOL_ERR_UNSUPPORTED when a sanity cap above is exceeded, LOL_ERR_MATERIAL when a top-level material
+ * index is out of range, LOL_ERR_NOMEM when memory runs out; *out is then empty (all counts 0, all pointers NULL).
  */
-int lol_scene_flatten(const lol_scene* scene, lol_program* out);
+int  lol_scene_flatten(const lol_scene* scene, lol_program* out);
+/* Frees the tables of a program filled by lol_scene_flatten and empties it (safe on an empty / zeroed one). */
+void lol_program_free(lol_program* prog);
 
 /* --------------------------------------------------------------- camera */
 

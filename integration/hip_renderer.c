@@ -210,6 +210,7 @@ void render_destroy(struct render_data* data) {
 	if (!r) return;
 	lol_gpu_multi_destroy(r->multi);
 	lol_gpu_destroy(r->gpu);
+	lol_program_free(&r->program);
 	free(r);
 	HOST_PRIVATE(data) = NULL;
 }

@@ -23,11 +23,16 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 #include <dlfcn.h>
+#include <pthread.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <memory>
+#include <thread>
 #include <functional>
 #include <cstddef>
 #include <cstdio>
@@ -51,16 +56,78 @@ static_assert(sizeof(lol_material) == lol::MATERIAL_DWORDS * 4, "lol_material la
 static_assert(sizeof(lol_frame_camera) == sizeof(lol::Cam), "lol_frame_camera layout");
 
 
+/* The scene compiler runs on a thread of its own with a LARGE stack: the compiler inside hipRTC recurses over the long
+ * dependent chains of a big scene's straight-line SDF — a field of 3000 objects overflowed the usual 8 MB in the hipRTC
+ * that PyTorch bundles (ROCm 7.0's; the system's 7.2 survived) and took the process down.  1 GB of address space; only
+ * the pages really used are ever committed. */
+struct BigStackThread {
+	pthread_t t{};
+	bool started = false;
+	std::function<void()> fn;
+	static void* entry(void* self) { static_cast<BigStackThread*>(self)->fn(); return nullptr; }
+	bool start(std::function<void()> f) {
+		fn = std::move(f);
+		pthread_attr_t attr;
+		if (pthread_attr_init(&attr) != 0) return false;
+		(void)pthread_attr_setstacksize(&attr, (size_t)1 << 30);
+		started = pthread_create(&t, &attr, entry, this) == 0;
+		if (!started) {                                 /* (no gigabyte of address space to be had: the default stack) */
+			pthread_attr_t plain;
+			if (pthread_attr_init(&plain) == 0) { started = pthread_create(&t, &plain, entry, this) == 0; pthread_attr_destroy(&plain); }
+		}
+		pthread_attr_destroy(&attr);
+		return started;
+	}
+	bool joinable() const { return started; }
+	void join() { if (started) { pthread_join(t, nullptr); started = false; } }
+};
+
+/* One run of the scene compiler on a host thread (tiered start-up: start_specialise / finish_specialise below). */
+struct SpecJob {
+	std::mutex mu;
+	std::condition_variable cv;
+	bool done = false, ok = false;
+	std::vector<char> code;
+	std::string log, note;
+	int shape[3] = { LOL_WAVE_W, LOL_WAVE_H, LOL_WAVES_X };
+	std::chrono::steady_clock::time_point started;
+	double compile_ms = 0;
+	BigStackThread th;
+};
+
+/* A program and the memory behind its four tables (lol_program itself only points: include/lol_scene.h). */
+struct OwnedProgram {
+	lol_program p{};
+	std::vector<lol_op> ops;
+	std::vector<lol_light> lights;
+	std::vector<lol_material> materials;
+	std::vector<uint32_t> root_material;
+	void assign(const lol_program& src) {
+		ops.assign(src.ops, src.ops + src.n_ops);
+		lights.assign(src.lights, src.lights + src.n_lights);
+		materials.assign(src.materials, src.materials + src.n_materials);
+		root_material.assign(src.root_material, src.root_material + src.n_roots);
+		p = src;
+		p.ops = ops.data(); p.lights = lights.data(); p.materials = materials.data(); p.root_material = root_material.data();
+	}
+	OwnedProgram() = default;
+	OwnedProgram(const OwnedProgram&) = delete;
+	OwnedProgram& operator=(const OwnedProgram&) = delete;
+};
+
 struct lol_gpu {
 	int          device = -1;
 	hipStream_t  stream = nullptr;
 	/* device tables, two sets: an upload fills the set no frame reads and flips `cur` only when every fallible step
-	 * has succeeded (lol_gpu_upload_program is all-or-nothing) */
-	lol_program* d_prog[2] = { nullptr, nullptr };   /* lights, materials, root_material tables */
-	uint32_t*    d_mops[2] = { nullptr, nullptr };   /* the interpreter's macro-op list (lol_kernel.h, Interp) */
+	 * has succeeded (lol_gpu_upload_program is all-or-nothing).  Sized by the program (grown when an upload needs more). */
+	uint32_t*    d_tables[2] = { nullptr, nullptr };   /* lights | materials | root_material, as dwords */
+	size_t       tables_cap[2] = { 0, 0 };             /* ... dwords allocated */
+	uint32_t*    d_mops[2] = { nullptr, nullptr };     /* the interpreter's two macro-op lists (lol_kernel.h, Interp) */
+	size_t       mops_cap[2] = { 0, 0 };               /* ... dwords allocated */
 	int          cur = 0;
 	uint32_t     n_mops = 0;
-	lol_program  h_prog;                 /* host mirror (counts, max_stack) */
+	OwnedProgram h_own;                  /* host copy of the uploaded program ... */
+	lol_program& h_prog = h_own.p;       /* ... and its lol_program view (counts, tables, max_stack) */
 	bool         have_prog = false;
 	/* the surface's pixel format (lol_gpu_set_pixel_format), packed as lol::Launch wants it; default XRGB8888 */
 	uint32_t     fmt_shift = 16u | 8u << 8 | 0u << 16, fmt_loss = 0, fmt_amask = 0;
@@ -80,6 +147,10 @@ struct lol_gpu {
 	hipFunction_t spec_fn = nullptr;
 	hipFunction_t spec_sdf_fn = nullptr; /* lol_sdf_spec of the same module (lol_gpu_sdf_batch) */
 	std::string  spec_log;
+	SpecJob*     job = nullptr;       /* the scene compiler's run for the CURRENT program, until its module is swapped in */
+	std::vector<SpecJob*> old_jobs;   /* runs for programs since replaced: joined when they have finished */
+	int          spec_state = 0;         /* 0 no specialised kernel wanted / possible, 1 compiling, 2 in use, -1 failed */
+	double       spec_compile_ms = 0;    /* how long the last finished run took (wall clock of its thread) */
 	std::string  spec_key;               /* FNV-1a of the code object the frames run (lol_gpu_kernel_key) */
 	std::string  interp_key;             /* ... and of {this build, the uploaded macro-op lists} for the interpreter */
 	int          fail_uploads = 0;       /* lol_gpu_testing_fail_uploads: that many uploads still fail at the copy */
@@ -141,11 +212,17 @@ hipError_t launch_sdf_interp(const uint32_t* mops, uint32_t n_mops, const float*
 	return hipGetLastError();
 }
 
-template <int SSIZE>
+template <int SSIZE, bool TABLES_GLOBAL = false>
 hipError_t launch_interp(const lol::Launch& L, dim3 grid, size_t lds, hipStream_t s, int sqrt_kind) {
-	if (sqrt_kind == 3) hipLaunchKernelGGL((lol::render_interp<SSIZE, 3>), grid, dim3(lol::BLOCK), lds, s, L);
-	else                hipLaunchKernelGGL((lol::render_interp<SSIZE, 0>), grid, dim3(lol::BLOCK), lds, s, L);
+	if (sqrt_kind == 3) hipLaunchKernelGGL((lol::render_interp<SSIZE, 3, TABLES_GLOBAL>), grid, dim3(lol::BLOCK), lds, s, L);
+	else                hipLaunchKernelGGL((lol::render_interp<SSIZE, 0, TABLES_GLOBAL>), grid, dim3(lol::BLOCK), lds, s, L);
 	return hipGetLastError();
+}
+
+/* operand-stack entries under the accumulator a program needs → the instantiation that has them */
+constexpr int interp_stack_class(uint32_t max_stack) {
+	const uint32_t need = max_stack > 1 ? max_stack - 1 : 1;      /* the accumulator holds the top entry */
+	return need <= 1 ? 1 : need <= 3 ? 3 : need <= 7 ? 7 : need < (uint32_t)lol::MOP_DEEP_FROM ? lol::MOP_DEEP_FROM - 1 : lol::MOP_DEEP_SLOTS;
 }
 
 
@@ -449,7 +526,7 @@ void cluster_bounds(const lol_program& P, RootBound& R) {
 			for (Sphere& l : a) l.r += 0.25 * (double)o.f[0];          /* the slack of this union, for every leaf under it */
 		} else return;                                                   /* (a plane: the object has no bound at all) */
 	}
-	if (st.size() != 1 || st[0].size() < 3) return;
+	if (st.size() != 1 || st[0].size() < 3 || st[0].size() > 4096) return;      /* (the cut search below is quadratic in the leaves) */
 	std::vector<Sphere>& leaves = st[0];
 	double mn[3] = { 1e300, 1e300, 1e300 }, mx[3] = { -1e300, -1e300, -1e300 };
 	for (const Sphere& l : leaves) for (int a = 0; a < 3; a++) { mn[a] = fmin(mn[a], l.c[a]); mx[a] = fmax(mx[a], l.c[a]); }
@@ -625,7 +702,9 @@ std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast, co
 	};
 	/* LOL_GPU_INTERP_CULL_MIN_PRIMS: leave out the tests of runs with fewer primitives (measured: 1, i.e. keeping
 	 * every test, is fastest here too — a test is one turn of a scalar loop inside the rare TAIL branch). */
-	const bool fuse_pops = !(getenv("LOL_GPU_INTERP_FUSE_POPS") && getenv("LOL_GPU_INTERP_FUSE_POPS")[0] == '0');     /* A/B switch */
+	/* deep: operand stacks beyond the 4-bit slot fields — slots travel in words of their own and pops are not fused (lol_kernel.h, MOP_DEEP_FROM) */
+	const bool deep = interp_stack_class(P.max_stack) == lol::MOP_DEEP_SLOTS;
+	const bool fuse_pops = !deep && !(getenv("LOL_GPU_INTERP_FUSE_POPS") && getenv("LOL_GPU_INTERP_FUSE_POPS")[0] == '0');     /* A/B switch */
 	uint32_t min_prims = 1;
 	if (const char* e = getenv("LOL_GPU_INTERP_CULL_MIN_PRIMS")) min_prims = (uint32_t)std::max(1, atoi(e));
 	std::vector<CullInterval> ivs;
@@ -638,6 +717,8 @@ std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast, co
 	std::vector<size_t> at(ivs.size());              /* where each test's constants record went */
 	std::vector<uint32_t> begins(plan.order.size() + 1, 0);
 	for (const CullInterval& iv : ivs) begins[iv.begin]++;
+	std::vector<std::vector<size_t>> ends_at(plan.order.size() + 1);      /* the runs that end after object oi - 1 (linear, not a scan per object) */
+	for (size_t k = 0; k < ivs.size(); k++) ends_at[ivs[k].end].push_back(k);
 	uint32_t max_id_seen = 0;
 	size_t next_iv = 0;
 	for (size_t oi = 0; oi < plan.order.size(); oi++) {
@@ -668,7 +749,10 @@ std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast, co
 					i++;                                /* the smooth min is part of this macro-op; depth unchanged */
 				} else {
 					m[0] = lol::mop_header(kind, depth == 0 ? lol::MOP_SET : lol::MOP_PUSH);
-					if (depth > 0) m[0] |= (uint32_t)(depth - 1) << lol::MOP_SLOT_SHIFT;      /* the accumulator goes to this slot */
+					if (depth > 0) {                                                       /* the accumulator goes to this slot */
+						if (deep) m[9] = (uint32_t)(depth - 1);
+						else m[0] |= (uint32_t)(depth - 1) << lol::MOP_SLOT_SHIFT;
+					}
 					depth++;
 				}
 			} else {                                     /* SMIN / SMIN_R on two computed operands */
@@ -682,7 +766,8 @@ std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast, co
 					continue;
 				}
 				m[0] = lol::mop_header(lol::MOP_POP, o.op == LOL_OP_SMIN ? lol::MOP_SMIN_X : lol::MOP_SMIN);
-				m[0] |= (uint32_t)(depth - 2) << lol::MOP_SLOT_SHIFT;                           /* the operand under the accumulator */
+				if (deep) m[2] = (uint32_t)(depth - 2);                                         /* the operand under the accumulator */
+				else m[0] |= (uint32_t)(depth - 2) << lol::MOP_SLOT_SHIFT;
 				smin_fields(m, o);
 				depth--;
 			}
@@ -698,8 +783,8 @@ std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast, co
 			if (group_here) out[last] |= lol::MOPB_CULL_NEXT;
 			if (begins[oi + 1] > (group_here ? 1u : 0u)) out[last] |= lol::MOPB_CULL_CHAIN;
 		}
-		for (size_t k = 0; k < ivs.size(); k++)                            /* every run that ends here: how far its test jumps */
-			if (ivs[k].end == oi + 1) out[at[k] + 1] = (uint32_t)((out.size() - at[k]) / lol::MOP_DWORDS - 1);
+		for (size_t k : ends_at[oi + 1])                                   /* every run that ends here: how far its test jumps */
+			out[at[k] + 1] = (uint32_t)((out.size() - at[k]) / lol::MOP_DWORDS - 1);
 	}
 	return out;
 }
@@ -788,6 +873,8 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 	};
 	uint32_t max_id_seen = 0;
 	size_t next_iv = 0;
+	std::vector<uint32_t> runs_ending(plan.order.size() + 1, 0);          /* how many runs end after object oi - 1 */
+	for (const CullInterval& iv : plan.intervals) runs_ending[iv.end]++;
 	for (size_t oi = 0; oi < plan.order.size(); oi++) {
 		const RootBound& R = roots[plan.order[oi]];
 		while (next_iv < plan.intervals.size() && plan.intervals[next_iv].begin == oi) {      /* outer runs first */
@@ -922,8 +1009,7 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 			snprintf(line, sizeof line, "\t\tif (t%d < best) { best = t%d; best_id = %uu; }\n", d, d, R.id);
 		s += line;
 		if (R.id > max_id_seen) max_id_seen = R.id;
-		for (const CullInterval& iv : plan.intervals)                                        /* every run that ends here */
-			if (iv.end == oi + 1) s += "\t\t} }\n";
+		for (uint32_t k = 0; k < runs_ending[oi + 1]; k++) s += "\t\t} }\n";               /* every run that ends here */
 	}
 	if (out_of_line) {
 		s += "\t\treturn { best, best_id, rg.lo, rg.hi, nan };\n}\n";
@@ -946,6 +1032,7 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
  * that compile time and code size (six copies of the SDF) grow linearly while the call overhead stays fixed.
  * LOL_GPU_SPEC_INLINE_MAX overrides. */
 constexpr uint32_t LOL_SPEC_INLINE_MAX_OPS = 256;
+constexpr uint32_t LOL_SPEC_MAX_OPS = 16384;           /* specialise(): larger scenes stay on the interpreter */
 
 bool spec_out_of_line(const lol_program& P) {
 	uint32_t limit = LOL_SPEC_INLINE_MAX_OPS;
@@ -977,22 +1064,27 @@ std::string generate_source(const lol_program& P, const FastPaths* fast, bool cu
 	const bool any_fast = fast && (fast->sqrt_kind || !fast->div_ok.empty());
 	if (any_fast) emit_sdf(s, P, "SpecSdfFast", fast, ool, roots, plan, occupancy);
 	s += "}  // namespace lol\n";
+	/* where lights / materials are read from is a property of the scene too (lol_kernel.h, TABLES_LDS_MAX_DWORDS) */
+	const bool tables_global = !lol::tables_in_lds(P.n_lights, P.n_materials, P.n_roots);
+	const std::string tg = tables_global ? "true" : "false";
 	s += "extern \"C\" __global__ __launch_bounds__(lol::BLOCK)" + occupancy + " void lol_render_spec(const lol::Launch L) {\n";
 	s += "\textern __shared__ lol::u32 lds[];\n";
-	s += "\tlol::stage_common(L, lds);\n";
-	s += "\t__syncthreads();\n";
+	if (!tables_global) {
+		s += "\tlol::stage_common(L, lds);\n";
+		s += "\t__syncthreads();\n";
+	}
 	if (any_fast) {
 		s += "\tlol::SpecSdfFast fast;\n";
-		s += "\tlol::Pixel P = lol::shade_pixel(L, fast, lds);\n";
+		s += "\tlol::Pixel P = lol::shade_pixel<lol::SpecSdfFast, " + tg + ">(L, fast, lds);\n";
 		s += "\tif (lol::unproven(fast)) {\n";
 		s += "\t\tlol::SpecSdfExact exact;\n";
-		s += "\t\tP = lol::shade_pixel(L, exact, lds);\n";
+		s += "\t\tP = lol::shade_pixel<lol::SpecSdfExact, " + tg + ">(L, exact, lds);\n";
 		s += "\t}\n";
 	} else {
 		s += "\tlol::SpecSdfExact exact;\n";
-		s += "\tlol::Pixel P = lol::shade_pixel(L, exact, lds);\n";
+		s += "\tlol::Pixel P = lol::shade_pixel<lol::SpecSdfExact, " + tg + ">(L, exact, lds);\n";
 	}
-	s += "\tlol::store_pixel(L, P, lds);\n";
+	s += "\tlol::store_pixel<" + tg + ">(L, P, lds);\n";
 	s += "}\n";
 	/* the SDF alone at arbitrary points (lol_gpu_sdf_batch) */
 	s += "extern \"C\" __global__ __launch_bounds__(64) void lol_sdf_spec(const float* pts, float* dist, lol::u32* id, lol::u32 n) {\n";
@@ -1278,62 +1370,152 @@ FastPaths prove_fast_paths(lol_gpu* ctx, const lol_program& prog) {
 	return fast;
 }
 
-/* Compile + load the specialised kernel for ctx's program.  On failure the context keeps the interpreter. */
-bool specialise(lol_gpu* ctx) {
-	if (ctx->spec_module) { (void)hipModuleUnload(ctx->spec_module); ctx->spec_module = nullptr; ctx->spec_fn = nullptr; }
+/*
+ * Tiered start-up.  The reference's render_prepare returns at once (naive_renderer.c:242-244 is empty; the tracing JIT's
+ * takes milliseconds, tracing_jit_renderer.dasc:416-434); hipRTC takes 0.6 s for scene4 and half a minute for 5000 ops.
+ * So lol_gpu_upload_program commits the tables and the interpreter's lists, starts the scene compiler on a host thread
+ * and returns: frames render on render_interp at once — same bits — and the first frame launched after the compiler has
+ * finished loads the module and runs lol_render_spec (a swap at a frame boundary, in the calling thread: no second
+ * process, nothing re-executed).  lol_gpu_specialize_wait() blocks until then (tests, benchmarks).
+ */
+/* hipRTC is entered by one thread at a time, and the second context that wants the same scene finds it in the cache */
+std::mutex g_rtc_mutex;
+
+void reap(lol_gpu* ctx, bool all) {
+	for (size_t i = 0; i < ctx->old_jobs.size();) {
+		SpecJob* j = ctx->old_jobs[i];
+		bool done;
+		{ std::lock_guard<std::mutex> lock(j->mu); done = j->done; }
+		if (done || all) {
+			if (j->th.joinable()) j->th.join();
+			delete j;
+			ctx->old_jobs.erase(ctx->old_jobs.begin() + (long)i);
+		} else i++;
+	}
+}
+
+/* Start compiling the specialised kernel of ctx's (just committed) program.  The previous scene's module is gone already
+ * (the caller has drained the device); until finish_specialise() swaps the new one in, the interpreter renders. */
+void start_specialise(lol_gpu* ctx, const FastPaths& fast) {
+	if (ctx->spec_module) { (void)hipModuleUnload(ctx->spec_module); ctx->spec_module = nullptr; }
+	ctx->spec_fn = nullptr;
 	ctx->spec_sdf_fn = nullptr;
 	snprintf(ctx->kernel_name, sizeof ctx->kernel_name, "render_interp");
 	ctx->spec_log.clear();
+	ctx->spec_state = 0;
+	if (ctx->job) { ctx->old_jobs.push_back(ctx->job); ctx->job = nullptr; }      /* a compile of the scene before: its result is not wanted any more */
+	reap(ctx, false);
 	const char* env = getenv("LOL_GPU_SPECIALIZE");
-	if (!ctx->want_spec || (env && env[0] == '0')) return false;
-	/* every program the library accepts is specialised; large ones get their SDF out of line (emit_sdf) */
-
+	if (!ctx->want_spec || (env && env[0] == '0')) return;
+	/* every program up to LOL_SPEC_MAX_OPS is specialised, large ones with their SDF out of line (emit_sdf).  Beyond that the
+	 * straight-line source (two SDF bodies of ~150 bytes per op) takes hipRTC minutes, and programs no longer have a
+	 * capacity (lol_scene.h): such a scene renders on the interpreter, which reads it as data.  Not a failure: no complaint. */
+	{
+		uint32_t limit = LOL_SPEC_MAX_OPS;
+		if (const char* e = getenv("LOL_GPU_SPEC_MAX_OPS")) limit = (uint32_t)strtoul(e, nullptr, 10);
+		if (ctx->h_prog.n_ops > limit) {
+			char b[160];
+			snprintf(b, sizeof b, "%u ops: above the %u the scene compiler takes on (LOL_GPU_SPEC_MAX_OPS); rendered by the interpreter", ctx->h_prog.n_ops, limit);
+			ctx->spec_log = b;
+			return;
+		}
+	}
 	hipDeviceProp_t prop;
 	std::string arch = "gfx950";
 	if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.gcnArchName[0]) {
 		std::string name = prop.gcnArchName;             /* e.g. "gfx950:sramecc+:xnack-" */
 		arch = name.substr(0, name.find(':'));
 	}
-	/* prove the shortcuts on this device before generating them */
-	FastPaths fast = prove_fast_paths(ctx, ctx->h_prog);
-	std::string note;
+	SpecJob* job = nullptr;
+	std::shared_ptr<OwnedProgram> prog;
+	try {
+		job = new SpecJob;
+		prog = std::make_shared<OwnedProgram>();         /* the thread's own copy: the context may take another scene meanwhile */
+		prog->assign(ctx->h_prog);
+	} catch (...) { delete job; ctx->spec_log = "out of host memory"; return; }
 	{
 		char b[160];
 		snprintf(b, sizeof b, "fast paths proven on device: sqrt=%d, smin divisors=%zu (without div_fixup: %zu)\n", fast.sqrt_kind,
 		         fast.div_ok.size(), fast.div_nf_ok.size());
-		note = b;
+		job->note = b;
 	}
-	std::vector<char> code;
 	/* tuning knobs for the pixel footprint of the specialised kernel (defaults: lol_kernel.h LOL_WAVE_W/H, LOL_WAVES_X) */
-	ctx->wave_w = LOL_WAVE_W; ctx->wave_h = LOL_WAVE_H; ctx->waves_x = LOL_WAVES_X;
 	if (const char* e = getenv("LOL_GPU_WAVE_SHAPE")) {
 		int a = 0, b = 0, c = 0;
 		if (sscanf(e, "%dx%dx%d", &a, &b, &c) == 3 && a > 0 && b > 0 && a * b == 64 && c >= 1 && c <= 16) {
-			ctx->wave_w = a; ctx->wave_h = b; ctx->waves_x = c;
+			job->shape[0] = a; job->shape[1] = b; job->shape[2] = c;
 		}
 	}
-	const int shape[3] = { ctx->wave_w, ctx->wave_h, ctx->waves_x };
-	/* an unexpected failure is reported once on stderr: frames still render, through the (slower) interpreter */
-	auto complain = [&]() {
-		fprintf(stderr, "lol_gpu: scene specialisation failed, using the interpreter kernel: %s\n", ctx->spec_log.c_str());
-		return false;
+	const bool cull = culling_enabled(ctx->want_cull);
+	job->started = std::chrono::steady_clock::now();
+	auto work = [job, prog, fast, arch, cull]() {
+		bool ok = false;
+		std::vector<char> code;
+		std::string log;
+		try {
+			std::lock_guard<std::mutex> rtc(g_rtc_mutex);
+			ok = compile_spec(prog->p, &fast, arch, code, log, nullptr, job->shape, cull);
+		} catch (...) { ok = false; log = "the scene compiler ran out of memory"; }
+		std::lock_guard<std::mutex> lock(job->mu);
+		job->compile_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - job->started).count();
+		job->code = std::move(code);
+		job->log = std::move(log);
+		job->ok = ok;
+		job->done = true;
+		job->cv.notify_all();
 	};
-	if (!compile_spec(ctx->h_prog, &fast, arch, code, ctx->spec_log, nullptr, shape, culling_enabled(ctx->want_cull))) return complain();
-	ctx->spec_log = note + ctx->spec_log;
-	if (hipModuleLoadData(&ctx->spec_module, code.data()) != hipSuccess) {
-		ctx->spec_log = "hipModuleLoadData failed";
-		ctx->spec_module = nullptr;
-		return complain();
+	ctx->job = job;
+	ctx->spec_state = 1;
+	const char* async = getenv("LOL_GPU_ASYNC_COMPILE");
+	bool threaded = !(async && async[0] == '0');
+	/* LOL_GPU_ASYNC_COMPILE=0: the upload itself waits for the compiler (still on the large-stack thread) */
+	bool started = false;
+	try { started = job->th.start(work); } catch (...) { started = false; }
+	if (!started) work();                                  /* no thread to be had: compile here */
+	else if (!threaded) job->th.join();
+}
+
+/* The frame boundary: when the compiler has finished (or `wait`), load the module and switch the context over to it.
+ * Returns true when the state changed.  The device of the context is current. */
+bool finish_specialise(lol_gpu* ctx, bool wait) {
+	SpecJob* job = ctx->job;
+	if (!job) return false;
+	{
+		std::unique_lock<std::mutex> lock(job->mu);
+		if (!job->done) {
+			if (!wait) return false;
+			job->cv.wait(lock, [job] { return job->done; });
+		}
 	}
-	if (hipModuleGetFunction(&ctx->spec_fn, ctx->spec_module, "lol_render_spec") != hipSuccess) {
-		ctx->spec_log = "lol_render_spec not found in the compiled module";
-		(void)hipModuleUnload(ctx->spec_module);
-		ctx->spec_module = nullptr; ctx->spec_fn = nullptr;
-		return complain();
+	if (job->th.joinable()) job->th.join();
+	ctx->job = nullptr;
+	ctx->spec_compile_ms = job->compile_ms;
+	/* an unexpected failure is reported once on stderr: frames still render, through the (slower) interpreter */
+	auto complain = [&](const std::string& why) {
+		ctx->spec_log = why;
+		ctx->spec_state = -1;
+		fprintf(stderr, "lol_gpu: scene specialisation failed, using the interpreter kernel: %s\n", ctx->spec_log.c_str());
+		delete job;
+		return true;
+	};
+	if (!job->ok) return complain(job->log);
+	hipModule_t mod = nullptr;
+	hipFunction_t fn = nullptr, sdf_fn = nullptr;
+	if (hipModuleLoadData(&mod, job->code.data()) != hipSuccess) return complain("hipModuleLoadData failed");
+	if (hipModuleGetFunction(&fn, mod, "lol_render_spec") != hipSuccess) {
+		(void)hipModuleUnload(mod);
+		return complain("lol_render_spec not found in the compiled module");
 	}
-	if (hipModuleGetFunction(&ctx->spec_sdf_fn, ctx->spec_module, "lol_sdf_spec") != hipSuccess) ctx->spec_sdf_fn = nullptr;
+	if (hipModuleGetFunction(&sdf_fn, mod, "lol_sdf_spec") != hipSuccess) sdf_fn = nullptr;
+	ctx->spec_module = mod;
+	ctx->spec_fn = fn;
+	ctx->spec_sdf_fn = sdf_fn;
+	ctx->wave_w = job->shape[0]; ctx->wave_h = job->shape[1]; ctx->waves_x = job->shape[2];
+	ctx->spec_log = job->note + job->log;
 	snprintf(ctx->kernel_name, sizeof ctx->kernel_name, "lol_render_spec");
-	ctx->spec_key = fnv_hex(code.data(), code.size());
+	ctx->spec_key = fnv_hex(job->code.data(), job->code.size());
+	ctx->spec_state = 2;
+	delete job;
 	return true;
 }
 
@@ -1357,11 +1539,7 @@ int lol_gpu_create(int device, lol_gpu** out) {
 	ctx->device = device;
 	hipError_t e = hipSetDevice(device);
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-	for (int i = 0; i < 2 && e == hipSuccess; i++) {
-		e = hipMalloc(reinterpret_cast<void**>(&ctx->d_prog[i]), sizeof(lol_program));
-		/* macro-ops + test records <= 1.5 x ops */
-		if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_mops[i]), (size_t)(2 * 2 * LOL_MAX_OPS) * lol::MOP_DWORDS * 4);      /* two lists (lol_gpu_upload_program) */
-	}
+	/* (the device tables are sized by the first upload) */
 	if (e != hipSuccess) {
 		fprintf(stderr, "lol_gpu_create: %s\n", hipGetErrorString(e));
 		lol_gpu_destroy(ctx);
@@ -1375,9 +1553,11 @@ void lol_gpu_destroy(lol_gpu* ctx) {
 	if (!ctx) return;
 	if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
 	if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+	if (ctx->job) { ctx->old_jobs.push_back(ctx->job); ctx->job = nullptr; }
+	reap(ctx, true);                         /* a compiler thread still running is waited for: it must not outlive the library */
 	if (ctx->spec_module) (void)hipModuleUnload(ctx->spec_module);
 	for (int i = 0; i < 2; i++) {
-		if (ctx->d_prog[i]) (void)hipFree(ctx->d_prog[i]);
+		if (ctx->d_tables[i]) (void)hipFree(ctx->d_tables[i]);
 		if (ctx->d_mops[i]) (void)hipFree(ctx->d_mops[i]);
 	}
 	if (ctx->d_frame) (void)hipFree(ctx->d_frame);
@@ -1499,7 +1679,7 @@ static int tile_order_for_frame(lol_gpu* ctx, int w, int h, int max_steps, const
 	lol_gpu::TileAuto& T = ctx->tiles;
 	*trial = -1;
 	if (T.mode != LOL_GPU_TILES_AUTO) return T.chosen;
-	const int key[6] = { w, h, max_steps, R->band_rows, R->cycle_rows, ctx->generation };
+	const int key[6] = { w, h, max_steps, R->band_rows, R->cycle_rows, ctx->generation * 2 + (ctx->spec_fn ? 1 : 0) };      /* (the kernel too: interpreter or the scene's own) */
 	if (memcmp(key, T.key, sizeof key) != 0) {          /* another scene, size or partition: measure again */
 		memcpy(T.key, key, sizeof key);
 		if (!T.have_events) {
@@ -1561,11 +1741,32 @@ int lol_gpu_verify_smin_no_fixup(lol_gpu* ctx, float k, unsigned long long* mism
 
 const char* lol_gpu_specialize_log(const lol_gpu* ctx) { return ctx ? ctx->spec_log.c_str() : ""; }
 
+int lol_gpu_specialize_wait(lol_gpu* ctx) {
+	if (!ctx) return LOL_GPU_ERR_ARG;
+	LOL_HIP(ctx, hipSetDevice(ctx->device));
+	finish_specialise(ctx, true);
+	return LOL_GPU_OK;
+}
+
+int lol_gpu_specialize_state(lol_gpu* ctx, double* compile_ms) {
+	if (!ctx) return LOL_GPU_ERR_ARG;
+	if (ctx->job) {                                    /* has the compiler finished?  (the swap itself happens at a frame or a wait) */
+		std::lock_guard<std::mutex> lock(ctx->job->mu);
+		if (compile_ms) *compile_ms = ctx->job->done ? ctx->job->compile_ms : 0.0;
+		return ctx->job->done ? 3 : 1;
+	}
+	if (compile_ms) *compile_ms = ctx->spec_compile_ms;
+	return ctx->spec_state;
+}
+
 int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog) {
 	if (!ctx || !prog) return LOL_GPU_ERR_ARG;
+	/* sanity caps (lol_scene.h): counts beyond them are corruption, not scenes; every table a count speaks of must be there */
 	if (prog->n_ops > LOL_MAX_OPS || prog->n_lights > LOL_MAX_LIGHTS || prog->n_materials > LOL_MAX_MATERIALS ||
 	    prog->n_roots > LOL_MAX_OPS || prog->max_stack > LOL_MAX_STACK || prog->n_materials == 0)
-		return fail(ctx, LOL_GPU_ERR_UNSUPPORTED, "program exceeds interpreter limits");
+		return fail(ctx, LOL_GPU_ERR_UNSUPPORTED, "program exceeds the sanity caps of lol_scene.h (or has no material)");
+	if ((prog->n_ops && !prog->ops) || (prog->n_lights && !prog->lights) || !prog->materials || (prog->n_roots && !prog->root_material))
+		return fail(ctx, LOL_GPU_ERR_ARG, "malformed program: a table is missing");
 	/* validate what the kernel indexes with: stack discipline and material indices */
 	int depth = 0;
 	for (uint32_t i = 0; i < prog->n_ops; i++) {
@@ -1605,7 +1806,6 @@ int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog) {
 	const CullPlan cull_plan = plan_culling(roots, culling_enabled(ctx->want_cull));
 	std::vector<uint32_t> mops = build_mops(*prog, &fast, roots, cull_plan, false);
 	const uint32_t n_mops = (uint32_t)(mops.size() / lol::MOP_DWORDS);
-	if (n_mops > 2 * LOL_MAX_OPS) return fail(ctx, LOL_GPU_ERR_UNSUPPORTED, "program exceeds interpreter limits");
 	{
 		const std::vector<uint32_t> nofix = build_mops(*prog, &fast, roots, cull_plan, true);
 		if (nofix.size() != mops.size()) return fail(ctx, LOL_GPU_ERR_UNSUPPORTED, "interpreter lists differ in length");      /* (same records by construction) */
@@ -1614,14 +1814,37 @@ int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog) {
 	const int next = ctx->cur ^ 1;
 	const bool injected = ctx->fail_uploads > 0;      /* lol_gpu_testing_fail_uploads (tests/test_gpu_boundary.py) */
 	if (injected) ctx->fail_uploads--;
-	hipError_t e = injected ? hipErrorOutOfMemory : hipMemcpy(ctx->d_prog[next], prog, sizeof *prog, hipMemcpyHostToDevice);
+	/* lights | materials | root_material as one array of dwords, in the set no frame reads; grown when this scene needs more */
+	std::vector<uint32_t> tables(lol::table_dwords(prog->n_lights, prog->n_materials, prog->n_roots));
+	{
+		uint32_t* t = tables.data();
+		if (prog->n_lights) memcpy(t, prog->lights, (size_t)prog->n_lights * sizeof(lol_light));
+		t += (size_t)prog->n_lights * lol::LIGHT_DWORDS;
+		memcpy(t, prog->materials, (size_t)prog->n_materials * sizeof(lol_material));
+		t += (size_t)prog->n_materials * lol::MATERIAL_DWORDS;
+		if (prog->n_roots) memcpy(t, prog->root_material, (size_t)prog->n_roots * 4);
+	}
+	auto fit = [&](uint32_t*& buf, size_t& cap, size_t need) -> hipError_t {
+		if (need <= cap) return hipSuccess;
+		uint32_t* nb = nullptr;
+		const size_t want = need + need / 2 + 256;
+		const hipError_t me = hipMalloc(reinterpret_cast<void**>(&nb), want * 4);
+		if (me != hipSuccess) return me;
+		if (buf) (void)hipFree(buf);                  /* (the device is idle and no frame reads this set) */
+		buf = nb; cap = want;
+		return hipSuccess;
+	};
+	hipError_t e = injected ? hipErrorOutOfMemory : fit(ctx->d_tables[next], ctx->tables_cap[next], tables.size());
+	if (e == hipSuccess) e = fit(ctx->d_mops[next], ctx->mops_cap[next], mops.size());
+	if (e == hipSuccess) e = hipMemcpy(ctx->d_tables[next], tables.data(), tables.size() * 4, hipMemcpyHostToDevice);
 	if (e == hipSuccess && !mops.empty())
 		e = hipMemcpy(ctx->d_mops[next], mops.data(), mops.size() * 4, hipMemcpyHostToDevice);
-	if (e != hipSuccess) return fail(ctx, LOL_GPU_ERR_HIP, "hipMemcpy(program)", e);
+	if (e != hipSuccess) return fail(ctx, LOL_GPU_ERR_HIP, "upload of the scene tables", e);
+	try { ctx->h_own.assign(*prog); }                 /* the last fallible step (host memory); the old scene is intact until here */
+	catch (...) { return fail(ctx, LOL_GPU_ERR_HIP, "out of host memory"); }
 	/* commit */
 	ctx->generation++;
 	ctx->cur = next;
-	ctx->h_prog = *prog;
 	ctx->have_prog = true;
 	ctx->n_mops = n_mops;
 	ctx->finite_scene = shadow_settle_ok(*prog);
@@ -1632,7 +1855,9 @@ int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog) {
 		ctx->interp_key = fnv_hex(id.data(), id.size());
 	}
 	resolve_skips(ctx);
-	specialise(ctx);          /* a failed specialisation is not an error: the interpreter renders the new scene */
+	/* the scene compiler starts on its own thread; the new scene renders on the interpreter until its kernel is there
+	 * (a failed specialisation is not an error either: the interpreter goes on rendering) */
+	start_specialise(ctx, fast);
 	return LOL_GPU_OK;
 }
 
@@ -1675,11 +1900,10 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	L.band_rows = R->band_rows; L.cycle_rows = R->cycle_rows; L.offset_rows = R->offset_rows;
 	const lol_program& P = ctx->h_prog;
 	L.n_ops = ctx->n_mops; L.n_lights = P.n_lights; L.n_materials = P.n_materials; L.n_roots = P.n_roots;
-	const char* base = reinterpret_cast<const char*>(ctx->d_prog[ctx->cur]);
 	L.ops           = ctx->d_mops[ctx->cur] + (ctx->finite_scene && camera_sane(*cam) ? (size_t)ctx->n_mops * lol::MOP_DWORDS : 0u);
-	L.lights        = reinterpret_cast<const uint32_t*>(base + offsetof(lol_program, lights));
-	L.materials     = reinterpret_cast<const uint32_t*>(base + offsetof(lol_program, materials));
-	L.root_material = reinterpret_cast<const uint32_t*>(base + offsetof(lol_program, root_material));
+	L.lights        = ctx->d_tables[ctx->cur];
+	L.materials     = L.lights + (size_t)P.n_lights * lol::LIGHT_DWORDS;
+	L.root_material = L.materials + (size_t)P.n_materials * lol::MATERIAL_DWORDS;
 	L.ambient[0] = P.ambient_color.x; L.ambient[1] = P.ambient_color.y; L.ambient[2] = P.ambient_color.z;
 	L.flags = (ctx->miss_skip ? lol::FLAG_MISS_SKIP : 0u) | (ctx->dark_skip ? lol::FLAG_DARK_SKIP : 0u) |
 	          (ctx->shadow_settle && camera_sane(*cam) ? lol::FLAG_SHADOW_SETTLED : 0u);
@@ -1691,13 +1915,14 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 		L.dbg_hit_id = dbg->hit_id; L.dbg_steps = dbg->steps;
 	}
 
+	hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;      /* LOL_GPU_STREAM_DEFAULT == hipStreamLegacy */
+	LOL_HIP(ctx, hipSetDevice(ctx->device));
+	finish_specialise(ctx, false);           /* the frame boundary at which a finished scene kernel takes over */
 	const bool spec = ctx->spec_fn != nullptr;
 	const int tile_w = spec ? ctx->wave_w * ctx->waves_x : lol::TILE_W, tile_h = spec ? ctx->wave_h : lol::TILE_H;
 	const int block = tile_w * tile_h;
 	dim3 grid((w + tile_w - 1) / tile_w, (n_rows + tile_h - 1) / tile_h);
-	size_t common = (size_t)(lol::common_lds_dwords(P.n_lights, P.n_materials, P.n_roots) - lol::TILE_W * lol::TILE_H + block) * 4;
-	hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;      /* LOL_GPU_STREAM_DEFAULT == hipStreamLegacy */
-	LOL_HIP(ctx, hipSetDevice(ctx->device));
+	const size_t common = (size_t)(lol::common_lds_dwords(P.n_lights, P.n_materials, P.n_roots) - lol::TILE_W * lol::TILE_H + block) * 4;
 	int trial = -1;
 	if (tile_order_for_frame(ctx, w, h, max_steps, R, dbg != nullptr, &trial) == LOL_GPU_TILES_COLS) {
 		L.flags |= lol::FLAG_TILE_COLS;
@@ -1716,12 +1941,19 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 		void* args[] = { &L };
 		e = hipModuleLaunchKernel(ctx->spec_fn, grid.x, grid.y, 1, block, 1, 1, (unsigned)common, s, args, nullptr);
 	} else {
-		const uint32_t need = P.max_stack > 1 ? P.max_stack - 1 : 1;      /* the accumulator holds the top entry */
 		const int kind = ctx->interp_sqrt_kind;
-		if (need <= 1)      e = launch_interp<1>(L, grid, common, s, kind);
-		else if (need <= 3) e = launch_interp<3>(L, grid, common, s, kind);
-		else if (need <= 7) e = launch_interp<7>(L, grid, common, s, kind);
-		else                e = launch_interp<LOL_MAX_STACK - 1>(L, grid, common, s, kind);
+		const int cls = interp_stack_class(P.max_stack);
+		if (lol::tables_in_lds(P.n_lights, P.n_materials, P.n_roots)) {
+			if (cls == 1)      e = launch_interp<1>(L, grid, common, s, kind);
+			else if (cls == 3) e = launch_interp<3>(L, grid, common, s, kind);
+			else if (cls == 7) e = launch_interp<7>(L, grid, common, s, kind);
+			else if (cls == lol::MOP_DEEP_FROM - 1) e = launch_interp<lol::MOP_DEEP_FROM - 1>(L, grid, common, s, kind);
+			else               e = launch_interp<lol::MOP_DEEP_SLOTS>(L, grid, common, s, kind);
+		} else {               /* large tables, read from global memory (lol_kernel.h, TABLES_LDS_MAX_DWORDS): three stack classes */
+			if (cls <= 3)      e = launch_interp<3, true>(L, grid, common, s, kind);
+			else if (cls <= lol::MOP_DEEP_FROM - 1) e = launch_interp<lol::MOP_DEEP_FROM - 1, true>(L, grid, common, s, kind);
+			else               e = launch_interp<lol::MOP_DEEP_SLOTS, true>(L, grid, common, s, kind);
+		}
 	}
 	if (g_roctx.pop) g_roctx.pop();
 	if (e != hipSuccess) return fail(ctx, LOL_GPU_ERR_HIP, "kernel launch", e);
@@ -1932,16 +2164,18 @@ int lol_gpu_sdf_batch(lol_gpu* ctx, const float* pts_dev, float* dist_dev, uint3
 	hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
 	uint32_t n32 = (uint32_t)n;
 	hipError_t e;
+	finish_specialise(ctx, false);
 	if (ctx->spec_fn && ctx->spec_sdf_fn) {
 		void* args[] = { &pts_dev, &dist_dev, &id_dev, &n32 };
 		e = hipModuleLaunchKernel(ctx->spec_sdf_fn, (n32 + 63) / 64, 1, 1, 64, 1, 1, 0, s, args, nullptr);
 	} else {
-		const uint32_t need = ctx->h_prog.max_stack > 1 ? ctx->h_prog.max_stack - 1 : 1;
 		const int kind = ctx->interp_sqrt_kind;
-		if (need <= 1)      e = launch_sdf_interp<1>(ctx->d_mops[ctx->cur], ctx->n_mops, pts_dev, dist_dev, id_dev, n32, s, kind);
-		else if (need <= 3) e = launch_sdf_interp<3>(ctx->d_mops[ctx->cur], ctx->n_mops, pts_dev, dist_dev, id_dev, n32, s, kind);
-		else if (need <= 7) e = launch_sdf_interp<7>(ctx->d_mops[ctx->cur], ctx->n_mops, pts_dev, dist_dev, id_dev, n32, s, kind);
-		else                e = launch_sdf_interp<LOL_MAX_STACK - 1>(ctx->d_mops[ctx->cur], ctx->n_mops, pts_dev, dist_dev, id_dev, n32, s, kind);
+		const int cls = interp_stack_class(ctx->h_prog.max_stack);
+		if (cls == 1)      e = launch_sdf_interp<1>(ctx->d_mops[ctx->cur], ctx->n_mops, pts_dev, dist_dev, id_dev, n32, s, kind);
+		else if (cls == 3) e = launch_sdf_interp<3>(ctx->d_mops[ctx->cur], ctx->n_mops, pts_dev, dist_dev, id_dev, n32, s, kind);
+		else if (cls == 7) e = launch_sdf_interp<7>(ctx->d_mops[ctx->cur], ctx->n_mops, pts_dev, dist_dev, id_dev, n32, s, kind);
+		else if (cls == lol::MOP_DEEP_FROM - 1) e = launch_sdf_interp<lol::MOP_DEEP_FROM - 1>(ctx->d_mops[ctx->cur], ctx->n_mops, pts_dev, dist_dev, id_dev, n32, s, kind);
+		else               e = launch_sdf_interp<lol::MOP_DEEP_SLOTS>(ctx->d_mops[ctx->cur], ctx->n_mops, pts_dev, dist_dev, id_dev, n32, s, kind);
 	}
 	if (e != hipSuccess) return fail(ctx, LOL_GPU_ERR_HIP, "sdf kernel launch", e);
 	return LOL_GPU_OK;
@@ -1962,7 +2196,18 @@ int lol_gpu_compile_offline(const lol_program* prog, const char* arch, const cha
 			if ((prog->ops[i].op == LOL_OP_SMIN || prog->ops[i].op == LOL_OP_SMIN_R) && !fast.has(prog->ops[i].f[0]))
 				{ fast.div_ok.push_back(prog->ops[i].f[0]); fast.div_nf_ok.push_back(prog->ops[i].f[0]); }
 	}
-	bool ok = compile_spec(*prog, &fast, arch, code, lg, &src, nullptr, culling_enabled(1));
+	bool ok = false;
+	{
+		/* on the large-stack thread, like every run of the scene compiler (BigStackThread) */
+		BigStackThread th;
+		auto work = [&]() {
+			try { std::lock_guard<std::mutex> rtc(g_rtc_mutex); ok = compile_spec(*prog, &fast, arch, code, lg, &src, nullptr, culling_enabled(1)); }
+			catch (...) { ok = false; lg = "the scene compiler ran out of memory"; }
+		};
+		bool started = false;
+		try { started = th.start(work); } catch (...) { started = false; }
+		if (started) th.join(); else work();
+	}
 	if (log && logcap) snprintf(log, logcap, "%s", lg.c_str());
 	if (out_base && out_base[0]) {
 		std::string base = out_base;

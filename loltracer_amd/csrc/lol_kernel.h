@@ -519,8 +519,16 @@ __host__ __device__ constexpr u32 mop_header(u32 kind, u32 comb) {
  * s_load_dwordx8 + x4 (vector-typed loads of such records miscompile under hipcc 7.2: lane .y read as .x) */
 typedef const __attribute__((address_space(4))) u32* mop_ptr;
 
+/* Operand stacks deeper than the 4-bit slot fields (MOP_DEEP_FROM entries under the accumulator: a tree of more than 4096
+ * primitives in ONE object) use the instantiation Interp<MOP_DEEP_SLOTS>: the slot number travels in a word of its own —
+ * word 9 of a PUSH record (it has no smooth min), word 2 of a POP record (it has no primitive) — the stack is indexed
+ * with it directly (registers or scratch, the compiler's choice) and lol_gpu.hip's build_mops does not fuse pops into
+ * MOPB_POST for such lists.  The reference recurses without a limit (naive_renderer.c:11-28); this is its counterpart. */
+constexpr int MOP_DEEP_FROM = 12, MOP_DEEP_SLOTS = 63;
+
 template <int SSIZE, int KIND = 0>
 struct Interp {
+	static constexpr bool DEEP = SSIZE >= MOP_DEEP_FROM;
 	const u32* mops;     /* global memory, MOP_DWORDS per macro-op, 16-byte aligned */
 	u32        n_mops;
 	Range      rg;       /* KIND != 0: range of the squared lengths given to the proven fast sqrt (see above) */
@@ -583,10 +591,14 @@ struct Interp {
 					x = p.y - F(2);                              /* plane: (p - (0,y,0)).y */
 				if (hdr & MOPB_POP) {
 					LOL_KEEP_BRANCH();
-					const u32 slot = hdr >> MOP_SLOT_SHIFT & MOP_SLOT_MASK;
-					x = s[0];
+					if constexpr (DEEP) {
+						x = s[w2 < (u32)SSIZE ? w2 : 0u];
+					} else {
+						const u32 slot = hdr >> MOP_SLOT_SHIFT & MOP_SLOT_MASK;
+						x = s[0];
 #pragma unroll
-					for (int j = 1; j < SSIZE; j++) x = slot == (u32)j ? s[j] : x;
+						for (int j = 1; j < SSIZE; j++) x = slot == (u32)j ? s[j] : x;
+					}
 				}
 			}
 			if (LOL_OFTEN(hdr & MOPB_SMIN)) {
@@ -610,7 +622,7 @@ struct Interp {
 				LOL_KEEP_BRANCH();
 				if (hdr & MOPB_STACK) {                                 /* POST | PUSH: the end of an object pays one test for both */
 					LOL_KEEP_BRANCH();
-					if (hdr & MOPB_POST) {
+					if constexpr (!DEEP) if (hdr & MOPB_POST) {                /* (deep lists carry no POST: build_mops) */
 						LOL_KEEP_BRANCH();
 						const u32 ps = hdr >> MOP_POST_SLOT_SHIFT & MOP_SLOT_MASK;
 						float y = s[0];
@@ -622,9 +634,13 @@ struct Interp {
 					}
 					if (hdr & MOPB_PUSH) {
 						LOL_KEEP_BRANCH();
-						const u32 slot = hdr >> MOP_SLOT_SHIFT & MOP_SLOT_MASK;
+						if constexpr (DEEP) {
+							s[w9 < (u32)SSIZE ? w9 : 0u] = acc;
+						} else {
+							const u32 slot = hdr >> MOP_SLOT_SHIFT & MOP_SLOT_MASK;
 #pragma unroll
-						for (int j = 0; j < SSIZE; j++) s[j] = slot == (u32)j ? acc : s[j];
+							for (int j = 0; j < SSIZE; j++) s[j] = slot == (u32)j ? acc : s[j];
+						}
 					}
 				}
 				if (hdr & MOP_TOP) {                                    /* (tests only follow finished objects) */
@@ -785,9 +801,22 @@ __device__ __forceinline__ V3 lds_v3(const u32* base) {
 	return { f[0], f[1], f[2] };
 }
 
-/* dwords of LDS the pipeline needs besides what the Sdf policy stages itself */
+/* Where the pipeline reads lights, materials and the objects' material indices from.  Small scenes: staged once per block
+ * into LDS (stage_common; scene4: 276 bytes).  That staging is per ONE-WAVE block, so it cannot scale with the scene — at
+ * the old capacity (64 lights, 256 materials, 1024 objects) it was 16.9 KB per wave, 9 waves per CU instead of 32 — and the
+ * tables have no capacity any more (lol_scene.h).  Beyond TABLES_LDS_MAX_DWORDS (4 KB: 32 waves x 4 KB + their tiles still
+ * fit the CU's 160 KB) the kernels are instantiated with TABLES_GLOBAL and read the tables where they lie: lights with
+ * wave-uniform addresses, the hit's material per lane, a few dozen loads per pixel against thousands of instructions. */
+constexpr u32 TABLES_LDS_MAX_DWORDS = 1024;
+__host__ __device__ inline u32 table_dwords(u32 n_lights, u32 n_materials, u32 n_roots) {
+	return n_lights * LIGHT_DWORDS + n_materials * MATERIAL_DWORDS + n_roots;
+}
+__host__ __device__ inline bool tables_in_lds(u32 n_lights, u32 n_materials, u32 n_roots) {
+	return table_dwords(n_lights, n_materials, n_roots) <= TABLES_LDS_MAX_DWORDS;
+}
+/* dwords of LDS a block needs: the tables (when staged) + its output tile */
 __host__ __device__ inline u32 common_lds_dwords(u32 n_lights, u32 n_materials, u32 n_roots) {
-	return n_lights * LIGHT_DWORDS + n_materials * MATERIAL_DWORDS + n_roots + TILE_W * TILE_H;
+	return (tables_in_lds(n_lights, n_materials, n_roots) ? table_dwords(n_lights, n_materials, n_roots) : 0u) + TILE_W * TILE_H;
 }
 
 struct Pixel { V3 rgb; Hit hit; u32 shadow_steps; };      /* rgb: post-gamma colour; packed into the surface's format by store_pixel */
@@ -800,13 +829,14 @@ __device__ __forceinline__ int frame_row(const Launch& L, int r) {
 
 /*
  * The per-pixel body, naive_renderer.c:217-235, for the pixel this lane owns.
- * `lds` = lights | materials | root_material | out tile (already staged and synchronised).
+ * `lds` = lights | materials | root_material | out tile (already staged and synchronised); with TABLES_GLOBAL the
+ * three tables are read from global memory instead (L.lights, L.materials, L.root_material) and `lds` is the tile alone.
  */
-template <class Sdf>
+template <class Sdf, bool TABLES_GLOBAL = false>
 __device__ __forceinline__ Pixel shade_pixel(const Launch& L, Sdf& sdf, const u32* lds) {
-	const u32* l_light = lds;
-	const u32* l_mat   = l_light + L.n_lights * LIGHT_DWORDS;
-	const u32* l_rootm = l_mat + L.n_materials * MATERIAL_DWORDS;
+	const u32* l_light = TABLES_GLOBAL ? L.lights : lds;
+	const u32* l_mat   = TABLES_GLOBAL ? L.materials : l_light + L.n_lights * LIGHT_DWORDS;
+	const u32* l_rootm = TABLES_GLOBAL ? L.root_material : l_mat + L.n_materials * MATERIAL_DWORDS;
 
 	/* lane → pixel: wave k covers a WAVE_W x WAVE_H patch of the block's tile */
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -892,6 +922,7 @@ __device__ __forceinline__ Pixel shade_pixel(const Launch& L, Sdf& sdf, const u3
 }
 
 /* Pack the lane's colour for the surface, write it (and the optional diagnostics).  Every thread of the block must call this. */
+template <bool TABLES_GLOBAL = false>
 __device__ __forceinline__ void store_pixel(const Launch& L, const Pixel& P, u32* lds) {
 	const LaunchTail T = launch_tail(L);
 	/* colorf_to_pixfmt, renderer.h:17-22: Uint8 r = colorf.x * 255 …; SDL_MapRGB(fmt, r, g, b) for a non-palettised format
@@ -901,7 +932,7 @@ __device__ __forceinline__ void store_pixel(const Launch& L, const Pixel& P, u32
 	const u32 px = (r8 >> (T.fmt_loss & 0xFFu)) << (T.fmt_shift & 0xFFu) |
 	               (g8 >> (T.fmt_loss >> 8 & 0xFFu)) << (T.fmt_shift >> 8 & 0xFFu) |
 	               (b8 >> (T.fmt_loss >> 16 & 0xFFu)) << (T.fmt_shift >> 16 & 0xFFu) | T.fmt_amask;
-	u32* l_tile = lds + L.n_lights * LIGHT_DWORDS + L.n_materials * MATERIAL_DWORDS + L.n_roots;
+	u32* l_tile = TABLES_GLOBAL ? lds : lds + L.n_lights * LIGHT_DWORDS + L.n_materials * MATERIAL_DWORDS + L.n_roots;
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int tx = wave * WAVE_W + (lane % WAVE_W), ty = lane / WAVE_W;
 	const bool cols = (L.flags & FLAG_TILE_COLS) != 0u;
@@ -938,19 +969,21 @@ __device__ __forceinline__ void stage_common(const Launch& L, u32* lds) {
  * proven fast sqrt (the host launches that instantiation only after the exhaustive check passed on the device); a
  * wave that fed it a squared length outside its proven domain shades its pixels again with the plain interpreter,
  * as in the specialised kernel. */
-template <int SSIZE, int KIND>
+template <int SSIZE, int KIND, bool TABLES_GLOBAL = false>
 __global__ __launch_bounds__(BLOCK)
 void render_interp(const Launch L) {
 	extern __shared__ u32 lds[];
-	stage_common(L, lds);
-	__syncthreads();
+	if constexpr (!TABLES_GLOBAL) {
+		stage_common(L, lds);
+		__syncthreads();
+	}
 	Interp<SSIZE, KIND> sdf{ L.ops, L.n_ops, {}, 0u };
-	Pixel P = shade_pixel(L, sdf, lds);
+	Pixel P = shade_pixel<Interp<SSIZE, KIND>, TABLES_GLOBAL>(L, sdf, lds);
 	if (KIND != 0 && unproven(sdf)) {
 		Interp<SSIZE, 0> exact{ L.ops, L.n_ops, {}, 0u };
-		P = shade_pixel(L, exact, lds);
+		P = shade_pixel<Interp<SSIZE, 0>, TABLES_GLOBAL>(L, exact, lds);
 	}
-	store_pixel(L, P, lds);
+	store_pixel<TABLES_GLOBAL>(L, P, lds);
 }
 
 /* Diagnostic: the scene SDF alone — sdf() of naive_renderer.c:31-44 — at arbitrary points, one per lane, through the

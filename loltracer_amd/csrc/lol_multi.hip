@@ -456,6 +456,15 @@ int lol_gpu_multi_upload_program(lol_gpu_multi* m, const lol_program* prog) {
 	return LOL_GPU_OK;
 }
 
+int lol_gpu_multi_specialize_wait(lol_gpu_multi* m) {
+	if (!m) return LOL_GPU_ERR_ARG;
+	for (int i = 0; i < m->n; i++) {
+		int st = lol_gpu_specialize_wait(m->dev[i].ctx);
+		if (st != LOL_GPU_OK) return mfail(m, st, "lol_gpu_specialize_wait", lol_gpu_error(m->dev[i].ctx));
+	}
+	return LOL_GPU_OK;
+}
+
 int lol_gpu_multi_set_parts_per_device(lol_gpu_multi* m, int parts) {
 	if (!m || parts < 1 || parts * m->n > MAX_PARTS) return LOL_GPU_ERR_ARG;
 	int st = lol_gpu_multi_sync(m);

@@ -158,7 +158,7 @@ struct def { enum tok prop; struct value v; };
 struct deflist { struct def* d; size_t n, cap; };
 
 /* Objects nest through `a = smooth_union { ... }`.  parse_value / parse_deflist recurse once per level, so the
- * depth is bounded: a chain this deep could never be flattened anyway (2 ops per level, LOL_MAX_OPS = 1024). */
+ * depth is bounded (the reference's own bison stack is: YYMAXDEPTH, a few thousand levels of nested objects). */
 #define LOL_PARSE_MAX_DEPTH 1024
 
 struct parser {
@@ -593,18 +593,33 @@ static int su_need(const lol_scene* s, int32_t idx, int depth, int16_t* need) {
 	return v;
 }
 
-static int emit(const lol_scene* s, int32_t idx, lol_program* out, const int16_t* need) {
+/* the next free op of a program whose `ops` table grows by doubling (cap = *ops_cap) */
+static lol_op* next_op(lol_program* out, size_t* ops_cap, int* status) {
+	if (out->n_ops >= LOL_MAX_OPS) { *status = LOL_ERR_UNSUPPORTED; return NULL; }
+	if (out->n_ops == *ops_cap) {
+		const size_t nc = *ops_cap ? *ops_cap * 2 : 64;
+		lol_op* np = realloc(out->ops, nc * sizeof *np);
+		if (!np) { *status = LOL_ERR_NOMEM; return NULL; }
+		out->ops = np;
+		*ops_cap = nc;
+	}
+	lol_op* op = &out->ops[out->n_ops++];
+	memset(op, 0, sizeof *op);
+	return op;
+}
+
+static int emit(const lol_scene* s, int32_t idx, lol_program* out, size_t* ops_cap, const int16_t* need) {
 	const lol_node* n = &s->nodes[idx];
 	const int swap = n->type == LOL_NODE_SMOOTH_UNION && need[n->b] > need[n->a];
 	if (n->type == LOL_NODE_SMOOTH_UNION) {
-		int st = emit(s, swap ? n->b : n->a, out, need);
+		int st = emit(s, swap ? n->b : n->a, out, ops_cap, need);
 		if (st != LOL_OK) return st;
-		st = emit(s, swap ? n->a : n->b, out, need);
+		st = emit(s, swap ? n->a : n->b, out, ops_cap, need);
 		if (st != LOL_OK) return st;
 	}
-	if (out->n_ops >= LOL_MAX_OPS) return LOL_ERR_UNSUPPORTED;
-	lol_op* op = &out->ops[out->n_ops++];
-	memset(op, 0, sizeof *op);
+	int status = LOL_OK;
+	lol_op* op = next_op(out, ops_cap, &status);
+	if (!op) return status;
 	switch (n->type) {
 	case LOL_NODE_SPHERE:
 		op->op = LOL_OP_SPHERE;
@@ -631,6 +646,12 @@ static int emit(const lol_scene* s, int32_t idx, lol_program* out, const int16_t
 	return LOL_OK;
 }
 
+void lol_program_free(lol_program* p) {
+	if (!p) return;
+	free(p->ops); free(p->lights); free(p->materials); free(p->root_material);
+	memset(p, 0, sizeof *p);
+}
+
 int lol_scene_flatten(const lol_scene* s, lol_program* out) {
 	memset(out, 0, sizeof *out);
 	if (s->n_lights > LOL_MAX_LIGHTS || s->n_materials > LOL_MAX_MATERIALS ||
@@ -639,30 +660,39 @@ int lol_scene_flatten(const lol_scene* s, lol_program* out) {
 	if (s->n_materials == 0 || !lol_scene_validate_materials(s))
 		return LOL_ERR_MATERIAL;   /* material #0 is the miss material (naive_renderer.c:103-112) */
 
-	out->n_lights = (uint32_t)s->n_lights;
-	out->n_materials = (uint32_t)s->n_materials;
-	out->n_roots = (uint32_t)s->n_roots;
-	out->ambient_color = s->ambient_color;
-	memcpy(out->lights, s->lights, s->n_lights * sizeof *s->lights);
-	memcpy(out->materials, s->materials, s->n_materials * sizeof *s->materials);
-
+	/* (a table of no entries is still a non-NULL allocation: consumers need not special-case it) */
+	out->lights = malloc((s->n_lights ? s->n_lights : 1) * sizeof *out->lights);
+	out->materials = malloc(s->n_materials * sizeof *out->materials);
+	out->root_material = malloc((s->n_roots ? s->n_roots : 1) * sizeof *out->root_material);
 	int16_t* memo = calloc(s->n_nodes ? s->n_nodes : 1, sizeof *memo);
-	if (!memo) return LOL_ERR_NOMEM;
-	int status = LOL_OK;
+	size_t ops_cap = 0;
+	int status = out->lights && out->materials && out->root_material && memo ? LOL_OK : LOL_ERR_NOMEM;
+	if (status == LOL_OK) {
+		out->n_lights = (uint32_t)s->n_lights;
+		out->n_materials = (uint32_t)s->n_materials;
+		out->n_roots = (uint32_t)s->n_roots;
+		out->ambient_color = s->ambient_color;
+		if (s->n_lights) memcpy(out->lights, s->lights, s->n_lights * sizeof *s->lights);
+		memcpy(out->materials, s->materials, s->n_materials * sizeof *s->materials);
+	}
 	for (size_t i = 0; i < s->n_roots && status == LOL_OK; i++) {
 		int need = su_need(s, s->roots[i], 0, memo);
 		if (need < 0 || need > LOL_MAX_STACK) { status = LOL_ERR_UNSUPPORTED; break; }
 		if ((uint32_t)need > out->max_stack) out->max_stack = (uint32_t)need;
-		status = emit(s, s->roots[i], out, memo);
+		status = emit(s, s->roots[i], out, &ops_cap, memo);
 		if (status != LOL_OK) break;
-		if (out->n_ops >= LOL_MAX_OPS) { status = LOL_ERR_UNSUPPORTED; break; }
-		lol_op* top = &out->ops[out->n_ops++];
-		memset(top, 0, sizeof *top);
+		lol_op* top = next_op(out, &ops_cap, &status);
+		if (!top) break;
 		top->op = LOL_OP_TOP;
 		top->id = (uint32_t)(i + 1);
 		out->root_material[i] = s->nodes[s->roots[i]].material;
 	}
 	free(memo);
+	if (status == LOL_OK && !out->ops) {            /* a scene without objects: an empty, non-NULL table */
+		out->ops = malloc(sizeof *out->ops);
+		if (!out->ops) status = LOL_ERR_NOMEM;
+	}
+	if (status != LOL_OK) lol_program_free(out);
 	return status;
 }
 

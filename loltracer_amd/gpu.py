@@ -154,6 +154,12 @@ def gpu_lib() -> C.CDLL:
         lib.lol_gpu_set_specialize.restype = C.c_int
         lib.lol_gpu_specialize_log.argtypes = [vp]
         lib.lol_gpu_specialize_log.restype = C.c_char_p
+        lib.lol_gpu_specialize_wait.argtypes = [vp]
+        lib.lol_gpu_specialize_wait.restype = C.c_int
+        lib.lol_gpu_specialize_state.argtypes = [vp, P(C.c_double)]
+        lib.lol_gpu_specialize_state.restype = C.c_int
+        lib.lol_gpu_multi_specialize_wait.argtypes = [vp]
+        lib.lol_gpu_multi_specialize_wait.restype = C.c_int
         lib.lol_gpu_compile_offline.argtypes = [P(S.Program), C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]
         lib.lol_gpu_compile_offline.restype = C.c_int
         lib.lol_gpu_verify_fast_paths.argtypes = [vp, C.c_float, P(C.c_ulonglong), P(C.c_ulonglong)]
@@ -247,7 +253,7 @@ EXPORTED_SYMBOLS = [
     "lol_gpu_abi_version", "lol_gpu_device_count", "lol_gpu_create", "lol_gpu_destroy", "lol_gpu_error", "lol_gpu_upload_program",
     "lol_gpu_part_rows", "lol_gpu_render_device", "lol_gpu_render_host", "lol_gpu_sync", "lol_gpu_malloc",
     "lol_gpu_free", "lol_gpu_memcpy_d2h", "lol_gpu_kernel_name", "lol_gpu_set_specialize",
-    "lol_gpu_specialize_log", "lol_gpu_compile_offline", "lol_gpu_verify_fast_paths", "lol_gpu_verify_smin_no_fixup", "lol_gpu_set_miss_skip",
+    "lol_gpu_specialize_log", "lol_gpu_specialize_wait", "lol_gpu_specialize_state", "lol_gpu_multi_specialize_wait", "lol_gpu_compile_offline", "lol_gpu_verify_fast_paths", "lol_gpu_verify_smin_no_fixup", "lol_gpu_set_miss_skip",
     "lol_gpu_miss_skip_active", "lol_gpu_set_exact_skips", "lol_gpu_powf_batch", "lol_gpu_device", "lol_gpu_sdf_batch", "lol_gpu_set_cull", "lol_gpu_set_tile_order", "lol_gpu_tile_order", "lol_gpu_cull_bounds", "lol_gpu_cull_bounds_clusters",
     "lol_gpu_render_host_begin", "lol_gpu_render_host_end", "lol_gpu_render_host_pending",
     "lol_gpu_multi_create", "lol_gpu_multi_destroy", "lol_gpu_multi_error", "lol_gpu_multi_device_count",
@@ -315,14 +321,29 @@ class Renderer:
             raise GpuError(st, self._lib.lol_gpu_error(self._ctx).decode())
 
     # render_prepare (renderer.h:25): flatten + upload the scene
-    def prepare(self, scene: S.Scene):
+    def prepare(self, scene: S.Scene, wait: bool = True):
+        """wait=True (tests, benchmarks): also wait for the scene's own kernel, so that the frames that follow all run it.
+        wait=False is what the C host does: return as soon as the interpreter can render (tiered start-up, lol_gpu.h)."""
         self.scene = scene
         self.program = scene.flatten()
         self._check(self._lib.lol_gpu_upload_program(self._ctx, C.byref(self.program)))
+        if wait:
+            self.specialize_wait()
 
-    def upload_program(self, program: S.Program):
+    def upload_program(self, program: S.Program, wait: bool = True):
         self.program = program
         self._check(self._lib.lol_gpu_upload_program(self._ctx, C.byref(program)))
+        if wait:
+            self.specialize_wait()
+
+    def specialize_wait(self):
+        self._check(self._lib.lol_gpu_specialize_wait(self._ctx))
+
+    def specialize_state(self):
+        """(state, compile_ms): 0 none, 1 compiling, 3 compiled (takes over at the next frame), 2 in use, -1 failed."""
+        ms = C.c_double()
+        st = self._lib.lol_gpu_specialize_state(self._ctx, C.byref(ms))
+        return st, ms.value
 
     def render_into(self, dst_ptr: int, w: int, h: int, max_steps: int = 256, camera: S.Camera | None = None,
                     rows: Rows | None = None, pitch_bytes: int | None = None, debug: Debug | None = None,
@@ -470,10 +491,12 @@ class MultiRenderer:
         if st != LOL_GPU_OK:
             raise GpuError(st, self._lib.lol_gpu_multi_error(self._m).decode())
 
-    def prepare(self, scene: S.Scene):
+    def prepare(self, scene: S.Scene, wait: bool = True):
         self.scene = scene
         self.program = scene.flatten()
         self._check(self._lib.lol_gpu_multi_upload_program(self._m, C.byref(self.program)))
+        if wait:
+            self._check(self._lib.lol_gpu_multi_specialize_wait(self._m))
 
     def set_band_rows(self, band_rows: int):
         self._check(self._lib.lol_gpu_multi_set_band_rows(self._m, band_rows))

@@ -14,10 +14,11 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 
-LOL_MAX_OPS = 1024
-LOL_MAX_LIGHTS = 64
-LOL_MAX_MATERIALS = 256
-LOL_MAX_STACK = 12
+# sanity caps of include/lol_scene.h (a program is as large as its scene; counts beyond these are taken for corruption)
+LOL_MAX_OPS = 1 << 20
+LOL_MAX_LIGHTS = 1 << 16
+LOL_MAX_MATERIALS = 1 << 20
+LOL_MAX_STACK = 64
 
 (LOL_OK, LOL_ERR_IO, LOL_ERR_SYNTAX, LOL_ERR_PROPERTY, LOL_ERR_TYPE, LOL_ERR_COMPONENT,
  LOL_ERR_MATERIAL, LOL_ERR_NOMEM, LOL_ERR_UNSUPPORTED) = range(9)
@@ -63,11 +64,31 @@ class Op(C.Structure):
 
 
 class Program(C.Structure):
+    """lol_program: counts + pointers to the four tables (allocated by lol_scene_flatten, released with the object)."""
     _fields_ = [("n_ops", C.c_uint32), ("n_lights", C.c_uint32), ("n_materials", C.c_uint32),
                 ("n_roots", C.c_uint32), ("max_stack", C.c_uint32), ("ambient_color", V3),
-                ("ops", Op * LOL_MAX_OPS), ("lights", Light * LOL_MAX_LIGHTS),
-                ("materials", Material * LOL_MAX_MATERIALS),
-                ("root_material", C.c_uint32 * LOL_MAX_OPS)]
+                ("ops", C.POINTER(Op)), ("lights", C.POINTER(Light)),
+                ("materials", C.POINTER(Material)), ("root_material", C.POINTER(C.c_uint32))]
+
+    def tables(self) -> bytes:
+        """Everything the program says, as bytes (two programs are the same scene iff these are equal)."""
+        head = bytes(memoryview(self).cast("B")[:C.sizeof(C.c_uint32) * 5 + C.sizeof(V3)])
+        parts = [head]
+        for ptr, n, t in ((self.ops, self.n_ops, Op), (self.lights, self.n_lights, Light),
+                          (self.materials, self.n_materials, Material), (self.root_material, self.n_roots, C.c_uint32)):
+            parts.append(C.string_at(ptr, n * C.sizeof(t)) if n else b"")
+        return b"".join(parts)
+
+    def free(self):
+        if getattr(self, "_owned", False):
+            self._owned = False
+            host_lib().lol_program_free(C.byref(self))
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class FrameCamera(C.Structure):
@@ -106,6 +127,8 @@ def host_lib() -> C.CDLL:
         lib.lol_scene_validate_materials.restype = C.c_int
         lib.lol_scene_flatten.argtypes = [P(SceneStruct), P(Program)]
         lib.lol_scene_flatten.restype = C.c_int
+        lib.lol_program_free.argtypes = [P(Program)]
+        lib.lol_program_free.restype = None
         lib.lol_frame_camera_init.argtypes = [P(FrameCamera), P(Camera), C.c_int, C.c_int]
         lib.lol_frame_camera_init.restype = None
         lib.lol_status_str.argtypes = [C.c_int]
@@ -161,6 +184,7 @@ class Scene:
         st = host_lib().lol_scene_flatten(self._ptr, C.byref(prog))
         if st != LOL_OK:
             raise SceneError(st, host_lib().lol_status_str(st).decode())
+        prog._owned = True                  # its tables belong to this object (lol_program_free when it goes)
         return prog
 
     def frame_camera(self, w: int, h: int, camera: Camera | None = None) -> FrameCamera:

@@ -191,7 +191,7 @@ static v3 get_light(const lol_scene* sc, v3 cam_pos, v3 p, v3 n, uint32_t obj_id
 		const lol_light* light = &sc->lights[li];
 		uint64_t before = t->shadow_steps, settled_before = t->settled_steps;
 		float shadow = in_shadow(sc, light, p, t);
-		if (probe && li < LOL_MAX_LIGHTS) {
+		if (probe && li < LOL_ORACLE_PROBE_LIGHTS) {
 			probe->shadow[li] = shadow;
 			probe->shadow_steps[li] = (uint32_t)(t->shadow_steps - before);
 		}

@@ -54,15 +54,17 @@ typedef struct lol_oracle_pixel_format {
 } lol_oracle_pixel_format;
 void lol_oracle_set_pixel_format(const lol_oracle_pixel_format* f);
 
-/* Per-pixel probe of the intermediate values (for debugging parity failures). */
+/* Per-pixel probe of the intermediate values (for debugging parity failures).  The per-light fields hold the first
+ * LOL_ORACLE_PROBE_LIGHTS lights of the scene (a scene may have any number: lol_scene.h). */
+#define LOL_ORACLE_PROBE_LIGHTS 64
 typedef struct lol_oracle_probe {
 	float    rd[3];
 	float    hit_dist;
 	uint32_t hit_id;
 	uint32_t march_steps;
 	float    normal[3];
-	float    shadow[LOL_MAX_LIGHTS];
-	uint32_t shadow_steps[LOL_MAX_LIGHTS];
+	float    shadow[LOL_ORACLE_PROBE_LIGHTS];
+	uint32_t shadow_steps[LOL_ORACLE_PROBE_LIGHTS];
 	float    rgb_linear[3];    /* get_light() result, before gamma */
 	float    rgb[3];           /* after gamma */
 	uint32_t xrgb;

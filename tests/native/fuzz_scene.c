@@ -77,6 +77,17 @@ int main(int argc, char** argv) {
 				flattened++;
 				lol_frame_camera fc;
 				lol_frame_camera_init(&fc, &sc->camera, 64, 36);
+				/* every table is as long as its count says (ASan sees an overrun) */
+				uint32_t touch = 0;
+				for (uint32_t k = 0; k < prog->n_ops; k++) touch += prog->ops[k].op;
+				for (uint32_t k = 0; k < prog->n_roots; k++) touch += prog->root_material[k];
+				if (prog->n_lights) touch += (uint32_t)prog->lights[prog->n_lights - 1].point.x;
+				touch += (uint32_t)prog->materials[prog->n_materials - 1].shininess;
+				(void)touch;
+				lol_program_free(prog);
+			} else if (prog->ops || prog->lights || prog->materials || prog->root_material) {
+				fprintf(stderr, "a failed flatten left tables behind\n");
+				return 1;
 			}
 			lol_scene_free(sc);
 		} else if (sc) {

@@ -18,10 +18,13 @@ class Counters(C.Structure):
                 ("settle_violations", C.c_uint64)]
 
 
+PROBE_LIGHTS = 64          # LOL_ORACLE_PROBE_LIGHTS (oracle/lol_oracle.h)
+
+
 class Probe(C.Structure):
     _fields_ = [("rd", C.c_float * 3), ("hit_dist", C.c_float), ("hit_id", C.c_uint32),
                 ("march_steps", C.c_uint32), ("normal", C.c_float * 3),
-                ("shadow", C.c_float * S.LOL_MAX_LIGHTS), ("shadow_steps", C.c_uint32 * S.LOL_MAX_LIGHTS),
+                ("shadow", C.c_float * PROBE_LIGHTS), ("shadow_steps", C.c_uint32 * PROBE_LIGHTS),
                 ("rgb_linear", C.c_float * 3), ("rgb", C.c_float * 3), ("xrgb", C.c_uint32)]
 
 

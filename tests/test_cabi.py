@@ -55,8 +55,13 @@ def test_struct_sizes_match_the_headers():
     # the Python mirrors must match the C layouts (lol_op is 10 dwords, see lol_scene.h)
     assert C.sizeof(S.Op) == 40 and C.sizeof(S.Light) == 36 and C.sizeof(S.Material) == 40
     assert C.sizeof(S.Node) == 48 and C.sizeof(S.FrameCamera) == 56
-    assert (S.LOL_MAX_OPS, S.LOL_MAX_LIGHTS, S.LOL_MAX_MATERIALS, S.LOL_MAX_STACK) == (1024, 64, 256, 12)
-    assert C.sizeof(S.Program) == 5 * 4 + 12 + 40 * S.LOL_MAX_OPS + 36 * S.LOL_MAX_LIGHTS + 40 * S.LOL_MAX_MATERIALS + 4 * S.LOL_MAX_OPS
+    # a program is counts + four pointers (no capacity: include/lol_scene.h); the caps are sanity bounds only
+    hdr = open(os.path.join(ROOT, "include", "lol_scene.h")).read()
+    caps = {k: eval(v.replace("u", "")) for k, v in re.findall(r"#define\s+(LOL_MAX_[A-Z]+)\s+(\(?[0-9u <]+\)?)", hdr)}
+    assert caps == {"LOL_MAX_OPS": S.LOL_MAX_OPS, "LOL_MAX_LIGHTS": S.LOL_MAX_LIGHTS, "LOL_MAX_MATERIALS": S.LOL_MAX_MATERIALS,
+                    "LOL_MAX_STACK": S.LOL_MAX_STACK}
+    assert min(S.LOL_MAX_OPS, S.LOL_MAX_LIGHTS, S.LOL_MAX_MATERIALS) >= 1 << 16
+    assert C.sizeof(S.Program) == 5 * 4 + 12 + 4 * C.sizeof(C.c_void_p)
 
 
 def test_part_rows_is_pure_host_logic():
@@ -144,3 +149,18 @@ def test_code_objects_are_cached_on_disk(tmp_path, scenes):
     p = subprocess.run([sys.executable, "-c", code], env=env_flags, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "disk cache" not in p.stdout
     assert "disk cache" not in run("")                            # switched off: compiles, writes nothing
+
+
+def test_small_scenes_keep_their_tables_in_lds_and_large_ones_do_not(tmp_path):
+    """lights | materials | root_material are staged into LDS per one-wave block while they fit 4 KB (lol_kernel.h,
+    TABLES_LDS_MAX_DWORDS) — a field of 250 objects does, as before — and are read from global memory beyond: the generated
+    kernel says which (the choice is a compile-time constant of the scene's kernel)."""
+    def field(n):
+        objs = ", ".join("sphere { material = #1, point = (%d, 0, -5), radius = 1 }" % i for i in range(n))
+        return S.Scene.parse_string("materials { { shininess = 1 }, { shininess = 2 } } scene { point_light { point = (0,9,0) }, %s }" % objs)
+    for n, want in ((250, "false"), (994, "false"), (996, "true"), (3000, "true")):
+        base = str(tmp_path / ("f%d" % n))
+        gpu.compile_offline(field(n).flatten(), base)
+        src = open(base + ".hip").read()
+        assert ("shade_pixel<lol::SpecSdfExact, %s>" % want) in src and ("store_pixel<%s>" % want) in src, n
+        assert ("stage_common" in src) == (want == "false")

@@ -284,7 +284,7 @@ def test_rejected_upload_leaves_the_previous_scene_rendering(torch_cuda, scenes,
         elif breaker == "material":
             bad.root_material[0] = 9999
         else:
-            bad.n_ops = S.LOL_MAX_OPS + 1
+            bad.n_ops = S.LOL_MAX_OPS + 1              # beyond the sanity cap: taken for corruption (the table is not read)
         with pytest.raises(gpu.GpuError):
             r._check(r._lib.lol_gpu_upload_program(r._ctx, C.byref(bad)))
         assert np.array_equal(frame(), want_a), breaker
@@ -354,3 +354,116 @@ def test_roctx_ranges_mark_every_frame_when_asked_for():
                            text=True, timeout=180)
         assert p.returncode == 0, p.stderr[-2000:]
         assert f"ranges 0 {want} 1" in p.stdout, (p.stdout, p.stderr[-500:])
+
+
+def _union_tree_scene(depth, seed=11):
+    """one object: a balanced smooth-union tree of 2^depth spheres (2^(depth+1) ops) — seconds of hipRTC"""
+    rng = np.random.default_rng(seed)
+
+    def tree(d):
+        if d == 0:
+            return "sphere { point = (%.3f, %.3f, %.3f), radius = %.3f }" % (*(rng.normal(size=3) * [4, 2, 3] + [0, 0, -9]), rng.uniform(0.2, 0.8))
+        return "smooth_union { smoothness = 0.5, a = %s, b = %s }" % (tree(d - 1), tree(d - 1))
+    return S.Scene.parse_string(
+        "materials { { shininess = 2, diffuse = (0,0,0), specular = (0,0,0), ambient = (.02,.02,.02) },"
+        " { shininess = 8, diffuse = (.5,.5,.5), specular = (.2,.2,.2), ambient = (.1,.1,.1) } }\n"
+        "scene { camera { point = (0, 1, 4), direction = (0, -0.1, -1), fov = 100 },"
+        " point_light { point = (0,9,0), diffuse_intensity = (2,2,2), specular_intensity = (2,2,2) }, "
+        + tree(depth).replace("{", "{ material = #1,", 1) + " }")
+
+
+@pytest.mark.gpu
+def test_tiered_start_up(torch_cuda, scenes, monkeypatch, tmp_path):
+    """render_prepare returns at once (naive_renderer.c:242-244; the JIT's takes milliseconds, tracing_jit_renderer.dasc:416-434):
+    lol_gpu_upload_program commits the tables and comes back while hipRTC compiles the scene's kernel on a host thread; frames
+    render on the interpreter meanwhile and the first frame after the compiler has finished runs the scene's kernel — the
+    same frame, bit for bit.  A 1024-op scene (seconds of hipRTC) with the code-object caches out of the way."""
+    import time
+    torch = torch_cuda
+    monkeypatch.setenv("LOL_GPU_CACHE_DIR", "")                  # no disk cache: the compiler really runs
+    sc = _union_tree_scene(9, seed=int(time.time()) % 100000)      # (a scene no earlier test of this process has compiled)
+    assert sc.flatten().n_ops == 1024
+    w, h = 96, 54
+    want, _, _ = O.render(sc, w, h, threads=4)
+    r = gpu.Renderer(0)
+    t0 = time.perf_counter()
+    r.prepare(sc, wait=False)
+    prepare_ms = (time.perf_counter() - t0) * 1e3
+    state, _ = r.specialize_state()
+    assert state == 1 and r.kernel_name() == "render_interp"      # compiling; the interpreter is what renders now
+    assert prepare_ms < 250, prepare_ms                            # (50 ms is the aim, measured in profiles/r4_startup.json; this bound only catches a blocking compile)
+    buf = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    frames_on_interp = 0
+    last = None
+    deadline = time.perf_counter() + 120
+    while r.kernel_name() == "render_interp" and time.perf_counter() < deadline:
+        buf.zero_()
+        r.render_into(buf.data_ptr(), w, h)
+        r.sync()
+        if r.kernel_name() == "render_interp":
+            frames_on_interp += 1
+        last = buf.cpu().numpy().view(np.uint32).copy()
+        assert np.array_equal(last, want)
+    assert frames_on_interp >= 1, "the compiler finished before a single frame could be rendered?"
+    assert r.kernel_name() == "lol_render_spec" and r.specialize_state()[0] == 2 and r.specialize_state()[1] > 100
+    # `last` was the first frame of the scene's own kernel; the frame before it came from the interpreter: identical (checked above)
+    buf.zero_()
+    r.render_into(buf.data_ptr(), w, h)
+    r.sync()
+    assert np.array_equal(buf.cpu().numpy().view(np.uint32), want)
+    # a second context, same scene: the code object is in the process's cache, the compiler's thread is done at once
+    r2 = gpu.Renderer(0)
+    t0 = time.perf_counter()
+    r2.prepare(sc, wait=False)
+    r2.specialize_wait()
+    assert (time.perf_counter() - t0) < 1.0 and r2.kernel_name() == "lol_render_spec"
+    r2.close()
+    r.close()
+
+
+@pytest.mark.gpu
+def test_uploads_while_the_scene_compiler_runs(torch_cuda, scenes, monkeypatch):
+    """A scene uploaded while the previous one is still being compiled replaces it — its frames at once (interpreter), its own
+    kernel later; the abandoned run's result is never used.  A REFUSED upload during a compile leaves scene and compile alone.
+    Destroying a context with the compiler at work waits for the thread instead of leaving it behind."""
+    import time
+    torch = torch_cuda
+    monkeypatch.setenv("LOL_GPU_CACHE_DIR", "")
+    big = _union_tree_scene(9, seed=int(time.time()) % 100000 + 7)
+    small = scenes["scene4"]
+    w, h = 64, 36
+    want_big, _, _ = O.render(big, w, h, threads=4)
+    want_small, _, _ = O.render(small, w, h, threads=4)
+    r = gpu.Renderer(0)
+    buf = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+
+    def frame(cam):
+        buf.zero_()
+        r.render_into(buf.data_ptr(), w, h, camera=cam)
+        r.sync()
+        return buf.cpu().numpy().view(np.uint32)
+    r.prepare(big, wait=False)
+    assert r.specialize_state()[0] == 1
+    assert np.array_equal(frame(big.c.camera), want_big)
+    # refused upload (malformed) while compiling: nothing changes
+    bad = small.flatten()
+    bad.root_material[0] = 9999
+    with pytest.raises(gpu.GpuError):
+        r._check(r._lib.lol_gpu_upload_program(r._ctx, C.byref(bad)))
+    assert r.specialize_state()[0] in (1, 3) and np.array_equal(frame(big.c.camera), want_big)
+    # a good upload replaces the scene; the run for `big` is abandoned
+    r.prepare(small, wait=False)
+    assert np.array_equal(frame(small.c.camera), want_small)
+    r.specialize_wait()
+    assert r.kernel_name() == "lol_render_spec" and np.array_equal(frame(small.c.camera), want_small)
+    key_small = r.kernel_key()
+    rs = gpu.Renderer(0)
+    rs.prepare(small)
+    assert rs.kernel_key() == key_small                        # the kernel in use is scene4's, not the abandoned tree's
+    rs.close()
+    # close with a compile in flight
+    r.prepare(_union_tree_scene(9, seed=int(time.time()) % 100000 + 13), wait=False)
+    assert r.specialize_state()[0] == 1
+    t0 = time.perf_counter()
+    r.close()
+    assert time.perf_counter() - t0 < 60

@@ -218,7 +218,7 @@ def test_deep_tree_needs_the_big_operand_stack(torch_cuda):
             + tree(9).replace("{", "{ material = #1,", 1) + " }")
     sc = S.Scene.parse_string(text)
     prog = sc.flatten()
-    assert prog.n_ops == S.LOL_MAX_OPS and prog.max_stack == 10
+    assert prog.n_ops == 1024 and prog.max_stack == 10
     for mode, name in ((4, "render_interp"), (1, "lol_render_spec")):
         r = gpu.Renderer(0, specialize=mode)
         r.prepare(sc)
@@ -226,3 +226,84 @@ def test_deep_tree_needs_the_big_operand_stack(torch_cuda):
         g = gpu_render(torch_cuda, r, sc, 32, 20)
         check_against_oracle(g, sc, 32, 20)
         r.close()
+
+
+def big_field_scene(n_obj, n_mat, n_light, seed=5):
+    """A field of n_obj separate objects (a tenth of them small unions) over a plane, n_mat materials, n_light lights."""
+    rng = np.random.default_rng(seed)
+    mats = ["{ shininess = 2, diffuse = (0,0,0), specular = (0,0,0), ambient = (.02,.02,.03) }"]
+    for i in range(1, n_mat):
+        mats.append("{ shininess = %s, diffuse = %s, specular = %s, ambient = %s }" % (
+            num(rng.choice([1, 2, 8, 30.5])), fmt(rng.uniform(0.1, 0.6, 3)), fmt(rng.uniform(0, 0.4, 3)), fmt(rng.uniform(0, 0.3, 3))))
+    comps = ["ambient { color = (.1,.1,.1) }", "camera { point = (0, 4, 6), direction = (0, -0.35, -1), fov = 110 }"]
+    for i in range(n_light):
+        comps.append("point_light { point = %s, diffuse_intensity = %s, specular_intensity = %s }" % (
+            fmt(rng.normal(size=3) * [12, 1, 12] + [0, 10, -10]), fmt(rng.uniform(0.02, 0.08, 3)), fmt(rng.uniform(0, 0.05, 3))))
+    comps.append("plane { material = #1, y = -1 }")
+    for i in range(n_obj - 1):
+        c = rng.uniform([-20, -0.5, -30], [20, 2, 2])
+        m = int(rng.integers(1, n_mat)) if i % 3 else (n_mat - 1 - i % 7)          # the last materials of the table are used too
+        if i % 10 == 0:
+            comps.append("smooth_union { material = #%d, smoothness = 0.5, a = sphere { point = %s, radius = %s }, b = box { point = %s, point2 = (.3,.4,.3), radius = .1 } }"
+                         % (m, fmt(c), num(rng.uniform(0.2, 0.6)), fmt(c + [0.4, 0.2, 0])))
+        else:
+            comps.append("sphere { material = #%d, point = %s, radius = %s }" % (m, fmt(c), num(rng.uniform(0.15, 0.7))))
+    return "materials { %s }\nscene { %s }\n" % (",\n".join(mats), ",\n".join(comps))
+
+
+@pytest.mark.parametrize("mode,name", [(4, "render_interp"), (0, "render_interp"), (1, "lol_render_spec")], ids=["interp", "interp-plain", "spec"])
+def test_scene_beyond_the_old_capacity(torch_cuda, mode, name):
+    """2300 objects / 5000+ ops, 300 materials, 100 lights — rounds 1-3 refused it (1024 ops, 256 materials, 64 lights).  The
+    tables (100 x 9 + 300 x 10 + 2300 dwords) no longer fit a one-wave block's LDS share and are read from global memory
+    (lol_kernel.h, TABLES_GLOBAL): every pixel, id, distance and step count equals the oracle's on both kernels."""
+    sc = S.Scene.parse_string(big_field_scene(2300, 300, 100))
+    prog = sc.flatten()
+    assert prog.n_ops >= 5000 and prog.n_materials == 300 and prog.n_lights == 100 and prog.n_roots == 2300
+    r = gpu.Renderer(0, specialize=mode)
+    r.prepare(sc)
+    assert r.kernel_name() == name, r.specialize_log()
+    w, h = 16, 8
+    g = gpu_render(torch_cuda, r, sc, w, h)
+    check_against_oracle(g, sc, w, h)
+    assert len(np.unique(g["id"])) > 3                            # the frame really shows several objects
+    r.close()
+
+
+def test_operand_stack_deeper_than_the_slot_fields(torch_cuda):
+    """A balanced smooth-union tree of 4096 spheres in ONE object: operand stack 13 — one more than the interpreter's register
+    stacks hold; the deep instantiation (slots in words of their own, lol_kernel.h MOP_DEEP_FROM) renders it like the oracle, and
+    so does the specialised kernel, whose straight-line SDF needs no stack at all."""
+    rng = np.random.default_rng(3)
+
+    def tree(d):
+        if d == 0:
+            return "sphere { point = %s, radius = %s }" % (fmt(rng.normal(size=3) * [5, 2, 4] + [0, 0, -10]), num(rng.uniform(0.1, 0.5)))
+        return "smooth_union { smoothness = 0.25, a = %s, b = %s }" % (tree(d - 1), tree(d - 1))
+    text = ("materials { { shininess = 2, diffuse = (0,0,0), specular = (0,0,0), ambient = (.02,.02,.02) },"
+            " { shininess = 8, diffuse = (.5,.5,.5), specular = (.2,.2,.2), ambient = (.1,.1,.1) } }\n"
+            "scene { camera { point = (0, 1, 4), direction = (0, -0.1, -1), fov = 100 },"
+            " point_light { point = (0,9,0), diffuse_intensity = (2,2,2), specular_intensity = (2,2,2) }, "
+            + tree(12).replace("{", "{ material = #1,", 1) + " }")
+    sc = S.Scene.parse_string(text)
+    prog = sc.flatten()
+    assert prog.n_ops == 8192 and prog.max_stack == 13
+    for mode, name in ((4, "render_interp"), (0, "render_interp"), (1, "lol_render_spec")):
+        r = gpu.Renderer(0, specialize=mode)
+        r.prepare(sc)
+        assert r.kernel_name() == name, r.specialize_log()
+        g = gpu_render(torch_cuda, r, sc, 16, 8)
+        check_against_oracle(g, sc, 16, 8)
+        r.close()
+
+
+def test_very_large_scenes_stay_on_the_interpreter(torch_cuda, monkeypatch):
+    """Above LOL_GPU_SPEC_MAX_OPS the scene compiler does not take a program on (minutes of hipRTC): it renders on the
+    interpreter, quietly, with the reason in the log."""
+    monkeypatch.setenv("LOL_GPU_SPEC_MAX_OPS", "100")
+    sc = S.Scene.parse_string(big_field_scene(120, 3, 1))
+    r = gpu.Renderer(0)
+    r.prepare(sc)
+    assert r.kernel_name() == "render_interp" and "LOL_GPU_SPEC_MAX_OPS" in r.specialize_log()
+    g = gpu_render(torch_cuda, r, sc, 32, 16)
+    check_against_oracle(g, sc, 32, 16)
+    r.close()
