@@ -1203,6 +1203,18 @@ void disk_cache_store(const std::string& key, const std::vector<char>& code) {
 	if (fclose(f) != 0 || !ok || rename(t.c_str(), path.c_str()) != 0) (void)remove(t.c_str());
 }
 
+/* The long-branch bug described in compile_spec, as it looks in the code: s_getpc_b64 s[30:31]; s_add_u32 s30, s30, <lit>;
+ * s_addc_u32 s31, s31, <lit>; s_setpc_b64 s[30:31] — a relaxed branch that goes through the register pair a function returns
+ * through.  (A call is s_getpc into some pair + s_swappc_b64 s[30:31], <pair>; a return is a bare s_setpc_b64 s[30:31].) */
+bool has_return_clobbering_branch(const std::vector<char>& code) {
+	const size_t n = code.size() / 4;
+	const uint32_t* w = reinterpret_cast<const uint32_t*>(code.data());
+	if (reinterpret_cast<uintptr_t>(code.data()) % 4) return false;      /* (std::vector<char> storage is suitably aligned) */
+	for (size_t i = 0; i + 6 <= n; i++)
+		if (w[i] == 0xBE9E1C00u && w[i + 1] == 0x801EFF1Eu && w[i + 3] == 0x821FFF1Fu && w[i + 5] == 0xBE801D1Eu) return true;
+	return false;
+}
+
 bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string& arch, std::vector<char>& code,
                   std::string& log, std::string* src_out = nullptr, const int* shape = nullptr, bool cull = true) {
 	std::string src = generate_source(P, fast, cull);
@@ -1244,6 +1256,16 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
 		 * `if (alive) { ... }` updates around the SDF become straight-line code for the ILP scheduler.  Sweep of 3 ... 64 on one
 		 * box (tools/rtc_flag_sweep.sh phi): from 4 upwards C2 +1.5 ... 2.5 %, C3 +0.2 %, the large scenes +-3 %; same bits. */
 		opts.push_back("-mllvm"); opts.push_back("-phi-node-folding-threshold=8");
+		/* ... and NO register reserved ahead of time for long branches.  An out-of-line SDF function of more than 128 KB (about
+		 * 800 ops: a field of 600 objects) has forward branches beyond s_cbranch's 16-bit reach; LLVM's AMDGPU backend then
+		 * reserves "an unused" SGPR pair for the s_getpc / s_add / s_setpc sequence before register allocation — and in a leaf
+		 * function picks s[30:31], the RETURN ADDRESS: the function jumps, and at its end "returns" to the branch target for
+		 * ever (found in round 4 when scenes lost their 1024-op capacity: the kernel never finished; ROCm 7.0 and 7.2 alike).
+		 * With the factor 0 no register is reserved and the branch relaxation scavenges a dead one at the branch, correctly.
+		 * has_return_clobbering_branch() below refuses any code object that still shows the pattern. */
+		/* (LOL_GPU_LONG_BRANCH_REG=1 leaves LLVM's default in place: for the test that sees the tripwire refuse the result) */
+		const char* lbr = getenv("LOL_GPU_LONG_BRANCH_REG");
+		if (!(lbr && lbr[0] == '1')) { opts.push_back("-mllvm"); opts.push_back("-amdgpu-long-branch-factor=0"); }
 	}
 	char d0[32], d1[32], d2[32];
 	if (shape) {
@@ -1297,7 +1319,7 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
 		for (size_t i = 0; i < opts.size(); i++) {
 			if (!strcmp(opts[i], "-mllvm") && i + 1 < opts.size() &&
 			    (!strcmp(opts[i + 1], "-amdgpu-sched-strategy=max-ilp") || !strcmp(opts[i + 1], "-enable-post-misched=0") ||
-			     !strcmp(opts[i + 1], "-phi-node-folding-threshold=8"))) { i++; continue; }
+			     !strcmp(opts[i + 1], "-phi-node-folding-threshold=8") || !strcmp(opts[i + 1], "-amdgpu-long-branch-factor=0"))) { i++; continue; }
 			plain.push_back(opts[i]);
 		}
 		if (plain.size() != opts.size()) {
@@ -1327,6 +1349,13 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
 	code.resize(code_size);
 	hiprtcGetCode(prog, code.data());
 	hiprtcDestroyProgram(&prog);
+	if (has_return_clobbering_branch(code)) {
+		/* a kernel that would never finish is worse than no kernel: the interpreter renders this scene */
+		log = "the compiler relaxed a long branch through s[30:31], the return address of a function (LLVM AMDGPU long-branch "
+		      "register bug; see compile_spec): code object refused";
+		code.clear();
+		return false;
+	}
 	{
 		std::lock_guard<std::mutex> lock(g_cache_mutex);
 		g_code_cache[key] = code;

@@ -3,6 +3,8 @@ import ctypes as C
 import os
 import re
 
+import numpy as np
+
 from loltracer_amd import gpu, scene as S
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -164,3 +166,27 @@ def test_small_scenes_keep_their_tables_in_lds_and_large_ones_do_not(tmp_path):
         src = open(base + ".hip").read()
         assert ("shade_pixel<lol::SpecSdfExact, %s>" % want) in src and ("store_pixel<%s>" % want) in src, n
         assert ("stage_common" in src) == (want == "false")
+
+
+def test_out_of_line_sdf_beyond_the_short_branch_range_is_compiled_correctly_or_refused(tmp_path, monkeypatch):
+    """An out-of-line SDF function of more than 128 KB (a field of 600 objects: 211 KB) needs branches beyond s_cbranch's
+    reach.  LLVM's AMDGPU backend (ROCm 7.0 and 7.2) then reserves a register pair for them ahead of time and, in a leaf
+    function, takes s[30:31] — the return address: the function never returns (found in round 4, once scenes could exceed
+    1024 ops: the kernel ran for ever).  compile_spec passes -amdgpu-long-branch-factor=0 (no reservation: a dead pair is
+    scavenged at the branch) and refuses any code object that still relaxes a branch through s[30:31]."""
+    objs = ", ".join("sphere { material = #1, point = (%d, %d, -5), radius = 0.4 }" % (i % 40, i // 40) for i in range(600))
+    sc = S.Scene.parse_string("materials { { shininess = 1 }, { shininess = 2 } } scene { point_light { point = (0,9,0) }, plane { material = #0, y = -1 }, %s }" % objs)
+    monkeypatch.setenv("LOL_GPU_CACHE_DIR", "")
+    base = str(tmp_path / "ok")
+    gpu.compile_offline(sc.flatten(), base, assume_fast=True)
+    code = open(base + ".co", "rb").read()
+    words = np.frombuffer(code[: len(code) // 4 * 4], dtype="<u4")
+    getpc_ra = np.flatnonzero(words == 0xBE9E1C00)                 # s_getpc_b64 s[30:31]
+    assert not any(words[i + 1] == 0x801EFF1E and words[i + 5] == 0xBE801D1E for i in getpc_ra if i + 5 < len(words))
+    assert len(code) > 300_000                                     # the function really is beyond the short-branch range
+    # with LLVM's own default the pattern appears — and the library refuses the code object instead of handing out a hang
+    monkeypatch.setenv("LOL_GPU_LONG_BRANCH_REG", "1")
+    import pytest
+    with pytest.raises(gpu.GpuError) as e:
+        gpu.compile_offline(sc.flatten(), str(tmp_path / "bad"), assume_fast=True)
+    assert "return address" in str(e.value)

@@ -263,9 +263,20 @@ def test_scene_beyond_the_old_capacity(torch_cuda, mode, name):
     r.prepare(sc)
     assert r.kernel_name() == name, r.specialize_log()
     w, h = 16, 8
+    # (the checker accounts the exact skips light by light for the first four lights only: first with every shadow ray marched
+    # to the reference's own end — all step counts against the oracle — then the production configuration against that frame)
+    r.set_exact_skips(0)
     g = gpu_render(torch_cuda, r, sc, w, h)
     check_against_oracle(g, sc, w, h)
     assert len(np.unique(g["id"])) > 3                            # the frame really shows several objects
+    r.set_exact_skips(7)
+    g2 = gpu_render(torch_cuda, r, sc, w, h)
+    assert g2["miss_skip"] != 0
+    for k in ("xrgb", "id"):
+        assert np.array_equal(g[k], g2[k]), k
+    assert np.array_equal(g["rgb"].view(np.uint32), g2["rgb"].view(np.uint32)) and np.array_equal(g["dist"].view(np.uint32), g2["dist"].view(np.uint32))
+    assert np.array_equal(g["steps"] & 0xFFFF, g2["steps"] & 0xFFFF) and ((g2["steps"] >> 16) <= (g["steps"] >> 16)).all()
+    assert ((g2["steps"] >> 16) < (g["steps"] >> 16)).any()
     r.close()
 
 
