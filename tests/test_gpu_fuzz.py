@@ -311,7 +311,7 @@ def test_very_large_scenes_stay_on_the_interpreter(torch_cuda, monkeypatch):
     """Above LOL_GPU_SPEC_MAX_OPS the scene compiler does not take a program on (minutes of hipRTC): it renders on the
     interpreter, quietly, with the reason in the log."""
     monkeypatch.setenv("LOL_GPU_SPEC_MAX_OPS", "100")
-    sc = S.Scene.parse_string(big_field_scene(120, 3, 1))
+    sc = S.Scene.parse_string(big_field_scene(120, 9, 1))
     r = gpu.Renderer(0)
     r.prepare(sc)
     assert r.kernel_name() == "render_interp" and "LOL_GPU_SPEC_MAX_OPS" in r.specialize_log()
