@@ -164,6 +164,8 @@ struct lol_gpu {
 	int          interp_sqrt_kind = 0;   /* fast sqrt of the interpreter: 3 (sqrt_r2) when proven and allowed, else 0 */
 	int          sqrt_verified = -1;     /* -1 not run, 0 none proven, else the lol::sqrt_fast KIND proven on this device */
 	bool         sqrt_tiny_ok = false;   /* the second counter of that run was 0 too (sd_sphere_fast_nr) */
+	int          fdiv_verified = -1;     /* -1 not run, 1 fdiv_fast == '/' over verify_fdiv_kernel's sweep on this device, 0 not */
+	bool         shadow_fdiv = false;    /* the kernels in use were built with it (FastPaths::fdiv_ok at the last upload) */
 	struct DivProof { uint32_t k_bits; bool ok, no_fixup_ok; };
 	std::vector<DivProof> div_verified;  /* per smoothness constant: smin_h_fast proven / proven without v_div_fixup too */
 	unsigned long long* d_bad = nullptr; /* mismatch counter of the verification kernels */
@@ -352,6 +354,34 @@ __global__ __launch_bounds__(VERIFY_THREADS) void verify_div_kernel(float k, flo
 	if (m) atomicAdd(bad + 1, (unsigned long long)m);
 }
 
+/* fdiv_fast(n, t) against n / t (lol_kernel.h): all 2^23 mantissas of n x 512 combinations of {exponent of n, exponent of t,
+ * mantissa of t} spread over the box soft_shadow keeps its operands in — n in [2^-60, 2^64], t in [2^-28, 2^58], corners and
+ * a margin beyond them included.  `seed` != 0 replaces the fixed divisor mantissas and moves the exponents (tests sweep a
+ * few seeds; the context runs seed 0 once).  2^32 quotients, a few ms. */
+__global__ __launch_bounds__(VERIFY_THREADS) void verify_fdiv_kernel(uint32_t seed, unsigned long long* bad) {
+	const int en_tab[8] = { -60, -37, -9, -1, 0, 7, 33, 64 }, et_tab[8] = { -28, -13, -1, 0, 1, 11, 35, 58 };
+	const uint32_t mt_tab[8] = { 0u, 1u, 0x7fffffu, 0x400000u, 0x2aaaaau, 0x555555u, 0x123456u, 0x7ffffeu };
+	uint32_t base = blockIdx.x * VERIFY_THREADS + threadIdx.x;
+	unsigned n_bad = 0;
+	for (uint32_t it = 0; it < VERIFY_ITERS; it++) {
+		const uint32_t idx = base + it * (VERIFY_BLOCKS * VERIFY_THREADS);
+		const uint32_t mn = idx & 0x7fffffu, sel = idx >> 23;
+		int en = en_tab[sel & 7u], et = et_tab[sel >> 3 & 7u];
+		uint32_t mt = mt_tab[sel >> 6 & 7u];
+		if (seed) {
+			uint32_t h = (sel + 1u) * 0x9E3779B1u ^ seed * 0x85EBCA77u;
+			h ^= h >> 15; h *= 0xC2B2AE3Du; h ^= h >> 13;
+			mt = h & 0x7fffffu;
+			en = -60 + (int)((h >> 23) % 125u);          /* [-60, 64] */
+			et = -28 + (int)((h >> 9 ^ h >> 27) % 87u);  /* [-28, 58] */
+		}
+		const float n = __builtin_bit_cast(float, (uint32_t)(en + 127) << 23 | mn);
+		const float t = __builtin_bit_cast(float, (uint32_t)(et + 127) << 23 | mt);
+		if (!same_float(lol::fdiv_fast(n, t), n / t)) n_bad++;
+	}
+	if (n_bad) atomicAdd(bad, (unsigned long long)n_bad);
+}
+
 /* diagnostic: out[i] = powf_glibc(x[i], y[i]) — lets the tests compare the device's powf with the CPU's */
 __global__ __launch_bounds__(256) void powf_batch_kernel(const float* x, const float* y, float* out, size_t n) {
 	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -364,7 +394,8 @@ unsigned long long run_verify(lol_gpu* ctx, int sqrt_kind, float k, unsigned lon
 		return ~0ull;
 	unsigned long long bad[2] = { 0, 0 };
 	if (hipMemcpy(ctx->d_bad, bad, sizeof bad, hipMemcpyHostToDevice) != hipSuccess) return ~0ull;
-	if (sqrt_kind == 3) hipLaunchKernelGGL(verify_sqrt_kernel<3>, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, ctx->d_bad);
+	if (sqrt_kind == -1) hipLaunchKernelGGL(verify_fdiv_kernel, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, __builtin_bit_cast(uint32_t, k), ctx->d_bad);
+	else if (sqrt_kind == 3) hipLaunchKernelGGL(verify_sqrt_kernel<3>, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, ctx->d_bad);
 	else if (sqrt_kind == 2) hipLaunchKernelGGL(verify_sqrt_kernel<2>, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, ctx->d_bad);
 	else if (sqrt_kind == 1) hipLaunchKernelGGL(verify_sqrt_kernel<1>, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, ctx->d_bad);
 	else hipLaunchKernelGGL(verify_div_kernel, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, k, 2.0f * k, 0.5f * (1.0f / k),
@@ -391,6 +422,7 @@ struct FastPaths {
 	bool sqrt_tiny_ok = false;            /* ... and NaN-or-tiny below its domain: spheres may drop the range tracker (sd_sphere_fast_nr) */
 	std::vector<float> div_ok;            /* smoothness constants k whose smin_h_fast verified */
 	std::vector<float> div_nf_ok;         /* ... and verified without v_div_fixup as well (smin_h_fast<false>) */
+	bool fdiv_ok = false;                 /* fdiv_fast == '/' over the sweep of verify_fdiv_kernel: the shadow march may use it */
 	bool has(float k) const {
 		for (float v : div_ok) if (memcmp(&v, &k, 4) == 0) return true;
 		return false;
@@ -812,7 +844,8 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 		         name, cool_decl);
 		s += line;
 	} else {
-		snprintf(line, sizeof line, "struct %s {\n\tstatic constexpr bool MASKS = true;\n\tRange rg;\n\tu64 nan = 0;\n%s", name, cool_decl);
+		snprintf(line, sizeof line, "struct %s {\n\tstatic constexpr bool MASKS = true;\n\tstatic constexpr bool FAST_DIV = %s;\n\tRange rg;\n\tu64 nan = 0;\n%s", name,
+		         fast && fast->fdiv_ok ? "true" : "false", cool_decl);
 		s += line;
 		s += "\t__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id, u64 care = ~0ull) {\n";
 	}
@@ -1013,9 +1046,9 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 	}
 	if (out_of_line) {
 		s += "\t\treturn { best, best_id, rg.lo, rg.hi, nan };\n}\n";
-		snprintf(line, sizeof line, "struct %s {\n\tstatic constexpr bool MASKS = true;\n\tRange rg;\n\tu64 nan = 0;\n\t__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id, u64 care = ~0ull) {\n"
+		snprintf(line, sizeof line, "struct %s {\n\tstatic constexpr bool MASKS = true;\n\tstatic constexpr bool FAST_DIV = %s;\n\tRange rg;\n\tu64 nan = 0;\n\t__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id, u64 care = ~0ull) {\n"
 		         "\t\tconst SdfOut o = %s_fn(p.x, p.y, p.z, rg.lo, rg.hi, care);\n"
-		         "\t\tbest = o.best; best_id = o.id; rg.lo = o.lo; rg.hi = o.hi; nan |= o.nan;\n\t}\n};\n", name, name);
+		         "\t\tbest = o.best; best_id = o.id; rg.lo = o.lo; rg.hi = o.hi; nan |= o.nan;\n\t}\n};\n", name, fast && fast->fdiv_ok ? "true" : "false", name);
 		s += line;
 	} else {
 		s += "\t}\n};\n";
@@ -1378,6 +1411,13 @@ FastPaths prove_fast_paths(lol_gpu* ctx, const lol_program& prog) {
 	}
 	fast.sqrt_kind = ctx->sqrt_verified;
 	fast.sqrt_tiny_ok = ctx->sqrt_tiny_ok;
+	/* The shadow march's division shortcut (lol_kernel.h, fdiv_fast) is OFF unless LOL_GPU_SHADOW_FDIV=1: exact, but it bought
+	 * C3 0.95 % in a same-call A/B (7854 vs 7779 Mpixels/s, profiles/r4_ab_fdiv.txt), below the 1.5 % the review set as the bar
+	 * for keeping it in the default kernel.  Asked for, it is still only used after this device's own sweep agrees. */
+	if (getenv("LOL_GPU_SHADOW_FDIV") && getenv("LOL_GPU_SHADOW_FDIV")[0] == '1') {
+		if (ctx->fdiv_verified < 0) ctx->fdiv_verified = run_verify(ctx, -1, 0.f) == 0 ? 1 : 0;      /* (seed 0 travels as the bits of k = 0) */
+		fast.fdiv_ok = ctx->fdiv_verified == 1;
+	}
 	for (uint32_t i = 0; i < prog.n_ops; i++) {
 		const lol_op& o = prog.ops[i];
 		if (o.op != LOL_OP_SMIN && o.op != LOL_OP_SMIN_R) continue;
@@ -1758,6 +1798,16 @@ int lol_gpu_verify_fast_paths(lol_gpu* ctx, float k, unsigned long long sqrt_mis
 	return LOL_GPU_OK;
 }
 
+/* ... and for the shadow march's division (fdiv_fast against '/', verify_fdiv_kernel): mismatches over the 2^32 quotients of
+ * the sweep `seed` selects (0 = the fixed corners the context itself checks; anything else = pseudo-random exponents and
+ * divisor mantissas inside the box) */
+int lol_gpu_verify_shadow_division(lol_gpu* ctx, uint32_t seed, unsigned long long* mismatches) {
+	if (!ctx || !mismatches) return LOL_GPU_ERR_ARG;
+	LOL_HIP(ctx, hipSetDevice(ctx->device));
+	*mismatches = run_verify(ctx, -1, __builtin_bit_cast(float, seed));
+	return LOL_GPU_OK;
+}
+
 /* ... and for the blend factor without v_div_fixup (smin_h_fast<false>): inputs on which it differs from the exact
  * factor (finite and NaN dlt) or fails to turn the smooth minimum NaN (dlt = +-inf); 0 = proven, ~0 = could not run */
 int lol_gpu_verify_smin_no_fixup(lol_gpu* ctx, float k, unsigned long long* mismatches) {
@@ -1878,9 +1928,11 @@ int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog) {
 	ctx->n_mops = n_mops;
 	ctx->finite_scene = shadow_settle_ok(*prog);
 	ctx->interp_sqrt_kind = fast.sqrt_kind == 3 ? 3 : 0;
+	ctx->shadow_fdiv = fast.fdiv_ok;
 	{
 		/* what render_interp executes = this build's code (lol_kernel.h AND this file: record layout, flags) + the lists */
-		std::string id = std::string(LOL_BUILD_ID) + "|" + fnv_hex(mops.data(), mops.size() * 4) + "|" + std::to_string(ctx->interp_sqrt_kind);
+		std::string id = std::string(LOL_BUILD_ID) + "|" + fnv_hex(mops.data(), mops.size() * 4) + "|" + std::to_string(ctx->interp_sqrt_kind) +
+		                 (ctx->shadow_fdiv ? "|fdiv" : "");
 		ctx->interp_key = fnv_hex(id.data(), id.size());
 	}
 	resolve_skips(ctx);
@@ -1935,7 +1987,7 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	L.root_material = L.materials + (size_t)P.n_materials * lol::MATERIAL_DWORDS;
 	L.ambient[0] = P.ambient_color.x; L.ambient[1] = P.ambient_color.y; L.ambient[2] = P.ambient_color.z;
 	L.flags = (ctx->miss_skip ? lol::FLAG_MISS_SKIP : 0u) | (ctx->dark_skip ? lol::FLAG_DARK_SKIP : 0u) |
-	          (ctx->shadow_settle && camera_sane(*cam) ? lol::FLAG_SHADOW_SETTLED : 0u);
+	          (ctx->shadow_settle && camera_sane(*cam) ? lol::FLAG_SHADOW_SETTLED | (ctx->shadow_fdiv ? lol::FLAG_SHADOW_FDIV : 0u) : 0u);
 	L.dst = static_cast<uint32_t*>(dst);
 	L.pitch_px = (uint32_t)(pitch_bytes / 4);
 	L.fmt_shift = ctx->fmt_shift; L.fmt_loss = ctx->fmt_loss; L.fmt_amask = ctx->fmt_amask;
@@ -2221,6 +2273,7 @@ int lol_gpu_compile_offline(const lol_program* prog, const char* arch, const cha
 	if (assume_fast) {                 /* ISA inspection only: pretend every shortcut was proven */
 		fast.sqrt_kind = assume_fast >= 1 && assume_fast <= 3 ? 4 - assume_fast : 3;   /* 1 → sqrt_r2, 2 → sqrt_gs, 3 → sqrt_pm */
 		fast.sqrt_tiny_ok = true;
+		fast.fdiv_ok = true;
 		for (uint32_t i = 0; i < prog->n_ops; i++)
 			if ((prog->ops[i].op == LOL_OP_SMIN || prog->ops[i].op == LOL_OP_SMIN_R) && !fast.has(prog->ops[i].f[0]))
 				{ fast.div_ok.push_back(prog->ops[i].f[0]); fast.div_nf_ok.push_back(prog->ops[i].f[0]); }

@@ -68,6 +68,7 @@ constexpr u32 FLAG_MISS_SKIP = 1u;   /* a wave whose rays all escaped may skip n
 constexpr u32 FLAG_DARK_SKIP = 2u;   /* lanes whose diffuse incidence for a light is exactly 0 need no shadow march for it */
 constexpr u32 FLAG_TILE_COLS = 8u;   /* the launch grid is transposed: tiles are handed out column by column (lol_gpu_set_tile_order) */
 constexpr u32 FLAG_SHADOW_SETTLED = 4u;   /* a shadow march ends as soon as its factor can only be 0 (soft_shadow) */
+constexpr u32 FLAG_SHADOW_FDIV = 16u;     /* with FLAG_SHADOW_SETTLED: 50 s / t by fdiv_fast where the Sdf policy allows it (soft_shadow) */
 
 /* = lol_frame_camera */
 struct Cam { float origin[3], dir[3], right[3], up[3]; float width, height; };
@@ -440,6 +441,31 @@ __device__ __forceinline__ float sd_round_box_fast(V3 p, float cx, float cy, flo
 	return root + minf_(maxf_(q.x, maxf_(q.y, q.z)), 0.f) - r;
 }
 
+/* 50 s / t of the shadow march (naive_renderer.c:83) without v_div_scale x 2, v_div_fmas and v_div_fixup: exactly the
+ * sequence hipcc emits for a correctly rounded `/` — reciprocal, one Newton step on it, quotient, two residual corrections,
+ * the last one fused — minus the scaling and the special-case fix-up around it.  By the ISA's definition of those three
+ * instructions the sequences are THE SAME arithmetic whenever v_div_scale returns its operand unscaled (vcc = 0, so
+ * v_div_fmas is a plain fma) and v_div_fixup hands its first operand through, i.e. for finite non-zero normal n, t with
+ *   t not a denormal, 1/t not a denormal, n/t not a denormal, exponent(n) - exponent(t) < 96, biased exponent(n) > 23.
+ * soft_shadow uses it for t in [2^-28, 2^58] and n = 50 s with n <= 0 (only the sign of the quotient is used then) or
+ * n in [2^-60, 2^64], and establishes those ranges from what it marches (FDIV_* below); verify_fdiv_kernel (lol_gpu.hip)
+ * holds the two sequences against each other on the device over all 2^23 mantissas of n for 512 combinations of exponents
+ * and divisor mantissas spread over that box, corners included.  Saves 4 half-rate instructions of 13 per shadow step. */
+#ifndef LOL_FDIV_T_MIN
+#define LOL_FDIV_T_MIN 0x1p-28f      /* (tests compile the scene kernel with a huge value here to see the fallback take over) */
+#endif
+constexpr float FDIV_T_MIN = LOL_FDIV_T_MIN, FDIV_T_MAX = 0x1p58f, FDIV_RES_MIN = 0x1p-30f;
+__device__ __forceinline__ float fdiv_fast(float n, float t) {
+	float y = __builtin_amdgcn_rcpf(t);
+	const float e = __builtin_fmaf(-t, y, 1.0f);
+	y = __builtin_fmaf(e, y, y);
+	float q = n * y;
+	float r = __builtin_fmaf(-t, q, n);
+	q = __builtin_fmaf(r, y, q);
+	r = __builtin_fmaf(-t, q, n);
+	return __builtin_fmaf(r, y, q);
+}
+
 /* ------------------------------------------------------------ SDF interpreter
  * Runs the scene's SDF for one point per lane from a list of MACRO-OPS (lol_gpu.hip: build_mops translates the
  * post-order program of lol_scene.h).  The machine has an accumulator `acc` (the top of the operand stack) and a
@@ -543,6 +569,10 @@ struct Interp {
 	 * (Handing the loop's own vote down as the mask: +0.5 % here, but the changed loop text cost the SPECIALISED kernel 2.4 %
 	 * on C2 — same instructions, another schedule.) */
 	static constexpr bool MASKS = false;
+	/* the shadow march keeps the plain division here (soft_shadow, fdiv_fast): this kernel is bound by its scalar side, and the
+	 * second division variant with its branch and votes in the loop cost it 9 % on C3 (4330 -> 3950 Mpixels/s, measured), the
+	 * four half-rate instructions it saves nothing */
+	static constexpr bool FAST_DIV = false;
 	__device__ __forceinline__ void eval(V3 p, float& best_out, u32& id_out, bool care = true) {
 		/* everything the loop carries is a local: the trip count and the list pointer must stay provably
 		 * wave-uniform (scalar loop, scalar loads, scalar branches), which they do not when they live behind
@@ -750,27 +780,48 @@ __device__ __forceinline__ Hit march(Sdf& sdf, V3 ro, V3 rd, int max_steps) {
  * origin, where s is what it was on the first step, and had that been 0 res would have been NaN from the first step on,
  * never <= 0).  The reference goes on until res < -1 or t > L; a ray that grazes along just inside a surface does so for
  * all 128 steps while its 63 neighbours wait.  Same pixels; the shadow step counts of lol_gpu_debug shrink.
+ *
+ * `fdiv` (FLAG_SHADOW_FDIV with `settled`, wave-uniform, Sdf::FAST_DIV): from the second step on the quotient is fdiv_fast's.
+ * What makes its operands lie in the proven box, for every lane that is still marching at step i >= 1:
+ *   - t.  Step 0 divides by t = 0 (the reference's +-inf / NaN semantics: always the plain division) and leaves t = s0.  A lane
+ *     still marching afterwards has s0 >= 0, and every later step of a marching lane had s > 0 (with s <= 0 the quotient is
+ *     <= 0, or NaN only for t = 0, and the lane is settled): t only grows.  So t >= s0, checked ONCE, at step 1: t >= 2^-28
+ *     (a NaN res from s0 = 0 fails this check too); and t <= 2^58 is checked at the end.
+ *   - n = 50 s <= 0: only `quotient <= 0` is used (the lane settles, the factor comes out 0) and fdiv_fast keeps the sign.
+ *   - n > 0: n <= 50 (t + s) <= 2^64 by the bound on t; and every such quotient is >= the final res, so res >= 2^-30 at the
+ *     end gives n >= 2^-30 t >= 2^-58 (below 2^-60 fdiv_fast could not have come out above 2^-31 either).
+ * A wave with a lane outside these checks marks sdf.nan — like a sphere without range tracker that went NaN — and shades
+ * its pixels again through the plain Sdf, whose FAST_DIV is false.
  */
 template <class Sdf>
-__device__ __forceinline__ float soft_shadow(Sdf& sdf, V3 p, V3 dir, float max_dist, u32& steps, bool needed, bool settled) {
+__device__ __forceinline__ float soft_shadow(Sdf& sdf, V3 p, V3 dir, float max_dist, u32& steps, bool needed, bool settled, bool fdiv_flag = false) {
 	V3 ro = add(p, dir);
 	float res = 1.f, t = 0.f;
 	const float stop_at = settled ? 0.f : -1.f;          /* res < -1 (naive_renderer.c:85), or res <= 0 */
+	const bool fdiv = Sdf::FAST_DIV && settled && fdiv_flag;
+	u64 out_of_box = 0;
 	bool alive = needed;          /* a lane that does not need the factor never marches (returns 1) */
 	u64 marching = Sdf::MASKS ? vote(needed) : 0;
 	for (int i = 0; i < 128; i++) {
-		if ((Sdf::MASKS ? marching : vote(alive)) == 0) break;
+		const u64 live = Sdf::MASKS ? marching : vote(alive);
+		if (live == 0) break;
+		if constexpr (Sdf::FAST_DIV) if (fdiv && i == 1) out_of_box |= vote(!(t >= FDIV_T_MIN)) & live;
 		V3 q = add(ro, scale(dir, t));
 		float s; u32 sid;
 		if constexpr (Sdf::MASKS) sdf.eval(q, s, sid, marching); else sdf.eval(q, s, sid, alive);
 		if (alive) {
-			res = minf_(res, 50.f * s / t);
+			float v;
+			if (Sdf::FAST_DIV && fdiv && i != 0) v = fdiv_fast(50.f * s, t);
+			else v = 50.f * s / t;
+			res = minf_(res, v);
 			t += s;
 			steps++;
 			if (res < -1.f || t > max_dist || (settled && res <= 0.f)) alive = false;
 		}
 		if constexpr (Sdf::MASKS) marching &= ~((settled ? vote(res <= stop_at) : vote(res < stop_at)) | vote(t > max_dist));
 	}
+	if constexpr (Sdf::FAST_DIV)
+		if (fdiv) sdf.nan |= out_of_box | (vote(res < FDIV_RES_MIN) & vote(res > 0.f)) | vote(!(t <= FDIV_T_MAX));
 	return maxf_(res, 0.f);
 }
 
@@ -901,7 +952,8 @@ __device__ __forceinline__ Pixel shade_pixel(const Launch& L, Sdf& sdf, const u3
 			bool needed = true;
 			if (L.flags & FLAG_DARK_SKIP) needed = di > 0.f;
 			if ((L.flags & FLAG_MISS_SKIP) && hit.id == 0u) needed = false;
-			float shadow = soft_shadow(sdf, p, light_dir, light_dist, shadow_steps, needed, (L.flags & FLAG_SHADOW_SETTLED) != 0u);
+			float shadow = soft_shadow(sdf, p, light_dir, light_dist, shadow_steps, needed, (L.flags & FLAG_SHADOW_SETTLED) != 0u,
+			                           (L.flags & FLAG_SHADOW_FDIV) != 0u);
 
 			V3 refl = sub(scale(n, 2.f * dot(light_dir, n)), light_dir);
 			V3 Id = mul(scale(lds_v3(lp + 3), shadow * di), m_diff);

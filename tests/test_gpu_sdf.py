@@ -13,6 +13,7 @@ import struct
 import numpy as np
 import pytest
 
+import oracle_lib as O
 from loltracer_amd import gpu
 
 pytestmark = pytest.mark.gpu
@@ -130,4 +131,41 @@ def test_points_where_the_fast_root_has_no_proof(scenes, mode):
     both_nan = np.isnan(got) & np.isnan(want_d)
     assert np.array_equal(got.view(np.uint32)[~both_nan], want_d.view(np.uint32)[~both_nan])
     assert np.array_equal(d_id.cpu().numpy(), want_id)
+    r.close()
+
+
+@pytest.mark.gpu
+def test_shadow_division_shortcut_is_the_division(scenes, monkeypatch):
+    """fdiv_fast (lol_kernel.h) = hipcc's own division sequence minus v_div_scale / v_div_fmas / v_div_fixup: the same arithmetic
+    inside the box of operands the shadow march keeps for itself.  The device holds it against '/' over 2^32 quotients per sweep:
+    the fixed exponent corners (what a context checks before using it) and pseudo-random exponents / divisor mantissas.
+    And the fallback: a kernel compiled with an absurd lower bound for t sends every wave that marches a shadow through the
+    plain path — same frame."""
+    import torch
+    r0 = gpu.Renderer(0)                                           # the default: the plain division
+    monkeypatch.setenv("LOL_GPU_SHADOW_FDIV", "1")                 # (off by default: +0.95 % on C3, below the bar for the default kernel)
+    r = gpu.Renderer(0)
+    for seed in (0, 1, 2, 20261004, 0xDEADBEEF):
+        assert r.verify_shadow_division(seed) == 0, seed
+    sc = scenes["scene4"]
+    w, h = 160, 90
+    want, _, _ = O.render(sc, w, h, threads=4)
+
+    def frame(rr):
+        rr.prepare(sc)
+        assert rr.kernel_name() == "lol_render_spec", rr.specialize_log()
+        buf = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+        rr.render_into(buf.data_ptr(), w, h)
+        rr.sync()
+        return buf.cpu().numpy().view(np.uint32)
+    assert np.array_equal(frame(r), want)
+    with monkeypatch.context() as m:
+        m.delenv("LOL_GPU_SHADOW_FDIV")                            # the plain division everywhere: another kernel, the same frame
+        assert np.array_equal(frame(r0), want) and r0.kernel_key() != r.kernel_key()
+        r0.close()
+    with monkeypatch.context() as m:
+        m.setenv("LOL_GPU_RTC_FLAGS", "-DLOL_FDIV_T_MIN=64.0f")    # no march ever starts 64 units from a surface: every one falls back
+        r1 = gpu.Renderer(0)
+        assert np.array_equal(frame(r1), want) and r1.kernel_key() != r.kernel_key()
+        r1.close()
     r.close()
