@@ -178,7 +178,7 @@ def valu_fields(kernel: str, workload: str, px_per_launch: int, kernel_key: str,
 
 # ---- N > 1: what every rank did, on rank 0's line -----------------------------------------------------------------
 RANK_STATS = ("rows", "frames", "kernel_ms_avg", "kernel_ms_min", "kernel_ms_max", "wall_ms_per_frame",
-              "host_issue_us_per_frame", "tile_order_cols", "tile_rows_ms", "tile_cols_ms", "tile_deciding")
+              "host_issue_us_per_frame", "tile_order_code", "tile_rows_ms", "tile_cols_ms", "tile_deciding")
 
 
 def gather_rank_stats(local: dict, device) -> list:
@@ -225,7 +225,7 @@ def per_rank_fields(stats: list, ms_per_step: float) -> dict:
                          "kernel_ms_max": round(s["kernel_ms_max"], 4), "wall_ms_per_frame": round(s["wall_ms_per_frame"], 4),
                          "exposed_ms_per_frame": round(s["wall_ms_per_frame"] - s["kernel_ms_avg"], 4),
                          "host_issue_us_per_frame": round(s["host_issue_us_per_frame"], 1),
-                         "tile_order": "cols" if s["tile_order_cols"] else "rows", "tile_order_deciding": bool(s["tile_deciding"]),
+                         "tile_order": ("rows", "cols", "auto", "lpt")[int(s["tile_order_code"]) & 3], "tile_order_deciding": bool(s["tile_deciding"]),
                          "tile_trial_ms": {"rows": round(s["tile_rows_ms"], 4), "cols": round(s["tile_cols_ms"], 4)}})
     k = [r["kernel_ms_avg"] for r in per_rank]
     return {"per_rank": per_rank,
@@ -478,7 +478,7 @@ def run_cabi(args, record_fd):
 
     per_dev = int(os.environ.get("LOL_BENCH_PARTS_PER_DEVICE", "1"))
     m.set_parts_per_device(per_dev)
-    want_order = os.environ.get("LOL_BENCH_TILE_ORDER", "auto")      # the library's own choice unless pinned (A/B runs)
+    want_order = os.environ.get("LOL_BENCH_TILE_ORDER", "lpt")       # the library's default unless pinned (A/B runs)
     m.set_tile_order(want_order)
     trials = []
     cands = root_share_candidates(n, h)
@@ -712,13 +712,13 @@ def main():
     # Set-up, not measurement: keep the device busy for about a quarter of a second so that the clocks have ramped before
     # the W warm-up steps — the timed region of the default run is only ~40 ms, and a cold start moved it by several %.
     # A fixed frame count per workload (every rank issues the same number of gathers), none for the 256-frame orbit.
-    # The order in which a launch hands out its tiles is the LIBRARY's decision (lol_gpu_set_tile_order, AUTO by default: it
-    # times both orders on the first frames of a scene / size / partition with its own events and keeps the faster), so the
-    # rate reported here is the rate a host gets through the boundary with no tuning of its own.  LOL_BENCH_TILE_ORDER =
-    # rows | cols pins it (A/B runs).  The set-up frames below are more than the gpu.TILE_TRIAL_FRAMES the decision takes.
-    want_order = os.environ.get("LOL_BENCH_TILE_ORDER", "auto")
-    if want_order not in ("rows", "cols", "auto"):
-        raise SystemExit(f"LOL_BENCH_TILE_ORDER={want_order}: want rows, cols or auto")
+    # The order in which a launch hands out its tiles is the LIBRARY's business (lol_gpu_set_tile_order; its default: longest
+    # tiles first, from the costs the tiles of the frames before reported — sorted on the device, on the frame's own stream, a
+    # few small kernels every fourth frame that are part of what is timed), so the rate reported here is the rate a host gets
+    # through the boundary with no tuning of its own.  LOL_BENCH_TILE_ORDER = rows | cols | auto pins another mode (A/B runs).
+    want_order = os.environ.get("LOL_BENCH_TILE_ORDER", "lpt")      # the library's default: longest tiles first
+    if want_order not in ("rows", "cols", "auto", "lpt"):
+        raise SystemExit(f"LOL_BENCH_TILE_ORDER={want_order}: want lpt, auto, rows or cols")
     r.set_tile_order(want_order)
     prewarm = {"c2": 400, "c3": 100, "c4": 32 * max(world, emulate), "orbit": gpu.TILE_TRIAL_FRAMES + 10}[name]
     prewarm = max(prewarm, gpu.TILE_TRIAL_FRAMES + 10)
@@ -799,8 +799,8 @@ def main():
         "rows": P.rank_rows[rank] if P is not None else h, "frames": steps,
         "kernel_ms_avg": k_avg, "kernel_ms_min": min(k_ms) if k_ms else 0.0, "kernel_ms_max": max(k_ms) if k_ms else 0.0,
         "wall_ms_per_frame": dt_local / max(steps, 1) * 1e3, "host_issue_us_per_frame": host_s / max(steps, 1) * 1e6,
-        "tile_order_cols": tile["order"] == "cols", "tile_rows_ms": tile["trial_ms"]["rows"], "tile_cols_ms": tile["trial_ms"]["cols"],
-        "tile_deciding": tile["deciding"]}, dev)
+        "tile_order_code": {"rows": 0, "cols": 1, "auto": 2, "lpt": 3}[tile["order"]], "tile_rows_ms": tile["trial_ms"]["rows"],
+        "tile_cols_ms": tile["trial_ms"]["cols"], "tile_deciding": tile["deciding"]}, dev)
     if orbit:
         total_px = cfg["frames"] * w * h              # all ranks together render each frame once
         steps_reported = cfg["frames"]
@@ -830,9 +830,10 @@ def main():
             "gather_ms": gather_ms,
             "partition": P.describe() if P is not None else None,
             "root_share_trials": trials or None,
-            # lol_gpu_set_tile_order(AUTO): what the LIBRARY measured on its first frames (typical frame of each order) and took
-            "tile_order": tile["order"], "tile_order_mode": tile["mode"], "tile_order_trials_ms": tile["trial_ms"],
-            "tile_order_decided_by": "liblol_gpu (lol_gpu_set_tile_order AUTO)" if tile["mode"] == "auto" else "LOL_BENCH_TILE_ORDER",
+            # lol_gpu_set_tile_order: the library's mode and what it is doing (lpt = longest tiles first: sorts so far; auto: its trials)
+            "tile_order": tile["order"], "tile_order_mode": tile["mode"], "tile_order_sorts_or_decisions": tile["decisions"],
+            "tile_order_trials_ms": tile["trial_ms"] if tile["mode"] == "auto" else None,
+            "tile_order_decided_by": "liblol_gpu (its default)" if "LOL_BENCH_TILE_ORDER" not in os.environ else "LOL_BENCH_TILE_ORDER",
             "assembly": None if pipe is None else ("lol_gpu_assemble_parts_at (library kernel, own stream)" if assembler else "torch index_select"),
             "host_issue_us_per_frame": round(host_s / max(steps, 1) * 1e6, 1),
             "prewarm_frames": prewarm,            # untimed set-up frames before the W warm-up steps (clock ramp)

@@ -258,22 +258,30 @@ int         lol_gpu_miss_skip_active(const lol_gpu* ctx);
  */
 int         lol_gpu_set_cull(lol_gpu* ctx, int enable);
 /*
- * The order in which a launch hands out its tiles of 16x4 pixels: LOL_GPU_TILES_ROWS = row by row, LOL_GPU_TILES_COLS = column
- * by column (the launch grid transposed).  Same pixels either way; which is faster depends on the scene and the frame (scene4
- * at 4K: columns +2.4 %, scene.lol at 1080p: columns -7 %), so the default is LOL_GPU_TILES_AUTO: the library
- * measures.  The first frames of a (scene, frame size, row partition, max_steps) are launched in both orders alternately, each
- * between two HIP events on its launch stream (LOL_GPU_TILE_TRIALS frames per order after a few untimed ones; nothing ever
- * waits: finished trials are collected, without blocking, by the frames that follow), and the order whose typical frame
- * is faster by more than 1 % is kept — rows otherwise — until the scene, the size or the partition changes (a resized window
- * decides again).  Every trial frame is an ordinary frame.  Takes effect at the next frame.  The reference has no
- * counterpart: its thread pool claims pixels one by one (naive_renderer.c:216).
+ * The order in which a launch hands out its tiles of 16x4 pixels.  Same pixels in every order; the time differs, because a
+ * frame is one launch of blocks that differ 100x in cost and ends with its slowest waves running on half-empty SIMDs.
+ *   LOL_GPU_TILES_LPT (the default): longest tiles first.  Every tile reports how long its wave ran; a counting sort on the
+ *     device (three small kernels on the frame's stream, after the first frame of a scene / frame size / row partition and
+ *     every few frames from then on) orders the tiles of the following frames by decreasing cost — list scheduling with
+ *     the last frames' costs, which a camera that moves a little per frame (main.c:70-112) changes little.  scene4 at 4K
+ *     +8 % over the better of the two fixed orders, scene.lol at 1080p +30 %, the bands of an 8-way split of the 8K frame
+ *     +16 %.  The first frame of a key is handed out row by row.  The tables live on the stream the
+ *     first frame was launched on; frames of the same geometry on other streams are launched row by row.
+ *   LOL_GPU_TILES_ROWS / LOL_GPU_TILES_COLS: row by row / column by column (the launch grid transposed).
+ *   LOL_GPU_TILES_AUTO: the better of those two, measured: the first frames of a (scene, frame size, row partition, max_steps)
+ *     are launched in both orders alternately, each between two HIP events on its launch stream (LOL_GPU_TILE_TRIALS frames
+ *     per order after a few untimed ones; nothing ever waits), and the order whose typical frame is faster by more than
+ *     1 % is kept — rows otherwise — until the scene, the size or the partition changes.
+ * Takes effect at the next frame.  The reference has no counterpart: its thread pool claims pixels one by one
+ * (naive_renderer.c:216) — which IS dynamic load balancing; this is its counterpart for a launch whose order is fixed up front.
  */
-enum { LOL_GPU_TILES_ROWS = 0, LOL_GPU_TILES_COLS = 1, LOL_GPU_TILES_AUTO = 2 };
+enum { LOL_GPU_TILES_ROWS = 0, LOL_GPU_TILES_COLS = 1, LOL_GPU_TILES_AUTO = 2, LOL_GPU_TILES_LPT = 3 };
 #define LOL_GPU_TILE_TRIALS 16
 int         lol_gpu_set_tile_order(lol_gpu* ctx, int order);
 /* What the context is doing about it: mode = what was asked for; order = the order of the next frame outside a trial
- * (LOL_GPU_TILES_ROWS until AUTO has decided); deciding != 0 while trials are still being launched or collected;
- * rows_ms / cols_ms = the typical trial frame of each order behind the last decision (0 before one). */
+ * (LOL_GPU_TILES_ROWS until AUTO has decided / until longest-first has its tables); deciding != 0 while AUTO's trials are
+ * still being launched or collected, or before longest-first has sorted once; decisions = AUTO decisions / sorts so far;
+ * rows_ms / cols_ms = the typical trial frame of each order behind AUTO's last decision (0 otherwise). */
 typedef struct lol_gpu_tile_order_info {
 	int32_t mode, order, deciding, decisions;
 	float   rows_ms, cols_ms;

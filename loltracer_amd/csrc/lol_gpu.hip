@@ -173,7 +173,7 @@ struct lol_gpu {
 	/* lol_gpu_set_tile_order.  AUTO: the first frames of a (scene, size, partition) alternate between the two orders, each
 	 * between two events on its launch stream; later frames collect the finished ones without waiting (tile_auto_*) */
 	struct TileAuto {
-		int   mode = LOL_GPU_TILES_AUTO;
+		int   mode = LOL_GPU_TILES_LPT;
 		int   chosen = LOL_GPU_TILES_ROWS;       /* order outside trials */
 		bool  deciding = false;
 		int   key[6] = { 0, 0, 0, 0, 0, 0 };    /* w, h, max_steps, band_rows, cycle_rows, program generation */
@@ -185,6 +185,19 @@ struct lol_gpu {
 		float typical[2] = { 0.f, 0.f };
 	} tiles;
 	int          generation = 0;         /* uploads so far */
+	/* LOL_GPU_TILES_LPT: longest tiles first ("longest tiles first" below) */
+	struct TileLpt {
+		int      key[7] = { 0, 0, 0, 0, 0, 0, 0 };   /* w, h, max_steps, band_rows, cycle_rows, offset_rows, generation * 2 + spec */
+		uint32_t n_tiles = 0;
+		uint32_t* d_order[2] = { nullptr, nullptr };   /* tile_order tables: frames read [cur], a sort writes [cur ^ 1] */
+		uint32_t* d_cost = nullptr;          /* what the blocks of the last frame cost, by launch position */
+		uint32_t* d_keys = nullptr;          /* the sort's snapshot of the costs (bucket numbers) */
+		uint32_t* d_hist = nullptr;          /* 2 x LPT_BUCKETS: bucket sizes, then the scatter's cursors */
+		size_t   cap = 0;                    /* tiles the buffers hold */
+		int      cur = 0;
+		unsigned frames = 0, sorts = 0;      /* frames launched with this key; sorts done */
+		hipStream_t home = nullptr;          /* the stream these tables live on (lpt_table_for_frame) */
+	} lpt;
 	char         err[512] = { 0 };
 	char         kernel_name[64] = "render_interp";
 };
@@ -1106,6 +1119,7 @@ std::string generate_source(const lol_program& P, const FastPaths* fast, bool cu
 		s += "\tlol::stage_common(L, lds);\n";
 		s += "\t__syncthreads();\n";
 	}
+	s += "\tlol::start_tile_clock<" + tg + ">(L, lds);\n";
 	if (any_fast) {
 		s += "\tlol::SpecSdfFast fast;\n";
 		s += "\tlol::Pixel P = lol::shade_pixel<lol::SpecSdfFast, " + tg + ">(L, fast, lds);\n";
@@ -1618,6 +1632,8 @@ int lol_gpu_create(int device, lol_gpu** out) {
 	return LOL_GPU_OK;
 }
 
+static void lpt_release(lol_gpu* ctx);
+
 void lol_gpu_destroy(lol_gpu* ctx) {
 	if (!ctx) return;
 	if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
@@ -1639,6 +1655,7 @@ void lol_gpu_destroy(lol_gpu* ctx) {
 
 	if (ctx->d_bad) (void)hipFree(ctx->d_bad);
 	if (ctx->tiles.have_events) for (hipEvent_t e : ctx->tiles.ev) (void)hipEventDestroy(e);
+	lpt_release(ctx);
 	delete ctx;
 }
 
@@ -1704,13 +1721,142 @@ int lol_gpu_cull_bounds_clusters(const lol_program* prog, uint32_t root, float o
 }
 
 int lol_gpu_set_tile_order(lol_gpu* ctx, int order) {
-	if (!ctx || order < LOL_GPU_TILES_ROWS || order > LOL_GPU_TILES_AUTO) return LOL_GPU_ERR_ARG;
+	if (!ctx || order < LOL_GPU_TILES_ROWS || order > LOL_GPU_TILES_LPT) return LOL_GPU_ERR_ARG;
 	lol_gpu::TileAuto& T = ctx->tiles;
 	T.mode = order;
 	T.deciding = false;                      /* a running series of trials is abandoned (its events are simply reused) */
 	T.key[0] = 0;                            /* ... and AUTO starts afresh at the next frame */
 	T.chosen = order == LOL_GPU_TILES_COLS ? LOL_GPU_TILES_COLS : LOL_GPU_TILES_ROWS;
+	ctx->lpt.key[0] = 0;                     /* longest-first starts afresh too (its tables stay allocated) */
 	return LOL_GPU_OK;
+}
+
+/*
+ * Longest tiles first.  A frame is ONE launch of one-wave blocks (129,600 for C3) that the hardware hands out in block order;
+ * blocks differ 100x in cost (sky against penumbra), the launch ends when the LAST wave ends, and while the slowest waves
+ * of the tail run the SIMDs stand half empty — frames issued on three streams so that the next frame's waves fill that
+ * tail render 9 % (C3) to 67 % (scene.lol at 1080p) faster (tools/stream_overlap_ab.py, profiles/r4_stream_overlap_ab.jsonl),
+ * but the reference's frame loop is sequential (main.c:189-194).  The same packing INSIDE one frame: hand the tiles out in the
+ * order of decreasing cost (list scheduling, longest processing time first), the cost being what the tile cost in the frame
+ * before — the camera moves a little per frame (main.c:70-112), a still camera not at all.  Every block writes how long its
+ * wave ran (shader clock, 32 x log2: store_pixel, tile_cost); a counting sort on the device (three small kernels on the
+ * frame's stream, once after the first frame of a scene / size and then every LPT_RESORT frames) turns the costs into the
+ * next order table; the kernel reads its tile from the table (tile_of_block).  Same pixels: only the ORDER in which tiles
+ * are rendered changes.  Measured, one stream, one box (tools/tile_order_ab.py, profiles/r4_tile_order_ab.jsonl,
+ * r4_lpt_sweep*.txt; best of rows / columns -> longest first): C3 7850 -> 8470 Mpixels/s, scene.lol at 1080p 14,400 ->
+ * 18,900, rank 0's bands of an 8-way C4 split 7370 -> 8580, a whole C4 frame 8600 -> 8770, the orbit (the costs lag the
+ * camera by up to LPT_RESORT frames) 10,050 -> 10,300.  (The run time predicts better than the evaluation count, the first
+ * cost tried: C3 8200.)
+ */
+constexpr unsigned LPT_BUCKETS = 1024, LPT_THREADS = 256, LPT_RESORT = 4;
+
+/* order[i] = tile i of the frame in row-major order, as column | row << 16 */
+__global__ __launch_bounds__(LPT_THREADS) void lpt_identity_kernel(uint32_t* order, uint32_t n, uint32_t tiles_x) {
+	const uint32_t i = blockIdx.x * LPT_THREADS + threadIdx.x;
+	if (i < n) order[i] = (i % tiles_x) | (i / tiles_x) << 16;
+}
+/* pass 1: snapshot every block's cost as a bucket number (bucket 0 = the most expensive), count the buckets */
+__global__ __launch_bounds__(LPT_THREADS) void lpt_hist_kernel(const uint32_t* cost, uint32_t* keys, uint32_t* hist, uint32_t n) {
+	__shared__ uint32_t h[LPT_BUCKETS];
+	for (uint32_t b = threadIdx.x; b < LPT_BUCKETS; b += LPT_THREADS) h[b] = 0;
+	__syncthreads();
+	const uint32_t i = blockIdx.x * LPT_THREADS + threadIdx.x;
+	if (i < n) {
+		uint32_t k = cost[i];                                  /* <= 703 (lol_kernel.h, store_pixel); clamped all the same */
+		k = LPT_BUCKETS - 1 - (k < LPT_BUCKETS ? k : LPT_BUCKETS - 1);
+		keys[i] = k;
+		atomicAdd(&h[k], 1u);
+	}
+	__syncthreads();
+	for (uint32_t b = threadIdx.x; b < LPT_BUCKETS; b += LPT_THREADS) if (h[b]) atomicAdd(&hist[b], h[b]);
+}
+/* pass 2 (one block): hist[LPT_BUCKETS + b] = where bucket b starts (exclusive prefix sum) */
+__global__ __launch_bounds__(LPT_BUCKETS) void lpt_scan_kernel(uint32_t* hist) {
+	__shared__ uint32_t s[LPT_BUCKETS];
+	const uint32_t b = threadIdx.x;
+	s[b] = hist[b];
+	__syncthreads();
+	for (uint32_t d = 1; d < LPT_BUCKETS; d <<= 1) {
+		const uint32_t v = b >= d ? s[b - d] : 0u;
+		__syncthreads();
+		s[b] += v;
+		__syncthreads();
+	}
+	hist[LPT_BUCKETS + b] = s[b] - hist[b];
+}
+/* pass 3: every block reserves room for its members of each bucket with ONE atomic per bucket and places them in their
+ * old order; what it places is the TILE the old table named for that launch position */
+__global__ __launch_bounds__(LPT_THREADS) void lpt_scatter_kernel(const uint32_t* keys, const uint32_t* order_in, uint32_t* order_out,
+                                                                  uint32_t* hist, uint32_t n) {
+	__shared__ uint32_t h[LPT_BUCKETS], base[LPT_BUCKETS];
+	for (uint32_t b = threadIdx.x; b < LPT_BUCKETS; b += LPT_THREADS) h[b] = 0;
+	__syncthreads();
+	const uint32_t i = blockIdx.x * LPT_THREADS + threadIdx.x;
+	uint32_t k = 0, rank = 0;
+	if (i < n) { k = keys[i]; rank = atomicAdd(&h[k], 1u); }
+	__syncthreads();
+	for (uint32_t b = threadIdx.x; b < LPT_BUCKETS; b += LPT_THREADS) if (h[b]) base[b] = atomicAdd(&hist[LPT_BUCKETS + b], h[b]);
+	__syncthreads();
+	if (i < n) order_out[base[k] + rank] = order_in[i];
+}
+
+static unsigned lpt_resort_period() {
+	static const unsigned period = [] { const char* e = getenv("LOL_GPU_LPT_RESORT"); const int v = e ? atoi(e) : 0; return v > 0 ? (unsigned)v : LPT_RESORT; }();
+	return period;
+}
+
+static void lpt_release(lol_gpu* ctx) {
+	lol_gpu::TileLpt& T = ctx->lpt;
+	for (uint32_t** p : { &T.d_order[0], &T.d_order[1], &T.d_cost, &T.d_keys, &T.d_hist })
+		if (*p) { (void)hipFree(*p); *p = nullptr; }
+	T.cap = 0; T.n_tiles = 0; T.key[0] = 0;
+}
+
+/* The table for the frame about to be launched on `s` (device current), or nullptr: a row-by-row launch as before.  Sets
+ * up (or re-creates) the tables when the scene, size, partition or kernel changed; sorts when it is time.  Everything
+ * about one set of tables happens on ONE stream — the one its first frame was launched on: frames, the costs they write
+ * and the sorts that read them are then ordered by the stream itself, and a table is never rewritten under a frame that
+ * still reads it.  A frame of the same key on another stream is simply launched without a table. */
+static const uint32_t* lpt_table_for_frame(lol_gpu* ctx, int w, int h, int max_steps, const lol_gpu_rows* R, int n_rows,
+                                           int tile_w, int tile_h, hipStream_t s, uint32_t** cost_out) {
+	lol_gpu::TileLpt& T = ctx->lpt;
+	*cost_out = nullptr;
+	const uint32_t tiles_x = (uint32_t)((w + tile_w - 1) / tile_w), tiles_y = (uint32_t)((n_rows + tile_h - 1) / tile_h);
+	const uint32_t n = tiles_x * tiles_y;
+	if (tiles_x > 0xFFFFu || tiles_y > 0xFFFFu) return nullptr;            /* (a tile is column | row << 16) */
+	const int key[7] = { w, h, max_steps, R->band_rows, R->cycle_rows, R->offset_rows, ctx->generation * 2 + (ctx->spec_fn ? 1 : 0) };
+	auto ok = [](hipError_t e) { if (e != hipSuccess) (void)hipGetLastError(); return e == hipSuccess; };
+	if (memcmp(key, T.key, sizeof key) != 0) {
+		/* frames of the old key may still read the tables, on their stream: drain the device before the tables change hands */
+		if (T.key[0] && (n > T.cap || s != T.home) && !ok(hipDeviceSynchronize())) return nullptr;
+		if (n > T.cap) {
+			lpt_release(ctx);
+			const size_t cap = (size_t)n + n / 4 + 1024;
+			const bool good = ok(hipMalloc(reinterpret_cast<void**>(&T.d_order[0]), cap * 4)) && ok(hipMalloc(reinterpret_cast<void**>(&T.d_order[1]), cap * 4)) &&
+			                  ok(hipMalloc(reinterpret_cast<void**>(&T.d_cost), cap * 4)) && ok(hipMalloc(reinterpret_cast<void**>(&T.d_keys), cap * 4)) &&
+			                  ok(hipMalloc(reinterpret_cast<void**>(&T.d_hist), 2 * LPT_BUCKETS * 4));
+			if (!good) { lpt_release(ctx); return nullptr; }
+			T.cap = cap;
+		}
+		memcpy(T.key, key, sizeof key);
+		T.n_tiles = n; T.cur = 0; T.frames = 0; T.sorts = 0; T.home = s;
+		hipLaunchKernelGGL(lpt_identity_kernel, dim3((n + LPT_THREADS - 1) / LPT_THREADS), dim3(LPT_THREADS), 0, s, T.d_order[0], n, tiles_x);
+		if (!ok(hipGetLastError()) || !ok(hipMemsetAsync(T.d_cost, 0, (size_t)n * 4, s))) { T.key[0] = 0; return nullptr; }
+	} else if (s != T.home) {
+		return nullptr;
+	} else if (T.frames == 1 || (T.frames > 1 && T.frames % lpt_resort_period() == 0)) {
+		/* the costs of the frame before are in (same stream): three small kernels, then the other table is the current one */
+		const dim3 grid((n + LPT_THREADS - 1) / LPT_THREADS);
+		if (ok(hipMemsetAsync(T.d_hist, 0, 2 * LPT_BUCKETS * 4, s))) {
+			hipLaunchKernelGGL(lpt_hist_kernel, grid, dim3(LPT_THREADS), 0, s, T.d_cost, T.d_keys, T.d_hist, n);
+			hipLaunchKernelGGL(lpt_scan_kernel, dim3(1), dim3(LPT_BUCKETS), 0, s, T.d_hist);
+			hipLaunchKernelGGL(lpt_scatter_kernel, grid, dim3(LPT_THREADS), 0, s, T.d_keys, T.d_order[T.cur], T.d_order[T.cur ^ 1], T.d_hist, n);
+			if (ok(hipGetLastError())) { T.cur ^= 1; T.sorts++; }
+		}
+	}
+	T.frames++;
+	*cost_out = T.d_cost;
+	return T.d_order[T.cur];
 }
 
 /* AUTO: collect the trial frames that have finished (never waits) and decide once all of them have */
@@ -1772,7 +1918,10 @@ int lol_gpu_tile_order(lol_gpu* ctx, lol_gpu_tile_order_info* out) {
 	LOL_HIP(ctx, hipSetDevice(ctx->device));
 	tile_auto_harvest(ctx);
 	const lol_gpu::TileAuto& T = ctx->tiles;
-	*out = { T.mode, T.chosen, T.deciding ? 1 : 0, T.decisions, T.typical[0], T.typical[1] };
+	if (T.mode == LOL_GPU_TILES_LPT)      /* longest first: "deciding" until the first sort has been queued (the first frame of a key runs row by row) */
+		*out = { T.mode, ctx->lpt.key[0] ? LOL_GPU_TILES_LPT : LOL_GPU_TILES_ROWS, ctx->lpt.sorts == 0 ? 1 : 0, (int32_t)ctx->lpt.sorts, 0.f, 0.f };
+	else
+		*out = { T.mode, T.chosen, T.deciding ? 1 : 0, T.decisions, T.typical[0], T.typical[1] };
 	return LOL_GPU_OK;
 }
 
@@ -2005,7 +2154,15 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	dim3 grid((w + tile_w - 1) / tile_w, (n_rows + tile_h - 1) / tile_h);
 	const size_t common = (size_t)(lol::common_lds_dwords(P.n_lights, P.n_materials, P.n_roots) - lol::TILE_W * lol::TILE_H + block) * 4;
 	int trial = -1;
-	if (tile_order_for_frame(ctx, w, h, max_steps, R, dbg != nullptr, &trial) == LOL_GPU_TILES_COLS) {
+	if (ctx->tiles.mode == LOL_GPU_TILES_LPT) {
+		uint32_t* cost = nullptr;
+		if (const uint32_t* table = lpt_table_for_frame(ctx, w, h, max_steps, R, n_rows, tile_w, tile_h, s, &cost)) {
+			L.flags |= lol::FLAG_TILE_TABLE;
+			L.tile_order = table;
+			L.tile_cost = cost;
+			grid = dim3(grid.x * grid.y, 1);
+		}
+	} else if (tile_order_for_frame(ctx, w, h, max_steps, R, dbg != nullptr, &trial) == LOL_GPU_TILES_COLS) {
 		L.flags |= lol::FLAG_TILE_COLS;
 		const unsigned t = grid.x; grid.x = grid.y; grid.y = t;      /* (both stay far below the 65535 blocks a grid may have in y) */
 	}

@@ -68,6 +68,7 @@ constexpr u32 FLAG_MISS_SKIP = 1u;   /* a wave whose rays all escaped may skip n
 constexpr u32 FLAG_DARK_SKIP = 2u;   /* lanes whose diffuse incidence for a light is exactly 0 need no shadow march for it */
 constexpr u32 FLAG_TILE_COLS = 8u;   /* the launch grid is transposed: tiles are handed out column by column (lol_gpu_set_tile_order) */
 constexpr u32 FLAG_SHADOW_SETTLED = 4u;   /* a shadow march ends as soon as its factor can only be 0 (soft_shadow) */
+constexpr u32 FLAG_TILE_TABLE = 32u;      /* a one-dimensional grid: block b renders the tile Launch::tile_order[b] names (longest tiles first, lol_gpu.hip) */
 constexpr u32 FLAG_SHADOW_FDIV = 16u;     /* with FLAG_SHADOW_SETTLED: 50 s / t by fdiv_fast where the Sdf policy allows it (soft_shadow) */
 
 /* = lol_frame_camera */
@@ -99,6 +100,10 @@ struct Launch {
 	float* dbg_hit_dist;
 	u32*   dbg_hit_id;
 	u32*   dbg_steps;
+	/* FLAG_TILE_TABLE: tile_order[b] = tile column | tile row << 16 of the b-th block of the launch; tile_cost[b] (may be NULL)
+	 * receives what that block's wave cost: how long it ran (store_pixel) */
+	const u32* tile_order;
+	u32*   tile_cost;
 };
 
 /* Fields of the launch arguments that only the last few instructions of a kernel need (destination, pitch, pixel
@@ -121,6 +126,28 @@ __device__ __forceinline__ LaunchTail launch_tail(const Launch& L0) {
 #endif
 }
 
+/* Which tile of the frame this block renders: its position in the grid (row by row, or column by column with
+ * FLAG_TILE_COLS), or — FLAG_TILE_TABLE — what the launch's order table says for it: one scalar load, read where it is
+ * needed (at the start for the pixel's coordinates, at the end for the store) like the other late fields. */
+__device__ __forceinline__ void tile_of_block(const Launch& L0, int& bx, int& by) {
+	if (L0.flags & FLAG_TILE_TABLE) {
+#if defined(__HIP_DEVICE_COMPILE__)
+		typedef const __attribute__((address_space(4))) Launch* kernarg_ptr;
+		kernarg_ptr L = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+		asm volatile("" : "+s"(L));
+		typedef const __attribute__((address_space(4))) u32* table_ptr;
+		const u32 pk = ((table_ptr)(unsigned long long)L->tile_order)[blockIdx.x];
+#else
+		const u32 pk = L0.tile_order[blockIdx.x];
+#endif
+		bx = (int)(pk & 0xFFFFu);
+		by = (int)(pk >> 16);
+	} else {
+		const bool cols = (L0.flags & FLAG_TILE_COLS) != 0u;
+		bx = cols ? blockIdx.y : blockIdx.x;
+		by = cols ? blockIdx.x : blockIdx.y;
+	}
+}
 struct V3 { float x, y, z; };
 
 /* ---- float.h / vec.h semantics (see oracle/lol_oracle.c for the citations) ---- */
@@ -892,9 +919,10 @@ __device__ __forceinline__ Pixel shade_pixel(const Launch& L, Sdf& sdf, const u3
 	/* lane → pixel: wave k covers a WAVE_W x WAVE_H patch of the block's tile */
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int tx = wave * WAVE_W + (lane % WAVE_W), ty = lane / WAVE_W;
-	const bool cols = (L.flags & FLAG_TILE_COLS) != 0u;
-	int x = (cols ? blockIdx.y : blockIdx.x) * TILE_W + tx;
-	int r = (cols ? blockIdx.x : blockIdx.y) * TILE_H + ty;                     /* local row */
+	int tbx, tby;
+	tile_of_block(L, tbx, tby);
+	int x = tbx * TILE_W + tx;
+	int r = tby * TILE_H + ty;                                                  /* local row */
 	/* out-of-frame lanes shade a clamped pixel and skip the store: keeps the wave uniform */
 	x = x < L.w ? x : L.w - 1;
 	r = r < L.n_rows ? r : L.n_rows - 1;
@@ -987,8 +1015,8 @@ __device__ __forceinline__ void store_pixel(const Launch& L, const Pixel& P, u32
 	u32* l_tile = TABLES_GLOBAL ? lds : lds + L.n_lights * LIGHT_DWORDS + L.n_materials * MATERIAL_DWORDS + L.n_roots;
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int tx = wave * WAVE_W + (lane % WAVE_W), ty = lane / WAVE_W;
-	const bool cols = (L.flags & FLAG_TILE_COLS) != 0u;
-	const int bx = cols ? blockIdx.y : blockIdx.x, by = cols ? blockIdx.x : blockIdx.y;
+	int bx, by;
+	tile_of_block(L, bx, by);
 	const int gx = bx * TILE_W + tx, gr = by * TILE_H + ty;
 	if (gx < L.w && gr < L.n_rows) {
 		unsigned long long o = (unsigned long long)gr * L.w + gx;
@@ -997,6 +1025,9 @@ __device__ __forceinline__ void store_pixel(const Launch& L, const Pixel& P, u32
 		if (T.dbg_hit_id) T.dbg_hit_id[o] = P.hit.id;
 		if (T.dbg_steps) T.dbg_steps[o] = (P.hit.steps & 0xFFFFu) | (P.shadow_steps << 16);
 	}
+	/* (the tile's first word held the wave's start time until now: start_tile_clock) */
+	u32 t_start = 0;
+	if (L.flags & FLAG_TILE_TABLE) { t_start = l_tile[0]; __syncthreads(); }
 	/* through LDS so the block stores whole row segments (64 bytes each with the default 16x4 patch) */
 	l_tile[ty * TILE_W + tx] = px;
 	__syncthreads();
@@ -1004,6 +1035,38 @@ __device__ __forceinline__ void store_pixel(const Launch& L, const Pixel& P, u32
 	const int ox = bx * TILE_W + sx, orow = by * TILE_H + sy;
 	if (ox < L.w && orow < L.n_rows)
 		T.dst[(unsigned long long)orow * T.pitch_px + ox] = l_tile[sy * TILE_W + sx];
+	/* what this tile cost, for the order of the NEXT frames' tiles (lol_gpu.hip, "longest tiles first") */
+	if (L.flags & FLAG_TILE_TABLE) {
+		u32* cost;
+#if defined(__HIP_DEVICE_COMPILE__)
+		{
+			typedef const __attribute__((address_space(4))) Launch* kernarg_ptr;
+			kernarg_ptr K = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+			asm volatile("" : "+s"(K));
+			cost = K->tile_cost;
+		}
+#else
+		cost = L.tile_cost;
+#endif
+		if (cost && threadIdx.x == 0) {
+			/* how long this wave ran: shader-clock ticks since start_tile_clock(), as 32 x log2 (5 fraction bits: steps of 2 %;
+			 * waves shorter than 1024 ticks all count 0) — at most 21 * 32 + 31 = 703, one bucket of the host's sort each */
+			const u32 dt = (u32)__builtin_readcyclecounter() - t_start;
+			const u32 e = 31u - (u32)__builtin_clz(dt | 1u);
+			cost[blockIdx.x] = e < 10u ? 0u : ((e - 10u) << 5 | ((dt >> (e - 5u)) & 31u));
+		}
+	}
+}
+
+/* FLAG_TILE_TABLE: when this block's wave started, parked in the first word of its (still unused) output tile in LDS rather
+ * than in a register for the whole kernel; store_pixel turns it into the tile's cost.  Call once, before the first shade_pixel
+ * (a wave that shades again through the plain path is timed over both passes: that is what it costs). */
+template <bool TABLES_GLOBAL = false>
+__device__ __forceinline__ void start_tile_clock(const Launch& L, u32* lds) {
+	if (L.flags & FLAG_TILE_TABLE) {
+		u32* l_tile = TABLES_GLOBAL ? lds : lds + L.n_lights * LIGHT_DWORDS + L.n_materials * MATERIAL_DWORDS + L.n_roots;
+		if (threadIdx.x == 0) l_tile[0] = (u32)__builtin_readcyclecounter();
+	}
 }
 
 /* stage lights | materials | root_material into `lds` (no barrier) */
@@ -1029,6 +1092,7 @@ void render_interp(const Launch L) {
 		stage_common(L, lds);
 		__syncthreads();
 	}
+	start_tile_clock<TABLES_GLOBAL>(L, lds);
 	Interp<SSIZE, KIND> sdf{ L.ops, L.n_ops, {}, 0u };
 	Pixel P = shade_pixel<Interp<SSIZE, KIND>, TABLES_GLOBAL>(L, sdf, lds);
 	if (KIND != 0 && unproven(sdf)) {

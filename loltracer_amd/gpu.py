@@ -57,14 +57,14 @@ class TileOrderInfo(C.Structure):
                 ("rows_ms", C.c_float), ("cols_ms", C.c_float)]
 
 
-TILES_ROWS, TILES_COLS, TILES_AUTO = 0, 1, 2
+TILES_ROWS, TILES_COLS, TILES_AUTO, TILES_LPT = 0, 1, 2, 3
 TILE_TRIALS = 16                     # LOL_GPU_TILE_TRIALS: trial frames per order (after 6 untimed ones)
 TILE_TRIAL_FRAMES = 6 + 2 * TILE_TRIALS
 
 
 def _tile_order_arg(order) -> int:
     if isinstance(order, str):
-        return {"rows": TILES_ROWS, "cols": TILES_COLS, "columns": TILES_COLS, "auto": TILES_AUTO}[order]
+        return {"rows": TILES_ROWS, "cols": TILES_COLS, "columns": TILES_COLS, "auto": TILES_AUTO, "lpt": TILES_LPT}[order]
     return int(order)                # False / True = rows / columns (the round-3 meaning of the argument), 2 = auto
 
 
@@ -447,7 +447,7 @@ class Renderer:
         """lol_gpu_tile_order: mode asked for, order in use, whether trials are still running, the two typical trial frames."""
         info = TileOrderInfo()
         self._check(self._lib.lol_gpu_tile_order(self._ctx, C.byref(info)))
-        names = {TILES_ROWS: "rows", TILES_COLS: "cols", TILES_AUTO: "auto"}
+        names = {TILES_ROWS: "rows", TILES_COLS: "cols", TILES_AUTO: "auto", TILES_LPT: "lpt"}
         return {"mode": names[info.mode], "order": names[info.order], "deciding": bool(info.deciding), "decisions": info.decisions,
                 "trial_ms": {"rows": round(info.rows_ms, 4), "cols": round(info.cols_ms, 4)}}
 
@@ -541,7 +541,7 @@ class MultiRenderer:
         st = self._lib.lol_gpu_tile_order(self._lib.lol_gpu_multi_context(self._m, i), C.byref(info))
         if st != LOL_GPU_OK:
             raise GpuError(st, "lol_gpu_tile_order")
-        names = {TILES_ROWS: "rows", TILES_COLS: "cols", TILES_AUTO: "auto"}
+        names = {TILES_ROWS: "rows", TILES_COLS: "cols", TILES_AUTO: "auto", TILES_LPT: "lpt"}
         return {"mode": names[info.mode], "order": names[info.order], "deciding": bool(info.deciding), "decisions": info.decisions,
                 "trial_ms": {"rows": round(info.rows_ms, 4), "cols": round(info.cols_ms, 4)}}
 

@@ -114,7 +114,7 @@ def test_multi_rank_record_schema():
     for rank in range(8):
         row = dict.fromkeys(bench.RANK_STATS, 0.0)
         row.update(rows=512 if rank == 0 else 544, frames=20, kernel_ms_avg=0.55 + 0.01 * rank, kernel_ms_min=0.54, kernel_ms_max=0.7,
-                   wall_ms_per_frame=0.68 if rank == 0 else 0.66, host_issue_us_per_frame=85.0, tile_order_cols=rank % 2,
+                   wall_ms_per_frame=0.68 if rank == 0 else 0.66, host_issue_us_per_frame=85.0, tile_order_code=3 if rank % 2 else 0,
                    tile_rows_ms=0.6, tile_cols_ms=0.58, tile_deciding=0)
         stats.append(row)
     f = bench.per_rank_fields(stats, 0.68)
@@ -123,7 +123,7 @@ def test_multi_rank_record_schema():
     for r in f["per_rank"]:
         assert set(r) >= {"rank", "rows", "frames", "kernel_ms_avg", "kernel_ms_min", "kernel_ms_max", "wall_ms_per_frame",
                           "exposed_ms_per_frame", "host_issue_us_per_frame", "tile_order", "tile_trial_ms"}
-    assert f["per_rank"][0]["rows"] == 512 and f["per_rank"][3]["tile_order"] == "cols"
+    assert f["per_rank"][0]["rows"] == 512 and f["per_rank"][3]["tile_order"] == "lpt" and f["per_rank"][2]["tile_order"] == "rows"
     assert f["kernel_ms"] == {"min": 0.55, "max": 0.62, "rank0": 0.55, "slowest_rank": 7}
     assert abs(f["gather_exposed_ms"] - 0.13) < 1e-9 and abs(f["per_rank"][0]["exposed_ms_per_frame"] - 0.13) < 1e-9
     # the names the record uses for the checks (bench.py main / run_cabi)
@@ -140,7 +140,7 @@ def _stats_worker(rank, world, port, q):
     try:
         mine = dict.fromkeys(bench.RANK_STATS, 0.0)
         mine.update(rows=100 + rank, frames=5, kernel_ms_avg=1.0 + rank, kernel_ms_min=0.9 + rank, kernel_ms_max=1.2 + rank,
-                    wall_ms_per_frame=1.5 + rank, tile_order_cols=rank == 1)
+                    wall_ms_per_frame=1.5 + rank, tile_order_code=1 if rank == 1 else 3)
         stats = bench.gather_rank_stats(mine, torch.device("cpu"))
         sums = bench.gather_checksums([rank * 7 + 1, -(2 ** 62) - rank], torch.device("cpu"))
         q.put((rank, stats, sums))
@@ -166,7 +166,7 @@ def test_rank_stats_and_checksums_reach_every_rank_over_gloo():
         assert p.exitcode == 0
     for rank, stats, sums in got:
         assert [s["rows"] for s in stats] == [100.0, 101.0, 102.0] and [s["kernel_ms_avg"] for s in stats] == [1.0, 2.0, 3.0]
-        assert [bool(s["tile_order_cols"]) for s in stats] == [False, True, False]
+        assert [int(s["tile_order_code"]) for s in stats] == [3, 1, 3]
         assert sums == [[1, -(2 ** 62)], [8, -(2 ** 62) - 1], [15, -(2 ** 62) - 2]]
     fields = bench.per_rank_fields(got[0][1], 3.6)
     assert fields["kernel_ms"]["slowest_rank"] == 2 and fields["per_rank"][1]["tile_order"] == "cols"

@@ -209,6 +209,8 @@ def test_tile_order_auto_decides_inside_the_library(torch_cuda, scenes):
     sc = scenes["scene4"]
     r = gpu.Renderer(0)
     r.prepare(sc)
+    assert r.tile_order()["mode"] == "lpt"                       # (the default is longest tiles first: next test)
+    r.set_tile_order("auto")
     info = r.tile_order()
     assert info["mode"] == "auto" and info["decisions"] == 0 and not info["deciding"]
     w, h = 320, 180
@@ -250,6 +252,67 @@ def test_tile_order_auto_decides_inside_the_library(torch_cuda, scenes):
     ox2, _, _ = O.render(scenes["scene"], w2, h2, threads=4)
     assert np.array_equal(buf2.cpu().numpy().view(np.uint32), ox2)
     r.close()
+
+
+@pytest.mark.parametrize("mode", [1, 4], ids=["spec", "interp"])
+def test_longest_tiles_first_renders_every_tile_exactly_once(torch_cuda, scenes, mode):
+    """lol_gpu_set_tile_order(LPT), the default: a launch hands its tiles out in the order of what they cost in the frames before
+    (sorted on the device from the run times the tiles report).  The order table must be a permutation of the frame's tiles
+    whatever the costs were: every frame — the first (row by row), the one after the first sort, the ones after later sorts,
+    after a resize, a new scene, a moving camera, with a row partition, into a pitched destination poisoned beforehand —
+    equals the frame of a context that hands its tiles out row by row, and the oracle's."""
+    torch = torch_cuda
+    a = gpu.Renderer(0, specialize=mode)
+    b = gpu.Renderer(0, specialize=mode)
+    b.set_tile_order("rows")
+    stream = torch.cuda.Stream()
+
+    def frames(sc, w, h, n, rows=None, cams=None, pitch_px=None):
+        pitch_px = pitch_px or w
+        n_rows = gpu.part_rows(h, rows)
+        got = torch.empty((n_rows, pitch_px), dtype=torch.int32, device="cuda")
+        want = torch.empty((n_rows, pitch_px), dtype=torch.int32, device="cuda")
+        for i in range(n):
+            cam = cams[i % len(cams)] if cams else None
+            with torch.cuda.stream(stream):
+                got.fill_(0x5A5A5A5A)
+                want.fill_(0x5A5A5A5A)
+            for r, buf in ((a, got), (b, want)):
+                r.render_into(buf.data_ptr(), w, h, rows=rows, camera=cam, pitch_bytes=pitch_px * 4, stream=stream.cuda_stream)
+            stream.synchronize()
+            assert torch.equal(got, want), (w, h, i)
+        return got.cpu().numpy().view(np.uint32)
+
+    sc = scenes["scene4"]
+    a.prepare(sc); b.prepare(sc)
+    assert a.tile_order()["mode"] == "lpt" and a.tile_order()["deciding"]
+    last = frames(sc, 333, 187, 11)                              # sizes that are no multiple of the tile: partial tiles at both edges
+    info = a.tile_order()
+    assert info["order"] == "lpt" and not info["deciding"] and info["decisions"] >= 3      # sorted after frame 1, 4, 8
+    ox, _, _ = O.render(sc, 333, 187, threads=4)
+    assert np.array_equal(last, ox)
+    frames(sc, 640, 360, 6, pitch_px=647)                         # resized, pitched: nothing written past the rows (poison intact = equal)
+    frames(sc, 200, 120, 6, rows=gpu.Rows(4, 12, 4))              # a row partition: the middle band of three
+    cams = []
+    for k in range(7):                                           # the camera moves every frame: the costs are always a little stale
+        cam = S.Camera()
+        C.memmove(C.byref(cam), C.byref(sc.c.camera), C.sizeof(cam))
+        cam.point.x += 0.4 * k
+        cams.append(cam)
+    frames(sc, 320, 180, 14, cams=cams)
+    sc2 = scenes["scene"]
+    a.prepare(sc2); b.prepare(sc2)
+    last = frames(sc2, 256, 144, 6)
+    ox, _, _ = O.render(sc2, 256, 144, threads=4)
+    assert np.array_equal(last, ox)
+    # a frame of the same geometry on ANOTHER stream is launched without the table (the tables belong to one stream): same frame
+    other = torch.cuda.Stream()
+    got = torch.zeros((144, 256), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    a.render_into(got.data_ptr(), 256, 144, stream=other.cuda_stream)
+    other.synchronize()
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), ox)
+    a.close(); b.close()
 
 
 def test_camera_beyond_the_sane_range(torch_cuda, renderer, scenes):

@@ -1,7 +1,7 @@
 # Round profile on the GPU box: kernel-trace stats + PMC passes of the default bench (C3) for BOTH kernels, the
 # other BASELINE workloads, and the summaries.  Everything lands under gpurun_out/prof_final; copy what is to be
-# judged into profiles/ (see profiles/README.md).   usage: bash tools/final_profile.sh [round-tag, default r3]
-TAG=${1:-r3}
+# judged into profiles/ (see profiles/README.md).   usage: bash tools/final_profile.sh [round-tag, default r4]
+TAG=${1:-r4}
 export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}; O=$R/gpurun_out/prof_final
 rm -rf "$O"; mkdir -p "$O"; cd /tmp
 export LOL_BENCH_HOST_SURFACE=0                     # the PMC passes time kernels; the host-surface leg has its own record
