@@ -197,6 +197,7 @@ struct lol_gpu {
 		int      cur = 0;
 		unsigned frames = 0, sorts = 0;      /* frames launched with this key; sorts done */
 		hipStream_t home = nullptr;          /* the stream these tables live on (lpt_table_for_frame) */
+		unsigned foreign = 0;                /* consecutive frames of this key launched on another stream */
 	} lpt;
 	char         err[512] = { 0 };
 	char         kernel_name[64] = "render_interp";
@@ -1839,11 +1840,18 @@ static const uint32_t* lpt_table_for_frame(lol_gpu* ctx, int w, int h, int max_s
 			T.cap = cap;
 		}
 		memcpy(T.key, key, sizeof key);
-		T.n_tiles = n; T.cur = 0; T.frames = 0; T.sorts = 0; T.home = s;
+		T.n_tiles = n; T.cur = 0; T.frames = 0; T.sorts = 0; T.home = s; T.foreign = 0;
 		hipLaunchKernelGGL(lpt_identity_kernel, dim3((n + LPT_THREADS - 1) / LPT_THREADS), dim3(LPT_THREADS), 0, s, T.d_order[0], n, tiles_x);
 		if (!ok(hipGetLastError()) || !ok(hipMemsetAsync(T.d_cost, 0, (size_t)n * 4, s))) { T.key[0] = 0; return nullptr; }
 	} else if (s != T.home) {
-		return nullptr;
+		/* a frame of this geometry on another stream: row by row — unless the host has moved over for good (the second such
+		 * frame in a row): then the tables move with it, once the old stream has run dry */
+		if (++T.foreign < 2 || !ok(hipStreamSynchronize(T.home))) return nullptr;
+		T.home = s;
+		T.foreign = 0;
+	}
+	if (T.frames == 0) {
+		/* (the first frame of a key: row by row through the identity table, nothing to sort yet) */
 	} else if (T.frames == 1 || (T.frames > 1 && T.frames % lpt_resort_period() == 0)) {
 		/* the costs of the frame before are in (same stream): three small kernels, then the other table is the current one */
 		const dim3 grid((n + LPT_THREADS - 1) / LPT_THREADS);
@@ -1854,6 +1862,7 @@ static const uint32_t* lpt_table_for_frame(lol_gpu* ctx, int w, int h, int max_s
 			if (ok(hipGetLastError())) { T.cur ^= 1; T.sorts++; }
 		}
 	}
+	T.foreign = 0;
 	T.frames++;
 	*cost_out = T.d_cost;
 	return T.d_order[T.cur];
