@@ -1751,19 +1751,20 @@ int lol_gpu_set_tile_order(lol_gpu* ctx, int order) {
  */
 constexpr unsigned LPT_BUCKETS = 1024, LPT_THREADS = 256, LPT_RESORT = 4;
 
-/* order[i] = tile i of the frame in row-major order, as column | row << 16 */
-__global__ __launch_bounds__(LPT_THREADS) void lpt_identity_kernel(uint32_t* order, uint32_t n, uint32_t tiles_x) {
+/* (the tables are stored XCD by XCD: lol_kernel.h, tile_slot)
+ * launch position i renders tile i of the frame in row-major order, as column | row << 16 */
+__global__ __launch_bounds__(LPT_THREADS) void lpt_identity_kernel(uint32_t* order, uint32_t n, uint32_t tiles_x, uint32_t stride) {
 	const uint32_t i = blockIdx.x * LPT_THREADS + threadIdx.x;
-	if (i < n) order[i] = (i % tiles_x) | (i / tiles_x) << 16;
+	if (i < n) order[lol::tile_slot(i, stride)] = (i % tiles_x) | (i / tiles_x) << 16;
 }
 /* pass 1: snapshot every block's cost as a bucket number (bucket 0 = the most expensive), count the buckets */
-__global__ __launch_bounds__(LPT_THREADS) void lpt_hist_kernel(const uint32_t* cost, uint32_t* keys, uint32_t* hist, uint32_t n) {
+__global__ __launch_bounds__(LPT_THREADS) void lpt_hist_kernel(const uint32_t* cost, uint32_t* keys, uint32_t* hist, uint32_t n, uint32_t stride) {
 	__shared__ uint32_t h[LPT_BUCKETS];
 	for (uint32_t b = threadIdx.x; b < LPT_BUCKETS; b += LPT_THREADS) h[b] = 0;
 	__syncthreads();
 	const uint32_t i = blockIdx.x * LPT_THREADS + threadIdx.x;
 	if (i < n) {
-		uint32_t k = cost[i];                                  /* <= 703 (lol_kernel.h, store_pixel); clamped all the same */
+		uint32_t k = cost[lol::tile_slot(i, stride)];          /* <= 703 (lol_kernel.h, store_pixel); clamped all the same */
 		k = LPT_BUCKETS - 1 - (k < LPT_BUCKETS ? k : LPT_BUCKETS - 1);
 		keys[i] = k;
 		atomicAdd(&h[k], 1u);
@@ -1788,7 +1789,7 @@ __global__ __launch_bounds__(LPT_BUCKETS) void lpt_scan_kernel(uint32_t* hist) {
 /* pass 3: every block reserves room for its members of each bucket with ONE atomic per bucket and places them in their
  * old order; what it places is the TILE the old table named for that launch position */
 __global__ __launch_bounds__(LPT_THREADS) void lpt_scatter_kernel(const uint32_t* keys, const uint32_t* order_in, uint32_t* order_out,
-                                                                  uint32_t* hist, uint32_t n) {
+                                                                  uint32_t* hist, uint32_t n, uint32_t stride) {
 	__shared__ uint32_t h[LPT_BUCKETS], base[LPT_BUCKETS];
 	for (uint32_t b = threadIdx.x; b < LPT_BUCKETS; b += LPT_THREADS) h[b] = 0;
 	__syncthreads();
@@ -1798,7 +1799,7 @@ __global__ __launch_bounds__(LPT_THREADS) void lpt_scatter_kernel(const uint32_t
 	__syncthreads();
 	for (uint32_t b = threadIdx.x; b < LPT_BUCKETS; b += LPT_THREADS) if (h[b]) base[b] = atomicAdd(&hist[LPT_BUCKETS + b], h[b]);
 	__syncthreads();
-	if (i < n) order_out[base[k] + rank] = order_in[i];
+	if (i < n) order_out[lol::tile_slot(base[k] + rank, stride)] = order_in[lol::tile_slot(i, stride)];
 }
 
 static unsigned lpt_resort_period() {
@@ -1832,7 +1833,7 @@ static const uint32_t* lpt_table_for_frame(lol_gpu* ctx, int w, int h, int max_s
 		if (T.key[0] && (n > T.cap || s != T.home) && !ok(hipDeviceSynchronize())) return nullptr;
 		if (n > T.cap) {
 			lpt_release(ctx);
-			const size_t cap = (size_t)n + n / 4 + 1024;
+			const size_t cap = (size_t)n + n / 4 + 1024;      /* (tile_slot reaches 8 * ceil(n / 8) - 1 < n + 8) */
 			const bool good = ok(hipMalloc(reinterpret_cast<void**>(&T.d_order[0]), cap * 4)) && ok(hipMalloc(reinterpret_cast<void**>(&T.d_order[1]), cap * 4)) &&
 			                  ok(hipMalloc(reinterpret_cast<void**>(&T.d_cost), cap * 4)) && ok(hipMalloc(reinterpret_cast<void**>(&T.d_keys), cap * 4)) &&
 			                  ok(hipMalloc(reinterpret_cast<void**>(&T.d_hist), 2 * LPT_BUCKETS * 4));
@@ -1841,8 +1842,8 @@ static const uint32_t* lpt_table_for_frame(lol_gpu* ctx, int w, int h, int max_s
 		}
 		memcpy(T.key, key, sizeof key);
 		T.n_tiles = n; T.cur = 0; T.frames = 0; T.sorts = 0; T.home = s; T.foreign = 0;
-		hipLaunchKernelGGL(lpt_identity_kernel, dim3((n + LPT_THREADS - 1) / LPT_THREADS), dim3(LPT_THREADS), 0, s, T.d_order[0], n, tiles_x);
-		if (!ok(hipGetLastError()) || !ok(hipMemsetAsync(T.d_cost, 0, (size_t)n * 4, s))) { T.key[0] = 0; return nullptr; }
+		hipLaunchKernelGGL(lpt_identity_kernel, dim3((n + LPT_THREADS - 1) / LPT_THREADS), dim3(LPT_THREADS), 0, s, T.d_order[0], n, tiles_x, (n + 7u) >> 3);
+		if (!ok(hipGetLastError()) || !ok(hipMemsetAsync(T.d_cost, 0, ((size_t)n + 8) * 4, s))) { T.key[0] = 0; return nullptr; }
 	} else if (s != T.home) {
 		/* a frame of this geometry on another stream: row by row — unless the host has moved over for good (the second such
 		 * frame in a row): then the tables move with it, once the old stream has run dry */
@@ -1856,9 +1857,10 @@ static const uint32_t* lpt_table_for_frame(lol_gpu* ctx, int w, int h, int max_s
 		/* the costs of the frame before are in (same stream): three small kernels, then the other table is the current one */
 		const dim3 grid((n + LPT_THREADS - 1) / LPT_THREADS);
 		if (ok(hipMemsetAsync(T.d_hist, 0, 2 * LPT_BUCKETS * 4, s))) {
-			hipLaunchKernelGGL(lpt_hist_kernel, grid, dim3(LPT_THREADS), 0, s, T.d_cost, T.d_keys, T.d_hist, n);
+			const uint32_t stride = (n + 7u) >> 3;
+			hipLaunchKernelGGL(lpt_hist_kernel, grid, dim3(LPT_THREADS), 0, s, T.d_cost, T.d_keys, T.d_hist, n, stride);
 			hipLaunchKernelGGL(lpt_scan_kernel, dim3(1), dim3(LPT_BUCKETS), 0, s, T.d_hist);
-			hipLaunchKernelGGL(lpt_scatter_kernel, grid, dim3(LPT_THREADS), 0, s, T.d_keys, T.d_order[T.cur], T.d_order[T.cur ^ 1], T.d_hist, n);
+			hipLaunchKernelGGL(lpt_scatter_kernel, grid, dim3(LPT_THREADS), 0, s, T.d_keys, T.d_order[T.cur], T.d_order[T.cur ^ 1], T.d_hist, n, stride);
 			if (ok(hipGetLastError())) { T.cur ^= 1; T.sorts++; }
 		}
 	}
@@ -2169,6 +2171,7 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 			L.flags |= lol::FLAG_TILE_TABLE;
 			L.tile_order = table;
 			L.tile_cost = cost;
+			L.tile_stride = (grid.x * grid.y + 7u) >> 3;
 			grid = dim3(grid.x * grid.y, 1);
 		}
 	} else if (tile_order_for_frame(ctx, w, h, max_steps, R, dbg != nullptr, &trial) == LOL_GPU_TILES_COLS) {

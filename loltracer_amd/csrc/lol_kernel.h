@@ -104,6 +104,7 @@ struct Launch {
 	 * receives what that block's wave cost: how long it ran (store_pixel) */
 	const u32* tile_order;
 	u32*   tile_cost;
+	u32    tile_stride;          /* both tables are indexed by tile_slot(block): ceil(blocks / 8) */
 };
 
 /* Fields of the launch arguments that only the last few instructions of a kernel need (destination, pitch, pixel
@@ -126,6 +127,13 @@ __device__ __forceinline__ LaunchTail launch_tail(const Launch& L0) {
 #endif
 }
 
+/* Where block b's entry lies in the launch's tile tables.  Consecutive blocks of a launch go to the 8 XCDs in turn, each with an
+ * L2 of its own: stored in block order, every XCD would fetch every line of the order table (8 x the table per frame) and the
+ * 4-byte cost of a block would be a 32-byte write transaction of its own.  Stored XCD by XCD — block b at (b mod 8) * stride +
+ * b / 8 — an XCD reads one contiguous eighth, and the costs its waves write fall into lines its L2 gathers before it writes
+ * them back.  (A layout, not an assumption anything but the traffic rests on.) */
+__device__ __forceinline__ u32 tile_slot(u32 b, u32 stride) { return (b & 7u) * stride + (b >> 3); }
+
 /* Which tile of the frame this block renders: its position in the grid (row by row, or column by column with
  * FLAG_TILE_COLS), or — FLAG_TILE_TABLE — what the launch's order table says for it: one scalar load, read where it is
  * needed (at the start for the pixel's coordinates, at the end for the store) like the other late fields. */
@@ -136,9 +144,9 @@ __device__ __forceinline__ void tile_of_block(const Launch& L0, int& bx, int& by
 		kernarg_ptr L = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
 		asm volatile("" : "+s"(L));
 		typedef const __attribute__((address_space(4))) u32* table_ptr;
-		const u32 pk = ((table_ptr)(unsigned long long)L->tile_order)[blockIdx.x];
+		const u32 pk = ((table_ptr)(unsigned long long)L->tile_order)[tile_slot(blockIdx.x, L->tile_stride)];
 #else
-		const u32 pk = L0.tile_order[blockIdx.x];
+		const u32 pk = L0.tile_order[tile_slot(blockIdx.x, L0.tile_stride)];
 #endif
 		bx = (int)(pk & 0xFFFFu);
 		by = (int)(pk >> 16);
@@ -1038,22 +1046,25 @@ __device__ __forceinline__ void store_pixel(const Launch& L, const Pixel& P, u32
 	/* what this tile cost, for the order of the NEXT frames' tiles (lol_gpu.hip, "longest tiles first") */
 	if (L.flags & FLAG_TILE_TABLE) {
 		u32* cost;
+		u32 stride;
 #if defined(__HIP_DEVICE_COMPILE__)
 		{
 			typedef const __attribute__((address_space(4))) Launch* kernarg_ptr;
 			kernarg_ptr K = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
 			asm volatile("" : "+s"(K));
 			cost = K->tile_cost;
+			stride = K->tile_stride;
 		}
 #else
 		cost = L.tile_cost;
+		stride = L.tile_stride;
 #endif
 		if (cost && threadIdx.x == 0) {
 			/* how long this wave ran: shader-clock ticks since start_tile_clock(), as 32 x log2 (5 fraction bits: steps of 2 %;
 			 * waves shorter than 1024 ticks all count 0) — at most 21 * 32 + 31 = 703, one bucket of the host's sort each */
 			const u32 dt = (u32)__builtin_readcyclecounter() - t_start;
 			const u32 e = 31u - (u32)__builtin_clz(dt | 1u);
-			cost[blockIdx.x] = e < 10u ? 0u : ((e - 10u) << 5 | ((dt >> (e - 5u)) & 31u));
+			cost[tile_slot(blockIdx.x, stride)] = e < 10u ? 0u : ((e - 10u) << 5 | ((dt >> (e - 5u)) & 31u));
 		}
 	}
 }
