@@ -198,6 +198,7 @@ struct lol_gpu {
 		unsigned frames = 0, sorts = 0;      /* frames launched with this key; sorts done */
 		hipStream_t home = nullptr;          /* the stream these tables live on (lpt_table_for_frame) */
 		unsigned foreign = 0;                /* consecutive frames of this key launched on another stream */
+		lol_frame_camera cam_last{}, cam_sorted{};   /* the camera of the last frame launched / of the frame whose costs the current table was sorted from */
 	} lpt;
 	char         err[512] = { 0 };
 	char         kernel_name[64] = "render_interp";
@@ -1749,7 +1750,7 @@ int lol_gpu_set_tile_order(lol_gpu* ctx, int order) {
  * camera by up to LPT_RESORT frames) 10,050 -> 10,300.  (The run time predicts better than the evaluation count, the first
  * cost tried: C3 8200.)
  */
-constexpr unsigned LPT_BUCKETS = 1024, LPT_THREADS = 256, LPT_RESORT = 4;
+constexpr unsigned LPT_BUCKETS = 1024, LPT_THREADS = 256, LPT_RESORT = 16;
 
 /* (the tables are stored XCD by XCD: lol_kernel.h, tile_slot)
  * launch position i renders tile i of the frame in row-major order, as column | row << 16 */
@@ -1819,7 +1820,7 @@ static void lpt_release(lol_gpu* ctx) {
  * about one set of tables happens on ONE stream — the one its first frame was launched on: frames, the costs they write
  * and the sorts that read them are then ordered by the stream itself, and a table is never rewritten under a frame that
  * still reads it.  A frame of the same key on another stream is simply launched without a table. */
-static const uint32_t* lpt_table_for_frame(lol_gpu* ctx, int w, int h, int max_steps, const lol_gpu_rows* R, int n_rows,
+static const uint32_t* lpt_table_for_frame(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h, int max_steps, const lol_gpu_rows* R, int n_rows,
                                            int tile_w, int tile_h, hipStream_t s, uint32_t** cost_out) {
 	lol_gpu::TileLpt& T = ctx->lpt;
 	*cost_out = nullptr;
@@ -1853,19 +1854,24 @@ static const uint32_t* lpt_table_for_frame(lol_gpu* ctx, int w, int h, int max_s
 	}
 	if (T.frames == 0) {
 		/* (the first frame of a key: row by row through the identity table, nothing to sort yet) */
-	} else if (T.frames == 1 || (T.frames > 1 && T.frames % lpt_resort_period() == 0)) {
-		/* the costs of the frame before are in (same stream): three small kernels, then the other table is the current one */
+	} else if (T.frames == 1 || memcmp(cam, &T.cam_sorted, sizeof *cam) != 0 || T.frames % lpt_resort_period() == 0) {
+		/* When to sort again: after the first frame of a key; whenever the camera has moved since the costs behind the current
+		 * table were taken (main.c:180: the host moves it between frames — the 256-frame orbit turns 1.4 degrees per frame, two
+		 * tiles' worth: an order four frames old is worse than the fixed column order there, 9800 against 10,130 Mpixels/s, a
+		 * fresh one a little better, 10,190); and every LPT_RESORT frames regardless (a still camera: nothing changes, the sort
+		 * is three small kernels).  The costs of the frame before are in (same stream); then the other table is the current one */
 		const dim3 grid((n + LPT_THREADS - 1) / LPT_THREADS);
 		if (ok(hipMemsetAsync(T.d_hist, 0, 2 * LPT_BUCKETS * 4, s))) {
 			const uint32_t stride = (n + 7u) >> 3;
 			hipLaunchKernelGGL(lpt_hist_kernel, grid, dim3(LPT_THREADS), 0, s, T.d_cost, T.d_keys, T.d_hist, n, stride);
 			hipLaunchKernelGGL(lpt_scan_kernel, dim3(1), dim3(LPT_BUCKETS), 0, s, T.d_hist);
 			hipLaunchKernelGGL(lpt_scatter_kernel, grid, dim3(LPT_THREADS), 0, s, T.d_keys, T.d_order[T.cur], T.d_order[T.cur ^ 1], T.d_hist, n, stride);
-			if (ok(hipGetLastError())) { T.cur ^= 1; T.sorts++; }
+			if (ok(hipGetLastError())) { T.cur ^= 1; T.sorts++; T.cam_sorted = T.cam_last; }
 		}
 	}
 	T.foreign = 0;
 	T.frames++;
+	T.cam_last = *cam;                       /* the camera the costs this frame writes belong to */
 	*cost_out = T.d_cost;
 	return T.d_order[T.cur];
 }
@@ -2167,7 +2173,7 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	int trial = -1;
 	if (ctx->tiles.mode == LOL_GPU_TILES_LPT) {
 		uint32_t* cost = nullptr;
-		if (const uint32_t* table = lpt_table_for_frame(ctx, w, h, max_steps, R, n_rows, tile_w, tile_h, s, &cost)) {
+		if (const uint32_t* table = lpt_table_for_frame(ctx, cam, w, h, max_steps, R, n_rows, tile_w, tile_h, s, &cost)) {
 			L.flags |= lol::FLAG_TILE_TABLE;
 			L.tile_order = table;
 			L.tile_cost = cost;
