@@ -260,13 +260,15 @@ int         lol_gpu_set_cull(lol_gpu* ctx, int enable);
 /*
  * The order in which a launch hands out its tiles of 16x4 pixels.  Same pixels in every order; the time differs, because a
  * frame is one launch of blocks that differ 100x in cost and ends with its slowest waves running on half-empty SIMDs.
- *   LOL_GPU_TILES_LPT (the default): longest tiles first.  Every tile reports how long its wave ran; a counting sort on the
- *     device (three small kernels on the frame's stream, after the first frame of a scene / frame size / row partition and
- *     every few frames from then on) orders the tiles of the following frames by decreasing cost — list scheduling with
- *     the last frames' costs, which a camera that moves a little per frame (main.c:70-112) changes little.  scene4 at 4K
- *     +8 % over the better of the two fixed orders, scene.lol at 1080p +30 %, the bands of an 8-way split of the 8K frame
- *     +16 %.  The first frame of a key is handed out row by row.  The tables live on the stream the
- *     first frame was launched on; frames of the same geometry on other streams are launched row by row.
+ *   LOL_GPU_TILES_LPT (the default): longest tiles first, while the camera stands still.  A frame under the same camera as
+ *     the frame before it goes through an order table and reports how long each tile's wave ran; a counting sort on the
+ *     device (three small kernels on the frame's stream) orders the tiles of the following frames by decreasing cost — list
+ *     scheduling with costs that are exact, because nothing moved.  scene4 at 4K +8 % over the better of the two fixed
+ *     orders, scene.lol at 1080p +30 %, the bands of an 8-way split of the 8K frame +16 %.  A frame whose
+ *     camera differs from its predecessor's is launched in the better fixed order (as LOL_GPU_TILES_AUTO finds it), with
+ *     no table, cost or sort: stale costs are worse than no costs (the reference's arrow keys turn the camera 5.7 degrees
+ *     a frame).  The tables live on the stream the first such frame was launched on; frames of the same geometry on
+ *     other streams are launched in the fixed order.
  *   LOL_GPU_TILES_ROWS / LOL_GPU_TILES_COLS: row by row / column by column (the launch grid transposed).
  *   LOL_GPU_TILES_AUTO: the better of those two, measured: the first frames of a (scene, frame size, row partition, max_steps)
  *     are launched in both orders alternately, each between two HIP events on its launch stream (LOL_GPU_TILE_TRIALS frames

@@ -198,7 +198,11 @@ struct lol_gpu {
 		unsigned frames = 0, sorts = 0;      /* frames launched with this key; sorts done */
 		hipStream_t home = nullptr;          /* the stream these tables live on (lpt_table_for_frame) */
 		unsigned foreign = 0;                /* consecutive frames of this key launched on another stream */
-		lol_frame_camera cam_last{}, cam_sorted{};   /* the camera of the last frame launched / of the frame whose costs the current table was sorted from */
+		lol_frame_camera cam_epoch{};        /* the view the tables' costs belong to */
+		int      last_key[7] = { 0, 0, 0, 0, 0, 0, 0 };
+		lol_frame_camera last_cam{};         /* the frame launched before this one: its key and view (lpt_table_for_frame: `still`) */
+		bool     have_last = false;
+		bool     last_table = false;         /* the last frame was launched through a table (lol_gpu_tile_order) */
 	} lpt;
 	char         err[512] = { 0 };
 	char         kernel_name[64] = "render_interp";
@@ -1730,6 +1734,7 @@ int lol_gpu_set_tile_order(lol_gpu* ctx, int order) {
 	T.key[0] = 0;                            /* ... and AUTO starts afresh at the next frame */
 	T.chosen = order == LOL_GPU_TILES_COLS ? LOL_GPU_TILES_COLS : LOL_GPU_TILES_ROWS;
 	ctx->lpt.key[0] = 0;                     /* longest-first starts afresh too (its tables stay allocated) */
+	ctx->lpt.have_last = false;
 	return LOL_GPU_OK;
 }
 
@@ -1815,11 +1820,22 @@ static void lpt_release(lol_gpu* ctx) {
 	T.cap = 0; T.n_tiles = 0; T.key[0] = 0;
 }
 
-/* The table for the frame about to be launched on `s` (device current), or nullptr: a row-by-row launch as before.  Sets
- * up (or re-creates) the tables when the scene, size, partition or kernel changed; sorts when it is time.  Everything
- * about one set of tables happens on ONE stream — the one its first frame was launched on: frames, the costs they write
- * and the sorts that read them are then ordered by the stream itself, and a table is never rewritten under a frame that
- * still reads it.  A frame of the same key on another stream is simply launched without a table. */
+/* The table for the frame about to be launched on `s` (device current), or nullptr: a launch in one of the fixed orders.
+ *
+ * Longest-first is for a camera that stands still: then a tile costs this frame exactly what it cost the frame before.
+ * Handed out by STALE costs the dear tiles come late, which is worse than any fixed order — measured on the 256-frame
+ * orbit taken at 1 / 2 / 4 / 8 frames per step (1.4 / 2.8 / 5.6 / 11 degrees; the reference's arrow keys turn the camera by
+ * atan(0.1) = 5.7 degrees a frame, main.c:70-112) with a sort before every frame: +3 % / -4 % / -7 % / -10 % against the
+ * column order, the +3 % being what is left of +7 % after paying for the sort (profiles/r4_orbit_stride_ab.jsonl,
+ * r4_lpt_verdict_ab.jsonl; a device-side verdict on how far the costs had moved was built and dropped: it needs the sort it
+ * wants to avoid).  So: a frame whose camera differs from the frame before it is launched in the fixed order (the caller
+ * falls back to AUTO's choice), without table, cost or sort — no overhead while the camera moves; the first frame under
+ * the camera of its predecessor goes through the row-order table and reports its tiles' costs; the next one is sorted.
+ *
+ * Sets up (or re-creates) the tables when the scene, size, partition or kernel changed.  Everything about one set of
+ * tables happens on ONE stream — the one its first frame was launched on: frames, the costs they write and the sorts that
+ * read them are then ordered by the stream itself, and a table is never rewritten under a frame that still reads it.  A
+ * frame of the same key on another stream is launched without a table, unless the host has moved over for good. */
 static const uint32_t* lpt_table_for_frame(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h, int max_steps, const lol_gpu_rows* R, int n_rows,
                                            int tile_w, int tile_h, hipStream_t s, uint32_t** cost_out) {
 	lol_gpu::TileLpt& T = ctx->lpt;
@@ -1828,8 +1844,15 @@ static const uint32_t* lpt_table_for_frame(lol_gpu* ctx, const lol_frame_camera*
 	const uint32_t n = tiles_x * tiles_y;
 	if (tiles_x > 0xFFFFu || tiles_y > 0xFFFFu) return nullptr;            /* (a tile is column | row << 16) */
 	const int key[7] = { w, h, max_steps, R->band_rows, R->cycle_rows, R->offset_rows, ctx->generation * 2 + (ctx->spec_fn ? 1 : 0) };
+	/* what the frame before this one was: the same view of the same frame? */
+	const bool still = T.have_last && memcmp(key, T.last_key, sizeof key) == 0 && memcmp(cam, &T.last_cam, sizeof *cam) == 0;
+	memcpy(T.last_key, key, sizeof key);
+	T.last_cam = *cam;
+	T.have_last = true;
+	if (!still) return nullptr;
 	auto ok = [](hipError_t e) { if (e != hipSuccess) (void)hipGetLastError(); return e == hipSuccess; };
-	if (memcmp(key, T.key, sizeof key) != 0) {
+	const bool new_key = memcmp(key, T.key, sizeof key) != 0;
+	if (new_key) {
 		/* frames of the old key may still read the tables, on their stream: drain the device before the tables change hands */
 		if (T.key[0] && (n > T.cap || s != T.home) && !ok(hipDeviceSynchronize())) return nullptr;
 		if (n > T.cap) {
@@ -1842,36 +1865,34 @@ static const uint32_t* lpt_table_for_frame(lol_gpu* ctx, const lol_frame_camera*
 			T.cap = cap;
 		}
 		memcpy(T.key, key, sizeof key);
-		T.n_tiles = n; T.cur = 0; T.frames = 0; T.sorts = 0; T.home = s; T.foreign = 0;
-		hipLaunchKernelGGL(lpt_identity_kernel, dim3((n + LPT_THREADS - 1) / LPT_THREADS), dim3(LPT_THREADS), 0, s, T.d_order[0], n, tiles_x, (n + 7u) >> 3);
-		if (!ok(hipGetLastError()) || !ok(hipMemsetAsync(T.d_cost, 0, ((size_t)n + 8) * 4, s))) { T.key[0] = 0; return nullptr; }
+		T.n_tiles = n; T.home = s; T.foreign = 0;
 	} else if (s != T.home) {
-		/* a frame of this geometry on another stream: row by row — unless the host has moved over for good (the second such
-		 * frame in a row): then the tables move with it, once the old stream has run dry */
+		/* a frame of this geometry on another stream: a fixed order — unless the host has moved over for good (the second
+		 * such frame in a row): then the tables move with it, once the old stream has run dry */
 		if (++T.foreign < 2 || !ok(hipStreamSynchronize(T.home))) return nullptr;
 		T.home = s;
 		T.foreign = 0;
 	}
-	if (T.frames == 0) {
-		/* (the first frame of a key: row by row through the identity table, nothing to sort yet) */
-	} else if (T.frames == 1 || memcmp(cam, &T.cam_sorted, sizeof *cam) != 0 || T.frames % lpt_resort_period() == 0) {
-		/* When to sort again: after the first frame of a key; whenever the camera has moved since the costs behind the current
-		 * table were taken (main.c:180: the host moves it between frames — the 256-frame orbit turns 1.4 degrees per frame, two
-		 * tiles' worth: an order four frames old is worse than the fixed column order there, 9800 against 10,130 Mpixels/s, a
-		 * fresh one a little better, 10,190); and every LPT_RESORT frames regardless (a still camera: nothing changes, the sort
-		 * is three small kernels).  The costs of the frame before are in (same stream); then the other table is the current one */
+	if (new_key || memcmp(cam, &T.cam_epoch, sizeof *cam) != 0) {
+		/* a view these tables have no costs for: the row order, and this frame reports its tiles' costs */
+		T.cam_epoch = *cam;
+		T.cur = 0; T.frames = 0;
+		hipLaunchKernelGGL(lpt_identity_kernel, dim3((n + LPT_THREADS - 1) / LPT_THREADS), dim3(LPT_THREADS), 0, s, T.d_order[0], n, tiles_x, (n + 7u) >> 3);
+		if (!ok(hipGetLastError()) || !ok(hipMemsetAsync(T.d_cost, 0, ((size_t)n + 8) * 4, s))) { T.key[0] = 0; return nullptr; }
+	} else if (T.frames == 1 || T.frames % lpt_resort_period() == 0) {
+		/* the costs of the frame before are in (same stream): three small kernels, then the other table is the current one.
+		 * (Again every LPT_RESORT frames: the run times drift a little with what runs beside a tile.) */
 		const dim3 grid((n + LPT_THREADS - 1) / LPT_THREADS);
 		if (ok(hipMemsetAsync(T.d_hist, 0, 2 * LPT_BUCKETS * 4, s))) {
 			const uint32_t stride = (n + 7u) >> 3;
 			hipLaunchKernelGGL(lpt_hist_kernel, grid, dim3(LPT_THREADS), 0, s, T.d_cost, T.d_keys, T.d_hist, n, stride);
 			hipLaunchKernelGGL(lpt_scan_kernel, dim3(1), dim3(LPT_BUCKETS), 0, s, T.d_hist);
 			hipLaunchKernelGGL(lpt_scatter_kernel, grid, dim3(LPT_THREADS), 0, s, T.d_keys, T.d_order[T.cur], T.d_order[T.cur ^ 1], T.d_hist, n, stride);
-			if (ok(hipGetLastError())) { T.cur ^= 1; T.sorts++; T.cam_sorted = T.cam_last; }
+			if (ok(hipGetLastError())) { T.cur ^= 1; T.sorts++; }
 		}
 	}
 	T.foreign = 0;
 	T.frames++;
-	T.cam_last = *cam;                       /* the camera the costs this frame writes belong to */
 	*cost_out = T.d_cost;
 	return T.d_order[T.cur];
 }
@@ -1910,7 +1931,7 @@ static void tile_auto_harvest(lol_gpu* ctx) {
 static int tile_order_for_frame(lol_gpu* ctx, int w, int h, int max_steps, const lol_gpu_rows* R, bool diagnostics, int* trial) {
 	lol_gpu::TileAuto& T = ctx->tiles;
 	*trial = -1;
-	if (T.mode != LOL_GPU_TILES_AUTO) return T.chosen;
+	if (T.mode != LOL_GPU_TILES_AUTO && T.mode != LOL_GPU_TILES_LPT) return T.chosen;
 	const int key[6] = { w, h, max_steps, R->band_rows, R->cycle_rows, ctx->generation * 2 + (ctx->spec_fn ? 1 : 0) };      /* (the kernel too: interpreter or the scene's own) */
 	if (memcmp(key, T.key, sizeof key) != 0) {          /* another scene, size or partition: measure again */
 		memcpy(T.key, key, sizeof key);
@@ -1935,9 +1956,13 @@ int lol_gpu_tile_order(lol_gpu* ctx, lol_gpu_tile_order_info* out) {
 	LOL_HIP(ctx, hipSetDevice(ctx->device));
 	tile_auto_harvest(ctx);
 	const lol_gpu::TileAuto& T = ctx->tiles;
-	if (T.mode == LOL_GPU_TILES_LPT)      /* longest first: "deciding" until the first sort has been queued (the first frame of a key runs row by row) */
-		*out = { T.mode, ctx->lpt.key[0] ? LOL_GPU_TILES_LPT : LOL_GPU_TILES_ROWS, ctx->lpt.sorts == 0 ? 1 : 0, (int32_t)ctx->lpt.sorts, 0.f, 0.f };
-	else
+	if (T.mode == LOL_GPU_TILES_LPT) {
+		/* longest first: the last frame went through a table (order LPT; "deciding" until its costs have been sorted once), or
+		 * the camera moves and AUTO's fixed order is in use (its state and trial times) */
+		const lol_gpu::TileLpt& P = ctx->lpt;
+		if (P.last_table) *out = { T.mode, LOL_GPU_TILES_LPT, P.frames < 2 ? 1 : 0, (int32_t)P.sorts, T.typical[0], T.typical[1] };
+		else *out = { T.mode, T.chosen, (T.deciding || P.sorts == 0) ? 1 : 0, (int32_t)P.sorts, T.typical[0], T.typical[1] };
+	} else
 		*out = { T.mode, T.chosen, T.deciding ? 1 : 0, T.decisions, T.typical[0], T.typical[1] };
 	return LOL_GPU_OK;
 }
@@ -2171,16 +2196,20 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	dim3 grid((w + tile_w - 1) / tile_w, (n_rows + tile_h - 1) / tile_h);
 	const size_t common = (size_t)(lol::common_lds_dwords(P.n_lights, P.n_materials, P.n_roots) - lol::TILE_W * lol::TILE_H + block) * 4;
 	int trial = -1;
+	const uint32_t* table = nullptr;
 	if (ctx->tiles.mode == LOL_GPU_TILES_LPT) {
 		uint32_t* cost = nullptr;
-		if (const uint32_t* table = lpt_table_for_frame(ctx, cam, w, h, max_steps, R, n_rows, tile_w, tile_h, s, &cost)) {
+		if ((table = lpt_table_for_frame(ctx, cam, w, h, max_steps, R, n_rows, tile_w, tile_h, s, &cost)) != nullptr) {
 			L.flags |= lol::FLAG_TILE_TABLE;
 			L.tile_order = table;
 			L.tile_cost = cost;
 			L.tile_stride = (grid.x * grid.y + 7u) >> 3;
 			grid = dim3(grid.x * grid.y, 1);
 		}
-	} else if (tile_order_for_frame(ctx, w, h, max_steps, R, dbg != nullptr, &trial) == LOL_GPU_TILES_COLS) {
+	}
+	ctx->lpt.last_table = table != nullptr;
+	/* (longest-first without a table — the camera moves, or another stream —: the better of the two fixed orders, like AUTO) */
+	if (!table && tile_order_for_frame(ctx, w, h, max_steps, R, dbg != nullptr, &trial) == LOL_GPU_TILES_COLS) {
 		L.flags |= lol::FLAG_TILE_COLS;
 		const unsigned t = grid.x; grid.x = grid.y; grid.y = t;      /* (both stay far below the 65535 blocks a grid may have in y) */
 	}

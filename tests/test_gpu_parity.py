@@ -256,8 +256,8 @@ def test_tile_order_auto_decides_inside_the_library(torch_cuda, scenes):
 
 @pytest.mark.parametrize("mode", [1, 4], ids=["spec", "interp"])
 def test_longest_tiles_first_renders_every_tile_exactly_once(torch_cuda, scenes, mode):
-    """lol_gpu_set_tile_order(LPT), the default: a launch hands its tiles out in the order of what they cost in the frames before
-    (sorted on the device from the run times the tiles report).  The order table must be a permutation of the frame's tiles
+    """lol_gpu_set_tile_order(LPT), the default: while the camera stands still a launch hands its tiles out in the order of what
+    they cost in the frame before (sorted on the device from the run times the tiles report); while it moves, in a fixed order.  The order table must be a permutation of the frame's tiles
     whatever the costs were: every frame — the first (row by row), the one after the first sort, the ones after later sorts,
     after a resize, a new scene, a moving camera, with a row partition, into a pitched destination poisoned beforehand —
     equals the frame of a context that hands its tiles out row by row, and the oracle's."""
@@ -294,13 +294,18 @@ def test_longest_tiles_first_renders_every_tile_exactly_once(torch_cuda, scenes,
     frames(sc, 640, 360, 6, pitch_px=647)                         # resized, pitched: nothing written past the rows (poison intact = equal)
     frames(sc, 200, 120, 6, rows=gpu.Rows(4, 12, 4))              # a row partition: the middle band of three
     cams = []
-    for k in range(7):                                           # the camera moves every frame: the costs are always a little stale
+    for k in range(7):                                           # the camera moves every frame: costs of another view are no prediction
         cam = S.Camera()
         C.memmove(C.byref(cam), C.byref(sc.c.camera), C.sizeof(cam))
         cam.point.x += 0.4 * k
         cams.append(cam)
+    sorts = a.tile_order()["decisions"]
     frames(sc, 320, 180, 14, cams=cams)
-    assert a.tile_order()["decisions"] == 13                     # ... and every frame sorts again (the first one has nothing to sort)
+    info = a.tile_order()
+    assert info["decisions"] == sorts and info["order"] in ("rows", "cols")      # a moving camera: a fixed order, nothing is sorted
+    frames(sc, 320, 180, 4, cams=cams[3:4])                      # ... it stops: one frame reports its costs, the next is sorted
+    info = a.tile_order()
+    assert info["decisions"] == sorts + 1 and info["order"] == "lpt" and not info["deciding"]
     sc2 = scenes["scene"]
     a.prepare(sc2); b.prepare(sc2)
     last = frames(sc2, 256, 144, 6)

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--workloads", default="c3,c2,c4,orbit,band")
     ap.add_argument("--kernels", default="spec,interp")
     ap.add_argument("--frames", type=int, default=100)
+    ap.add_argument("--orbit-stride", type=int, default=1, help="orbit: every n-th frame of the 256 (what one of n ranks renders)")
     a = ap.parse_args()
     for wl in a.workloads.split(","):
         band = wl == "band"                              # rank 0's share of a C4 frame over 8 ranks, one launch
@@ -29,13 +30,13 @@ def main():
         sc = S.Scene.parse_file(os.path.join(ROOT, "tests", "golden", "scenes", cfg["scene"] + ".lol"))
         rows = gpu.Rows(16, 128, 0) if band else None
         n_rows = gpu.part_rows(h, rows)
-        cams = [sc.frame_camera(w, h, bench.orbit_camera(i, 256)) for i in range(256)] if wl == "orbit" else [sc.frame_camera(w, h)]
+        cams = [sc.frame_camera(w, h, bench.orbit_camera(i, 256)) for i in range(0, 256, a.orbit_stride)] if wl == "orbit" else [sc.frame_camera(w, h)]
         for kern in a.kernels.split(","):
             r = gpu.Renderer(0, specialize=1 if kern == "spec" else 4)
             r.prepare(sc)
             stream = torch.cuda.Stream()
             buf = torch.zeros((n_rows, w), dtype=torch.int32, device="cuda")
-            out = {"workload": wl, "kernel": r.kernel_name(), "pixels_per_frame": n_rows * w}
+            out = {"workload": wl + (f" stride {a.orbit_stride}" if wl == "orbit" else ""), "kernel": r.kernel_name(), "pixels_per_frame": n_rows * w}
             ref = None
             for order in ("rows", "cols", "lpt"):
                 r.set_tile_order(order)
