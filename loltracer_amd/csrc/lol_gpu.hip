@@ -179,10 +179,17 @@ struct lol_gpu {
 		int   key[6] = { 0, 0, 0, 0, 0, 0 };    /* w, h, max_steps, band_rows, cycle_rows, program generation */
 		int   issued = 0, harvested = 0, decisions = 0;
 		static constexpr int SKIP = 6, TOTAL = SKIP + 2 * LOL_GPU_TILE_TRIALS;
+		/* trial i: untimed row-order frames first, then pairs (rows, columns), (columns, rows), (rows, columns) ... */
+		static constexpr int order_of_trial(int i) { return i < SKIP ? LOL_GPU_TILES_ROWS : ((((i - SKIP) >> 1) ^ (i - SKIP)) & 1); }
 		hipEvent_t ev[2 * TOTAL] = {};          /* start / end of trial frame i at [2i], [2i + 1]; created on first use */
 		bool  have_events = false;
 		float ms[TOTAL] = {};
 		float typical[2] = { 0.f, 0.f };
+		/* after the decision: a timed pair (order in use, other order) every MONITOR_PERIOD frames (tile_order_for_frame) */
+		static constexpr unsigned MONITOR_PERIOD = 8, MONITOR_WINDOW = 5;
+		unsigned mon_frames = 0, mon_n = 0, swaps = 0;
+		bool  mon_pending = false;
+		float mon_ratio[MONITOR_WINDOW] = {};
 	} tiles;
 	int          generation = 0;         /* uploads so far */
 	/* LOL_GPU_TILES_LPT: longest tiles first ("longest tiles first" below) */
@@ -1910,19 +1917,33 @@ static void tile_auto_harvest(lol_gpu* ctx) {
 		T.harvested++;
 	}
 	if (T.harvested < lol_gpu::TileAuto::TOTAL) return;
-	/* the typical frame of each order: the mean of the faster half of its trials (a frame that shared the device with
-	 * something else, or ran before the clocks had settled, does not vote) */
+	/* the typical frame of each order (reported): the mean of the faster half of its trials (a frame that shared the device
+	 * with something else, or ran before the clocks had settled, does not count) */
 	for (int o = 0; o < 2; o++) {
 		float v[LOL_GPU_TILE_TRIALS];
 		int n = 0;
-		for (int i = lol_gpu::TileAuto::SKIP + o; i < lol_gpu::TileAuto::TOTAL; i += 2) if (T.ms[i] > 0.f) v[n++] = T.ms[i];
+		for (int i = lol_gpu::TileAuto::SKIP; i < lol_gpu::TileAuto::TOTAL; i++) if (lol_gpu::TileAuto::order_of_trial(i) == o && T.ms[i] > 0.f) v[n++] = T.ms[i];
 		std::sort(v, v + n);
 		const int half = n > 1 ? n / 2 : n;
 		float sum = 0.f;
 		for (int i = 0; i < half; i++) sum += v[i];
 		T.typical[o] = half ? sum / (float)half : 0.f;
 	}
-	T.chosen = (T.typical[0] > 0.f && T.typical[1] > 0.f && T.typical[1] < 0.99f * T.typical[0]) ? LOL_GPU_TILES_COLS : LOL_GPU_TILES_ROWS;
+	/* The decision: the trials come in PAIRS of consecutive frames, one of each order — a host whose camera moves (the orbit: a
+	 * frame costs 0.7 to 1.0 ms depending on where the camera is) renders nearly the same view twice in a pair, so the ratio
+	 * columns / rows of a pair is about the orders and not about the view; which order goes first alternates from pair to
+	 * pair, so a cost that drifts one way cancels; the median ratio decides (round 4: the means of two interleaved series
+	 * picked rows for the orbit, 4 % behind). */
+	float ratio[LOL_GPU_TILE_TRIALS];
+	int n_ratios = 0;
+	for (int i = lol_gpu::TileAuto::SKIP; i + 1 < lol_gpu::TileAuto::TOTAL; i += 2) {
+		const float a = T.ms[i], b = T.ms[i + 1];
+		if (!(a > 0.f && b > 0.f)) continue;
+		ratio[n_ratios++] = lol_gpu::TileAuto::order_of_trial(i) == LOL_GPU_TILES_ROWS ? b / a : a / b;      /* columns / rows */
+	}
+	std::sort(ratio, ratio + n_ratios);
+	const float median = n_ratios ? (n_ratios & 1 ? ratio[n_ratios / 2] : 0.5f * (ratio[n_ratios / 2 - 1] + ratio[n_ratios / 2])) : 1.f;
+	T.chosen = median < 0.99f ? LOL_GPU_TILES_COLS : LOL_GPU_TILES_ROWS;
 	T.deciding = false;
 	T.decisions++;
 }
@@ -1944,11 +1965,49 @@ static int tile_order_for_frame(lol_gpu* ctx, int w, int h, int max_steps, const
 		T.deciding = true;
 		T.issued = T.harvested = 0;
 		T.chosen = LOL_GPU_TILES_ROWS;
+		T.mon_frames = T.mon_n = 0;
+		T.mon_pending = false;
 	}
 	tile_auto_harvest(ctx);
-	if (!T.deciding || T.issued >= lol_gpu::TileAuto::TOTAL || diagnostics) return T.chosen;
-	*trial = T.issued++;
-	return *trial < lol_gpu::TileAuto::SKIP ? LOL_GPU_TILES_ROWS : ((*trial - lol_gpu::TileAuto::SKIP) & 1);
+	if (T.deciding) {
+		if (T.issued >= lol_gpu::TileAuto::TOTAL || diagnostics) return T.chosen;
+		*trial = T.issued++;
+		return lol_gpu::TileAuto::order_of_trial(*trial);
+	}
+	/* Decided — and watched from then on: which fixed order is better depends on the VIEW as well (the orbit's first forty
+	 * frames favour rows by 5 %, the orbit as a whole columns by 3.5 %), and the host moves the camera (main.c:180).  Every
+	 * MONITOR_PERIOD frames one frame in the order in use and the next one in the other order are timed like trial frames
+	 * (two event pairs, collected without waiting); when the other order has been faster by more than 1 % in the median of
+	 * the last MONITOR_WINDOW such pairs, the orders change places.  A probe frame costs what the orders differ by. */
+	if (diagnostics) return T.chosen;
+	if (T.mon_pending) {
+		if (hipEventQuery(T.ev[3]) == hipSuccess) {
+			float a = 0.f, b = 0.f;
+			if (hipEventElapsedTime(&a, T.ev[0], T.ev[1]) == hipSuccess && hipEventElapsedTime(&b, T.ev[2], T.ev[3]) == hipSuccess && a > 0.f && b > 0.f) {
+				T.mon_ratio[T.mon_n % lol_gpu::TileAuto::MONITOR_WINDOW] = b / a;      /* other / in use */
+				T.mon_n++;
+				if (T.mon_n >= lol_gpu::TileAuto::MONITOR_WINDOW) {
+					float r[lol_gpu::TileAuto::MONITOR_WINDOW];
+					memcpy(r, T.mon_ratio, sizeof r);
+					std::sort(r, r + lol_gpu::TileAuto::MONITOR_WINDOW);
+					if (r[lol_gpu::TileAuto::MONITOR_WINDOW / 2] < 0.99f) {
+						T.chosen = T.chosen == LOL_GPU_TILES_COLS ? LOL_GPU_TILES_ROWS : LOL_GPU_TILES_COLS;
+						T.mon_n = 0;
+						T.swaps++;
+					}
+				}
+			} else (void)hipGetLastError();
+			T.mon_pending = false;
+		} else { (void)hipGetLastError(); return T.chosen; }      /* (the pair is still in flight: no new one) */
+	}
+	const unsigned phase = T.mon_frames++ % lol_gpu::TileAuto::MONITOR_PERIOD;
+	if (phase == lol_gpu::TileAuto::MONITOR_PERIOD - 2) { *trial = 0; return T.chosen; }
+	if (phase == lol_gpu::TileAuto::MONITOR_PERIOD - 1) {
+		*trial = 1;
+		T.mon_pending = true;
+		return T.chosen == LOL_GPU_TILES_COLS ? LOL_GPU_TILES_ROWS : LOL_GPU_TILES_COLS;
+	}
+	return T.chosen;
 }
 
 int lol_gpu_tile_order(lol_gpu* ctx, lol_gpu_tile_order_info* out) {
