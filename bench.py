@@ -300,7 +300,8 @@ def both_kernels(r, sc, spec_frame, w, h, max_steps, fc, stream, spec_ms, px, fr
             out["note"] = f"the second renderer runs {ri.kernel_name()} too (LOL_GPU_SPECIALIZE / hipRTC): no second kernel timed"
             return out
         buf = torch.zeros_like(spec_frame)
-        ri.render_into(buf.data_ptr(), w, h, max_steps, stream=stream, frame_camera=fc)      # warm-up
+        for _ in range(8):                                # warm-up: the view repeats, so the library's tables settle (three frames)
+            ri.render_into(buf.data_ptr(), w, h, max_steps, stream=stream, frame_camera=fc)
         ev = []
         for _ in range(frames):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -200,6 +200,9 @@ struct lol_gpu {
 		uint32_t* d_cost = nullptr;          /* what the blocks of the last frame cost, by launch position */
 		uint32_t* d_keys = nullptr;          /* the sort's snapshot of the costs (bucket numbers) */
 		uint32_t* d_hist = nullptr;          /* 2 x LPT_BUCKETS: bucket sizes, then the scatter's cursors */
+		uint32_t* d_lanes = nullptr;         /* the pixel table: 64 entries per wave slot ("pixels dealt by cost") */
+		unsigned short* d_pixel_cost = nullptr;   /* what every pixel of the view's first frame cost */
+		size_t   lanes_cap = 0, pixels_cap = 0;
 		size_t   cap = 0;                    /* tiles the buffers hold */
 		int      cur = 0;
 		unsigned frames = 0, sorts = 0;      /* frames launched with this key; sorts done */
@@ -1132,7 +1135,7 @@ std::string generate_source(const lol_program& P, const FastPaths* fast, bool cu
 		s += "\tlol::stage_common(L, lds);\n";
 		s += "\t__syncthreads();\n";
 	}
-	s += "\tlol::start_tile_clock<" + tg + ">(L, lds);\n";
+	s += "\tif (!lol::start_tile_clock<" + tg + ">(L, lds)) return;\n";
 	if (any_fast) {
 		s += "\tlol::SpecSdfFast fast;\n";
 		s += "\tlol::Pixel P = lol::shade_pixel<lol::SpecSdfFast, " + tg + ">(L, fast, lds);\n";
@@ -1765,10 +1768,83 @@ int lol_gpu_set_tile_order(lol_gpu* ctx, int order) {
 constexpr unsigned LPT_BUCKETS = 1024, LPT_THREADS = 256, LPT_RESORT = 16;
 
 /* (the tables are stored XCD by XCD: lol_kernel.h, tile_slot)
- * launch position i renders tile i of the frame in row-major order, as column | row << 16 */
-__global__ __launch_bounds__(LPT_THREADS) void lpt_identity_kernel(uint32_t* order, uint32_t n, uint32_t tiles_x, uint32_t stride) {
+ * launch position i shades wave slot i */
+__global__ __launch_bounds__(LPT_THREADS) void lpt_identity_kernel(uint32_t* order, uint32_t n, uint32_t stride) {
 	const uint32_t i = blockIdx.x * LPT_THREADS + threadIdx.x;
-	if (i < n) order[lol::tile_slot(i, stride)] = (i % tiles_x) | (i / tiles_x) << 16;
+	if (i < n) order[lol::tile_slot(i, stride)] = i;
+}
+
+/*
+ * Pixels dealt by cost.  A wave runs every loop to its slowest lane: the 16x4 pixels of a rectangle execute 66.9 SDF
+ * evaluations per pixel on C3 where their pixels need 57.0 — lane efficiency 0.85, 0.79 in the shadow marches, whose long
+ * tails are single pixels (a ray grazing a surface) among quick neighbours.  For a camera that stands still the step
+ * counts of the frame before are EXACT, so the pixels can be dealt to waves ahead of time: the frame is cut into regions
+ * of REGION_W x REGION_H pixels (16 waves' worth), the pixels of a region are sorted by the evaluations they needed, and
+ * wave k of the region gets the k-th 64 of them — waves of like pixels, no compaction at run time, and still neighbours
+ * within 64 x 16 pixels (the culling votes of a wave keep working: pixels of like cost are pixels of like fate).  The
+ * oracle's step counts put the evaluations a frame executes at -11.4 % for this region size (-9.3 % for 32 x 8, -11.2 %
+ * for 128 x 32; keeping runs of 2 / 4 / 8 adjacent pixels together leaves -7.7 / -4.6 / -2.2 %: the stragglers really are
+ * single pixels — tests/tools/sorted_region_model.py, profiles/r4_sorted_region_model.json).  The price is memory traffic,
+ * of which this path has 250x to spare: a 4-byte table entry read per pixel, and every lane storing its own pixel.
+ * lane_pixels[64 * slot + lane] = column | local row << 16 | LANE_PADDING; wave slot = 16 * region + k.
+ */
+struct RegionShape { uint32_t w, h; };       /* multiples of 16 x 4; w * h a power of two <= 4096 (the sort's LDS) */
+static RegionShape region_shape() {
+	static const RegionShape shape = [] {
+		RegionShape r = { 64, 16 };
+		if (const char* e = getenv("LOL_GPU_REGION")) {      /* WxH, for A/B runs */
+			unsigned a = 0, b = 0;
+			if (sscanf(e, "%ux%u", &a, &b) == 2 && a % 16 == 0 && b % 4 == 0 && a * b >= 64 && a * b <= 4096 && ((a * b) & (a * b - 1)) == 0) r = { a, b };
+		}
+		return r;
+	}();
+	return shape;
+}
+
+/* the first frame of a view: wave k of a region = its k-th 16x4 rectangle (what a launch without tables shades) */
+__global__ __launch_bounds__(LPT_THREADS) void deal_rectangles_kernel(uint32_t* lane_pixels, uint32_t n_lanes, uint32_t w, uint32_t n_rows, uint32_t regions_x,
+                                                                      uint32_t REGION_W, uint32_t REGION_H) {
+	const uint32_t REGION_PIXELS = REGION_W * REGION_H;
+	const uint32_t i = blockIdx.x * LPT_THREADS + threadIdx.x;
+	if (i >= n_lanes) return;
+	const uint32_t region = i / REGION_PIXELS, j = i % REGION_PIXELS, k = j / 64, lane = j % 64;
+	uint32_t x = (region % regions_x) * REGION_W + (k % (REGION_W / 16)) * 16 + lane % 16;
+	uint32_t r = (region / regions_x) * REGION_H + (k / (REGION_W / 16)) * 4 + lane / 16;
+	uint32_t pad = 0;
+	if (x >= w) { x = w - 1; pad = lol::LANE_PADDING; }
+	if (r >= n_rows) { r = n_rows - 1; pad = lol::LANE_PADDING; }
+	lane_pixels[i] = x | r << 16 | pad;
+}
+/* one block per region: sort its pixels by what they cost (bitonic, in LDS; the pixels beyond the frame's edge first) and
+ * deal them to the region's waves in that order */
+__global__ __launch_bounds__(LPT_THREADS) void deal_by_cost_kernel(const unsigned short* pixel_cost, uint32_t* lane_pixels, uint32_t w, uint32_t n_rows,
+                                                                   uint32_t regions_x, uint32_t REGION_W, uint32_t REGION_H) {
+	__shared__ uint32_t key[4096];                         /* cost + 1 (0 = beyond the edge) << 12 | position in the region */
+	const uint32_t REGION_PIXELS = REGION_W * REGION_H;
+	const uint32_t region = blockIdx.x, x0 = (region % regions_x) * REGION_W, r0 = (region / regions_x) * REGION_H;
+	for (uint32_t j = threadIdx.x; j < REGION_PIXELS; j += LPT_THREADS) {
+		const uint32_t x = x0 + j % REGION_W, r = r0 + j / REGION_W;
+		const uint32_t c = (x < w && r < n_rows) ? (uint32_t)pixel_cost[(size_t)r * w + x] + 1u : 0u;
+		key[j] = c << 12 | j;
+	}
+	__syncthreads();
+	for (uint32_t k = 2; k <= REGION_PIXELS; k <<= 1)
+		for (uint32_t d = k >> 1; d > 0; d >>= 1) {
+			for (uint32_t t = threadIdx.x; t < REGION_PIXELS / 2; t += LPT_THREADS) {
+				const uint32_t lo = 2 * t - (t & (d - 1)), hi = lo + d;      /* the pair (lo, lo + d) of this compare-exchange network step */
+				const bool up = (lo & k) == 0;
+				const uint32_t a = key[lo], b = key[hi];
+				if ((a > b) == up) { key[lo] = b; key[hi] = a; }
+			}
+			__syncthreads();
+		}
+	for (uint32_t j = threadIdx.x; j < REGION_PIXELS; j += LPT_THREADS) {
+		const uint32_t q = key[j] & (REGION_PIXELS - 1);
+		uint32_t x = x0 + q % REGION_W, r = r0 + q / REGION_W, pad = 0;
+		if (x >= w) { x = w - 1; pad = lol::LANE_PADDING; }
+		if (r >= n_rows) { r = n_rows - 1; pad = lol::LANE_PADDING; }
+		lane_pixels[(size_t)region * REGION_PIXELS + j] = x | r << 16 | pad;
+	}
 }
 /* pass 1: snapshot every block's cost as a bucket number (bucket 0 = the most expensive), count the buckets */
 __global__ __launch_bounds__(LPT_THREADS) void lpt_hist_kernel(const uint32_t* cost, uint32_t* keys, uint32_t* hist, uint32_t n, uint32_t stride) {
@@ -1822,9 +1898,10 @@ static unsigned lpt_resort_period() {
 
 static void lpt_release(lol_gpu* ctx) {
 	lol_gpu::TileLpt& T = ctx->lpt;
-	for (uint32_t** p : { &T.d_order[0], &T.d_order[1], &T.d_cost, &T.d_keys, &T.d_hist })
+	for (uint32_t** p : { &T.d_order[0], &T.d_order[1], &T.d_cost, &T.d_keys, &T.d_hist, &T.d_lanes })
 		if (*p) { (void)hipFree(*p); *p = nullptr; }
-	T.cap = 0; T.n_tiles = 0; T.key[0] = 0;
+	if (T.d_pixel_cost) { (void)hipFree(T.d_pixel_cost); T.d_pixel_cost = nullptr; }
+	T.cap = 0; T.lanes_cap = 0; T.pixels_cap = 0; T.n_tiles = 0; T.key[0] = 0;
 }
 
 /* The table for the frame about to be launched on `s` (device current), or nullptr: a launch in one of the fixed orders.
@@ -1843,55 +1920,71 @@ static void lpt_release(lol_gpu* ctx) {
  * tables happens on ONE stream — the one its first frame was launched on: frames, the costs they write and the sorts that
  * read them are then ordered by the stream itself, and a table is never rewritten under a frame that still reads it.  A
  * frame of the same key on another stream is launched without a table, unless the host has moved over for good. */
-static const uint32_t* lpt_table_for_frame(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h, int max_steps, const lol_gpu_rows* R, int n_rows,
-                                           int tile_w, int tile_h, hipStream_t s, uint32_t** cost_out) {
+struct FrameTables { const uint32_t* order; uint32_t* cost; const uint32_t* lanes; unsigned short* pixel_cost; uint32_t n_waves; };
+
+static bool lpt_table_for_frame(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h, int max_steps, const lol_gpu_rows* R, int n_rows,
+                                int block, hipStream_t s, FrameTables* out) {
 	lol_gpu::TileLpt& T = ctx->lpt;
-	*cost_out = nullptr;
-	const uint32_t tiles_x = (uint32_t)((w + tile_w - 1) / tile_w), tiles_y = (uint32_t)((n_rows + tile_h - 1) / tile_h);
-	const uint32_t n = tiles_x * tiles_y;
-	if (tiles_x > 0xFFFFu || tiles_y > 0xFFFFu) return nullptr;            /* (a tile is column | row << 16) */
+	const uint32_t REGION_W = region_shape().w, REGION_H = region_shape().h, REGION_WAVES = REGION_W * REGION_H / 64;
+	const uint32_t regions_x = ((uint32_t)w + REGION_W - 1) / REGION_W, regions_y = ((uint32_t)n_rows + REGION_H - 1) / REGION_H;
+	const uint32_t n = regions_x * regions_y * REGION_WAVES;            /* wave slots = blocks of the launch */
+	const size_t n_lanes = (size_t)n * 64, n_pixels = (size_t)w * (size_t)n_rows;
+	if (block != 64 || w > 0xFFFF || n_rows > 0x7FFF || n_lanes > 0xFFFFFFFFull) return false;      /* (an entry is column | row << 16 | flag; one-wave blocks) */
 	const int key[7] = { w, h, max_steps, R->band_rows, R->cycle_rows, R->offset_rows, ctx->generation * 2 + (ctx->spec_fn ? 1 : 0) };
 	/* what the frame before this one was: the same view of the same frame? */
 	const bool still = T.have_last && memcmp(key, T.last_key, sizeof key) == 0 && memcmp(cam, &T.last_cam, sizeof *cam) == 0;
 	memcpy(T.last_key, key, sizeof key);
 	T.last_cam = *cam;
 	T.have_last = true;
-	if (!still) return nullptr;
+	if (!still) return false;
 	auto ok = [](hipError_t e) { if (e != hipSuccess) (void)hipGetLastError(); return e == hipSuccess; };
 	const bool new_key = memcmp(key, T.key, sizeof key) != 0;
 	if (new_key) {
 		/* frames of the old key may still read the tables, on their stream: drain the device before the tables change hands */
-		if (T.key[0] && (n > T.cap || s != T.home) && !ok(hipDeviceSynchronize())) return nullptr;
-		if (n > T.cap) {
+		const bool grow = n > T.cap || n_lanes > T.lanes_cap || n_pixels > T.pixels_cap;
+		if (T.key[0] && (grow || s != T.home) && !ok(hipDeviceSynchronize())) return false;
+		if (grow) {
 			lpt_release(ctx);
 			const size_t cap = (size_t)n + n / 4 + 1024;      /* (tile_slot reaches 8 * ceil(n / 8) - 1 < n + 8) */
 			const bool good = ok(hipMalloc(reinterpret_cast<void**>(&T.d_order[0]), cap * 4)) && ok(hipMalloc(reinterpret_cast<void**>(&T.d_order[1]), cap * 4)) &&
 			                  ok(hipMalloc(reinterpret_cast<void**>(&T.d_cost), cap * 4)) && ok(hipMalloc(reinterpret_cast<void**>(&T.d_keys), cap * 4)) &&
-			                  ok(hipMalloc(reinterpret_cast<void**>(&T.d_hist), 2 * LPT_BUCKETS * 4));
-			if (!good) { lpt_release(ctx); return nullptr; }
-			T.cap = cap;
+			                  ok(hipMalloc(reinterpret_cast<void**>(&T.d_hist), 2 * LPT_BUCKETS * 4)) &&
+			                  ok(hipMalloc(reinterpret_cast<void**>(&T.d_lanes), n_lanes * 4)) &&
+			                  ok(hipMalloc(reinterpret_cast<void**>(&T.d_pixel_cost), n_pixels * 2));
+			if (!good) { lpt_release(ctx); return false; }
+			T.cap = cap; T.lanes_cap = n_lanes; T.pixels_cap = n_pixels;
 		}
 		memcpy(T.key, key, sizeof key);
 		T.n_tiles = n; T.home = s; T.foreign = 0;
 	} else if (s != T.home) {
 		/* a frame of this geometry on another stream: a fixed order — unless the host has moved over for good (the second
 		 * such frame in a row): then the tables move with it, once the old stream has run dry */
-		if (++T.foreign < 2 || !ok(hipStreamSynchronize(T.home))) return nullptr;
+		if (++T.foreign < 2 || !ok(hipStreamSynchronize(T.home))) return false;
 		T.home = s;
 		T.foreign = 0;
 	}
+	const dim3 grid((n + LPT_THREADS - 1) / LPT_THREADS);
+	const uint32_t stride = (n + 7u) >> 3;
+	bool record_pixels = false;
 	if (new_key || memcmp(cam, &T.cam_epoch, sizeof *cam) != 0) {
-		/* a view these tables have no costs for: the row order, and this frame reports its tiles' costs */
+		/* a view these tables know nothing about: rectangles, handed out in region order; this frame reports what every
+		 * pixel and every wave cost */
 		T.cam_epoch = *cam;
 		T.cur = 0; T.frames = 0;
-		hipLaunchKernelGGL(lpt_identity_kernel, dim3((n + LPT_THREADS - 1) / LPT_THREADS), dim3(LPT_THREADS), 0, s, T.d_order[0], n, tiles_x, (n + 7u) >> 3);
-		if (!ok(hipGetLastError()) || !ok(hipMemsetAsync(T.d_cost, 0, ((size_t)n + 8) * 4, s))) { T.key[0] = 0; return nullptr; }
-	} else if (T.frames == 1 || T.frames % lpt_resort_period() == 0) {
-		/* the costs of the frame before are in (same stream): three small kernels, then the other table is the current one.
-		 * (Again every LPT_RESORT frames: the run times drift a little with what runs beside a tile.) */
-		const dim3 grid((n + LPT_THREADS - 1) / LPT_THREADS);
+		hipLaunchKernelGGL(lpt_identity_kernel, grid, dim3(LPT_THREADS), 0, s, T.d_order[0], n, stride);
+		hipLaunchKernelGGL(deal_rectangles_kernel, dim3((unsigned)((n_lanes + LPT_THREADS - 1) / LPT_THREADS)), dim3(LPT_THREADS), 0, s,
+		                   T.d_lanes, (uint32_t)n_lanes, (uint32_t)w, (uint32_t)n_rows, regions_x, REGION_W, REGION_H);
+		if (!ok(hipGetLastError()) || !ok(hipMemsetAsync(T.d_cost, 0, ((size_t)n + 8) * 4, s))) { T.key[0] = 0; return false; }
+		record_pixels = true;
+	} else if (T.frames == 1) {
+		/* the second frame of the view: its pixels dealt to the waves of their region by what they cost (exact: nothing moved);
+		 * the waves are new ones, so they go out in region order once more and report how long THEY run */
+		hipLaunchKernelGGL(deal_by_cost_kernel, dim3(regions_x * regions_y), dim3(LPT_THREADS), 0, s, T.d_pixel_cost, T.d_lanes, (uint32_t)w, (uint32_t)n_rows, regions_x, REGION_W, REGION_H);
+		if (!ok(hipGetLastError())) { T.key[0] = 0; return false; }
+	} else if (T.frames == 2 || T.frames % lpt_resort_period() == 0) {
+		/* the run times of the frame before are in (same stream): three small kernels, then the other table is the current
+		 * one.  (Again every LPT_RESORT frames: the run times drift a little with what runs beside a wave.) */
 		if (ok(hipMemsetAsync(T.d_hist, 0, 2 * LPT_BUCKETS * 4, s))) {
-			const uint32_t stride = (n + 7u) >> 3;
 			hipLaunchKernelGGL(lpt_hist_kernel, grid, dim3(LPT_THREADS), 0, s, T.d_cost, T.d_keys, T.d_hist, n, stride);
 			hipLaunchKernelGGL(lpt_scan_kernel, dim3(1), dim3(LPT_BUCKETS), 0, s, T.d_hist);
 			hipLaunchKernelGGL(lpt_scatter_kernel, grid, dim3(LPT_THREADS), 0, s, T.d_keys, T.d_order[T.cur], T.d_order[T.cur ^ 1], T.d_hist, n, stride);
@@ -1900,8 +1993,8 @@ static const uint32_t* lpt_table_for_frame(lol_gpu* ctx, const lol_frame_camera*
 	}
 	T.foreign = 0;
 	T.frames++;
-	*cost_out = T.d_cost;
-	return T.d_order[T.cur];
+	*out = { T.d_order[T.cur], T.d_cost, T.d_lanes, record_pixels ? T.d_pixel_cost : nullptr, n };
+	return true;
 }
 
 /* AUTO: collect the trial frames that have finished (never waits) and decide once all of them have */
@@ -2019,7 +2112,7 @@ int lol_gpu_tile_order(lol_gpu* ctx, lol_gpu_tile_order_info* out) {
 		/* longest first: the last frame went through a table (order LPT; "deciding" until its costs have been sorted once), or
 		 * the camera moves and AUTO's fixed order is in use (its state and trial times) */
 		const lol_gpu::TileLpt& P = ctx->lpt;
-		if (P.last_table) *out = { T.mode, LOL_GPU_TILES_LPT, P.frames < 2 ? 1 : 0, (int32_t)P.sorts, T.typical[0], T.typical[1] };
+		if (P.last_table) *out = { T.mode, LOL_GPU_TILES_LPT, P.frames < 3 ? 1 : 0, (int32_t)P.sorts, T.typical[0], T.typical[1] };
 		else *out = { T.mode, T.chosen, (T.deciding || P.sorts == 0) ? 1 : 0, (int32_t)P.sorts, T.typical[0], T.typical[1] };
 	} else
 		*out = { T.mode, T.chosen, T.deciding ? 1 : 0, T.decisions, T.typical[0], T.typical[1] };
@@ -2255,18 +2348,20 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	dim3 grid((w + tile_w - 1) / tile_w, (n_rows + tile_h - 1) / tile_h);
 	const size_t common = (size_t)(lol::common_lds_dwords(P.n_lights, P.n_materials, P.n_roots) - lol::TILE_W * lol::TILE_H + block) * 4;
 	int trial = -1;
-	const uint32_t* table = nullptr;
+	bool table = false;
 	if (ctx->tiles.mode == LOL_GPU_TILES_LPT) {
-		uint32_t* cost = nullptr;
-		if ((table = lpt_table_for_frame(ctx, cam, w, h, max_steps, R, n_rows, tile_w, tile_h, s, &cost)) != nullptr) {
+		FrameTables F;
+		if ((table = lpt_table_for_frame(ctx, cam, w, h, max_steps, R, n_rows, block, s, &F))) {
 			L.flags |= lol::FLAG_TILE_TABLE;
-			L.tile_order = table;
-			L.tile_cost = cost;
-			L.tile_stride = (grid.x * grid.y + 7u) >> 3;
-			grid = dim3(grid.x * grid.y, 1);
+			L.tile_order = F.order;
+			L.tile_cost = F.cost;
+			L.tile_stride = (F.n_waves + 7u) >> 3;
+			L.lane_pixels = F.lanes;
+			L.pixel_cost = F.pixel_cost;
+			grid = dim3(F.n_waves, 1);
 		}
 	}
-	ctx->lpt.last_table = table != nullptr;
+	ctx->lpt.last_table = table;
 	/* (longest-first without a table — the camera moves, or another stream —: the better of the two fixed orders, like AUTO) */
 	if (!table && tile_order_for_frame(ctx, w, h, max_steps, R, dbg != nullptr, &trial) == LOL_GPU_TILES_COLS) {
 		L.flags |= lol::FLAG_TILE_COLS;

@@ -68,7 +68,8 @@ constexpr u32 FLAG_MISS_SKIP = 1u;   /* a wave whose rays all escaped may skip n
 constexpr u32 FLAG_DARK_SKIP = 2u;   /* lanes whose diffuse incidence for a light is exactly 0 need no shadow march for it */
 constexpr u32 FLAG_TILE_COLS = 8u;   /* the launch grid is transposed: tiles are handed out column by column (lol_gpu_set_tile_order) */
 constexpr u32 FLAG_SHADOW_SETTLED = 4u;   /* a shadow march ends as soon as its factor can only be 0 (soft_shadow) */
-constexpr u32 FLAG_TILE_TABLE = 32u;      /* a one-dimensional grid: block b renders the tile Launch::tile_order[b] names (longest tiles first, lol_gpu.hip) */
+constexpr u32 FLAG_TILE_TABLE = 32u;      /* a one-dimensional grid of one-wave blocks: block b shades the 64 pixels of wave slot Launch::tile_order[b] of the
+                                           * pixel table Launch::lane_pixels (pixels dealt to waves by cost, waves handed out longest first: lol_gpu.hip) */
 constexpr u32 FLAG_SHADOW_FDIV = 16u;     /* with FLAG_SHADOW_SETTLED: 50 s / t by fdiv_fast where the Sdf policy allows it (soft_shadow) */
 
 /* = lol_frame_camera */
@@ -100,12 +101,17 @@ struct Launch {
 	float* dbg_hit_dist;
 	u32*   dbg_hit_id;
 	u32*   dbg_steps;
-	/* FLAG_TILE_TABLE: tile_order[b] = tile column | tile row << 16 of the b-th block of the launch; tile_cost[b] (may be NULL)
-	 * receives what that block's wave cost: how long it ran (store_pixel) */
+	/* FLAG_TILE_TABLE: tile_order[b] = the wave slot the b-th block of the launch shades; tile_cost[b] (may be NULL) receives
+	 * what that block's wave cost: how long it ran (store_pixel).  lane_pixels[64 * slot + lane] = that lane's pixel: column |
+	 * local row << 16 (| LANE_PADDING for a lane that only fills up its wave: it shades the pixel it names and stores nothing).
+	 * pixel_cost (may be NULL) receives every pixel's step count, w per local row: what the pixels are dealt by. */
 	const u32* tile_order;
 	u32*   tile_cost;
 	u32    tile_stride;          /* both tables are indexed by tile_slot(block): ceil(blocks / 8) */
+	const u32* lane_pixels;
+	unsigned short* pixel_cost;
 };
+constexpr u32 LANE_PADDING = 1u << 31;
 
 /* Fields of the launch arguments that only the last few instructions of a kernel need (destination, pitch, pixel
  * format, diagnostics) are read THERE, from the kernel-argument segment, through a pointer the compiler cannot see
@@ -134,27 +140,27 @@ __device__ __forceinline__ LaunchTail launch_tail(const Launch& L0) {
  * them back.  (A layout, not an assumption anything but the traffic rests on.) */
 __device__ __forceinline__ u32 tile_slot(u32 b, u32 stride) { return (b & 7u) * stride + (b >> 3); }
 
-/* Which tile of the frame this block renders: its position in the grid (row by row, or column by column with
- * FLAG_TILE_COLS), or — FLAG_TILE_TABLE — what the launch's order table says for it: one scalar load, read where it is
- * needed (at the start for the pixel's coordinates, at the end for the store) like the other late fields. */
+/* Which tile of the frame this block renders in the fixed orders: its position in the grid, row by row, or column by column
+ * with FLAG_TILE_COLS. */
 __device__ __forceinline__ void tile_of_block(const Launch& L0, int& bx, int& by) {
-	if (L0.flags & FLAG_TILE_TABLE) {
+	const bool cols = (L0.flags & FLAG_TILE_COLS) != 0u;
+	bx = cols ? blockIdx.y : blockIdx.x;
+	by = cols ? blockIdx.x : blockIdx.y;
+}
+/* FLAG_TILE_TABLE: this lane's entry of the pixel table — the block's wave slot from the order table (one scalar load), the
+ * lane's pixel from that slot's 64 entries (one coalesced load).  Read where it is needed (at the start for the pixel's
+ * coordinates, at the end for the store) like the other late fields: no register is held for it in between. */
+__device__ __forceinline__ u32 lane_pixel(const Launch& L0) {
 #if defined(__HIP_DEVICE_COMPILE__)
-		typedef const __attribute__((address_space(4))) Launch* kernarg_ptr;
-		kernarg_ptr L = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
-		asm volatile("" : "+s"(L));
-		typedef const __attribute__((address_space(4))) u32* table_ptr;
-		const u32 pk = ((table_ptr)(unsigned long long)L->tile_order)[tile_slot(blockIdx.x, L->tile_stride)];
+	typedef const __attribute__((address_space(4))) Launch* kernarg_ptr;
+	kernarg_ptr L = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+	asm volatile("" : "+s"(L));
+	typedef const __attribute__((address_space(4))) u32* table_ptr;
+	const u32 slot = ((table_ptr)(unsigned long long)L->tile_order)[tile_slot(blockIdx.x, L->tile_stride)];
+	return L->lane_pixels[(unsigned long long)slot * 64u + (threadIdx.x & 63u)];
 #else
-		const u32 pk = L0.tile_order[tile_slot(blockIdx.x, L0.tile_stride)];
+	return L0.lane_pixels[(unsigned long long)L0.tile_order[tile_slot(blockIdx.x, L0.tile_stride)] * 64u + (threadIdx.x & 63u)];
 #endif
-		bx = (int)(pk & 0xFFFFu);
-		by = (int)(pk >> 16);
-	} else {
-		const bool cols = (L0.flags & FLAG_TILE_COLS) != 0u;
-		bx = cols ? blockIdx.y : blockIdx.x;
-		by = cols ? blockIdx.x : blockIdx.y;
-	}
 }
 struct V3 { float x, y, z; };
 
@@ -924,16 +930,24 @@ __device__ __forceinline__ Pixel shade_pixel(const Launch& L, Sdf& sdf, const u3
 	const u32* l_mat   = TABLES_GLOBAL ? L.materials : l_light + L.n_lights * LIGHT_DWORDS;
 	const u32* l_rootm = TABLES_GLOBAL ? L.root_material : l_mat + L.n_materials * MATERIAL_DWORDS;
 
-	/* lane → pixel: wave k covers a WAVE_W x WAVE_H patch of the block's tile */
-	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int tx = wave * WAVE_W + (lane % WAVE_W), ty = lane / WAVE_W;
-	int tbx, tby;
-	tile_of_block(L, tbx, tby);
-	int x = tbx * TILE_W + tx;
-	int r = tby * TILE_H + ty;                                                  /* local row */
-	/* out-of-frame lanes shade a clamped pixel and skip the store: keeps the wave uniform */
-	x = x < L.w ? x : L.w - 1;
-	r = r < L.n_rows ? r : L.n_rows - 1;
+	/* lane → pixel: wave k covers a WAVE_W x WAVE_H patch of the block's tile — or, FLAG_TILE_TABLE, the pixel the table deals
+	 * this lane (in the frame by construction) */
+	int x, r;                                                                       /* r: local row */
+	if (L.flags & FLAG_TILE_TABLE) {
+		const u32 e = lane_pixel(L);
+		x = (int)(e & 0xFFFFu);
+		r = (int)(e >> 16 & 0x7FFFu);
+	} else {
+		const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+		const int tx = wave * WAVE_W + (lane % WAVE_W), ty = lane / WAVE_W;
+		int tbx, tby;
+		tile_of_block(L, tbx, tby);
+		x = tbx * TILE_W + tx;
+		r = tby * TILE_H + ty;
+		/* out-of-frame lanes shade a clamped pixel and skip the store: keeps the wave uniform */
+		x = x < L.w ? x : L.w - 1;
+		r = r < L.n_rows ? r : L.n_rows - 1;
+	}
 	const int y = frame_row(L, r);
 
 	/* naive_renderer.c:218-221 */
@@ -1021,6 +1035,51 @@ __device__ __forceinline__ void store_pixel(const Launch& L, const Pixel& P, u32
 	               (g8 >> (T.fmt_loss >> 8 & 0xFFu)) << (T.fmt_shift >> 8 & 0xFFu) |
 	               (b8 >> (T.fmt_loss >> 16 & 0xFFu)) << (T.fmt_shift >> 16 & 0xFFu) | T.fmt_amask;
 	u32* l_tile = TABLES_GLOBAL ? lds : lds + L.n_lights * LIGHT_DWORDS + L.n_materials * MATERIAL_DWORDS + L.n_roots;
+	if (L.flags & FLAG_TILE_TABLE) {
+		/* the pixels of this wave lie where the table dealt them: every lane stores its own (4 bytes; the tables trade the
+		 * idle memory system for lanes that finish together — lol_gpu.hip, "pixels dealt by cost") */
+		const u32 e = lane_pixel(L);
+		const int gx = (int)(e & 0xFFFFu), gr = (int)(e >> 16 & 0x7FFFu);
+		u32* cost;
+		unsigned short* pixel_cost;
+		u32 stride;
+#if defined(__HIP_DEVICE_COMPILE__)
+		{
+			typedef const __attribute__((address_space(4))) Launch* kernarg_ptr;
+			kernarg_ptr K = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+			asm volatile("" : "+s"(K));
+			cost = K->tile_cost;
+			stride = K->tile_stride;
+			pixel_cost = K->pixel_cost;
+		}
+#else
+		cost = L.tile_cost;
+		stride = L.tile_stride;
+		pixel_cost = L.pixel_cost;
+#endif
+		if (!(e & LANE_PADDING)) {
+			const unsigned long long o = (unsigned long long)gr * L.w + gx;
+			if (T.dbg_rgb) { T.dbg_rgb[o * 3 + 0] = P.rgb.x; T.dbg_rgb[o * 3 + 1] = P.rgb.y; T.dbg_rgb[o * 3 + 2] = P.rgb.z; }
+			if (T.dbg_hit_dist) T.dbg_hit_dist[o] = P.hit.dist;
+			if (T.dbg_hit_id) T.dbg_hit_id[o] = P.hit.id;
+			if (T.dbg_steps) T.dbg_steps[o] = (P.hit.steps & 0xFFFFu) | (P.shadow_steps << 16);
+			T.dst[(unsigned long long)gr * T.pitch_px + gx] = px;
+			if (pixel_cost) {                                   /* what the pixels are dealt to waves by: the evaluations this one needed */
+				const u32 c = P.hit.steps + P.shadow_steps;
+				pixel_cost[o] = (unsigned short)(c < 0xFFFFu ? c : 0xFFFFu);
+			}
+		}
+		/* what this wave cost, for the order of the NEXT frames' waves (lol_gpu.hip, "longest tiles first"): how long it ran —
+		 * shader-clock ticks since start_tile_clock() (parked in the first word of the unused output tile), as 32 x log2 (5
+		 * fraction bits: steps of 2 %; waves shorter than 1024 ticks all count 0) — at most 21 * 32 + 31 = 703, one bucket of
+		 * the host's sort each */
+		if (cost && threadIdx.x == 0) {
+			const u32 dt = (u32)__builtin_readcyclecounter() - l_tile[0];
+			const u32 le = 31u - (u32)__builtin_clz(dt | 1u);
+			cost[tile_slot(blockIdx.x, stride)] = le < 10u ? 0u : ((le - 10u) << 5 | ((dt >> (le - 5u)) & 31u));
+		}
+		return;
+	}
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int tx = wave * WAVE_W + (lane % WAVE_W), ty = lane / WAVE_W;
 	int bx, by;
@@ -1033,9 +1092,6 @@ __device__ __forceinline__ void store_pixel(const Launch& L, const Pixel& P, u32
 		if (T.dbg_hit_id) T.dbg_hit_id[o] = P.hit.id;
 		if (T.dbg_steps) T.dbg_steps[o] = (P.hit.steps & 0xFFFFu) | (P.shadow_steps << 16);
 	}
-	/* (the tile's first word held the wave's start time until now: start_tile_clock) */
-	u32 t_start = 0;
-	if (L.flags & FLAG_TILE_TABLE) { t_start = l_tile[0]; __syncthreads(); }
 	/* through LDS so the block stores whole row segments (64 bytes each with the default 16x4 patch) */
 	l_tile[ty * TILE_W + tx] = px;
 	__syncthreads();
@@ -1043,41 +1099,20 @@ __device__ __forceinline__ void store_pixel(const Launch& L, const Pixel& P, u32
 	const int ox = bx * TILE_W + sx, orow = by * TILE_H + sy;
 	if (ox < L.w && orow < L.n_rows)
 		T.dst[(unsigned long long)orow * T.pitch_px + ox] = l_tile[sy * TILE_W + sx];
-	/* what this tile cost, for the order of the NEXT frames' tiles (lol_gpu.hip, "longest tiles first") */
-	if (L.flags & FLAG_TILE_TABLE) {
-		u32* cost;
-		u32 stride;
-#if defined(__HIP_DEVICE_COMPILE__)
-		{
-			typedef const __attribute__((address_space(4))) Launch* kernarg_ptr;
-			kernarg_ptr K = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
-			asm volatile("" : "+s"(K));
-			cost = K->tile_cost;
-			stride = K->tile_stride;
-		}
-#else
-		cost = L.tile_cost;
-		stride = L.tile_stride;
-#endif
-		if (cost && threadIdx.x == 0) {
-			/* how long this wave ran: shader-clock ticks since start_tile_clock(), as 32 x log2 (5 fraction bits: steps of 2 %;
-			 * waves shorter than 1024 ticks all count 0) — at most 21 * 32 + 31 = 703, one bucket of the host's sort each */
-			const u32 dt = (u32)__builtin_readcyclecounter() - t_start;
-			const u32 e = 31u - (u32)__builtin_clz(dt | 1u);
-			cost[tile_slot(blockIdx.x, stride)] = e < 10u ? 0u : ((e - 10u) << 5 | ((dt >> (e - 5u)) & 31u));
-		}
-	}
 }
 
 /* FLAG_TILE_TABLE: when this block's wave started, parked in the first word of its (still unused) output tile in LDS rather
  * than in a register for the whole kernel; store_pixel turns it into the tile's cost.  Call once, before the first shade_pixel
  * (a wave that shades again through the plain path is timed over both passes: that is what it costs). */
 template <bool TABLES_GLOBAL = false>
-__device__ __forceinline__ void start_tile_clock(const Launch& L, u32* lds) {
+__device__ __forceinline__ bool start_tile_clock(const Launch& L, u32* lds) {
 	if (L.flags & FLAG_TILE_TABLE) {
+		/* false: every lane of this wave only fills up a region at the frame's edge — nothing to shade */
+		if (vote((lane_pixel(L) & LANE_PADDING) == 0u) == 0) return false;
 		u32* l_tile = TABLES_GLOBAL ? lds : lds + L.n_lights * LIGHT_DWORDS + L.n_materials * MATERIAL_DWORDS + L.n_roots;
 		if (threadIdx.x == 0) l_tile[0] = (u32)__builtin_readcyclecounter();
 	}
+	return true;
 }
 
 /* stage lights | materials | root_material into `lds` (no barrier) */
@@ -1103,7 +1138,7 @@ void render_interp(const Launch L) {
 		stage_common(L, lds);
 		__syncthreads();
 	}
-	start_tile_clock<TABLES_GLOBAL>(L, lds);
+	if (!start_tile_clock<TABLES_GLOBAL>(L, lds)) return;
 	Interp<SSIZE, KIND> sdf{ L.ops, L.n_ops, {}, 0u };
 	Pixel P = shade_pixel<Interp<SSIZE, KIND>, TABLES_GLOBAL>(L, sdf, lds);
 	if (KIND != 0 && unproven(sdf)) {

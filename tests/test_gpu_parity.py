@@ -45,7 +45,7 @@ def renderer(torch_cuda, request):
     r.close()
 
 
-def gpu_render(torch, r, sc, w, h, max_steps=256, rows=None, camera=None, pitch_px=None):
+def gpu_render(torch, r, sc, w, h, max_steps=256, rows=None, camera=None, pitch_px=None, repeat=1):
     n_rows = gpu.part_rows(h, rows)
     pitch_px = pitch_px or w
     dev = torch.device("cuda:0")
@@ -57,8 +57,11 @@ def gpu_render(torch, r, sc, w, h, max_steps=256, rows=None, camera=None, pitch_
     dbg = gpu.Debug(rgb.data_ptr(), dist.data_ptr(), hid.data_ptr(), steps.data_ptr())
     r.prepare(sc)
     assert r.kernel_name() == getattr(r, "want_kernel", r.kernel_name()), r.specialize_log()
-    r.render_into(frame.data_ptr(), w, h, max_steps, camera=camera, rows=rows, pitch_bytes=pitch_px * 4,
-                  debug=dbg, stream=torch.cuda.current_stream().cuda_stream)
+    for i in range(repeat):            # repeat > 1: the same view again and again — the later frames go through the library's tables
+        if i:
+            frame.fill_(0x55AA55); rgb.zero_(); dist.zero_(); hid.zero_(); steps.zero_()
+        r.render_into(frame.data_ptr(), w, h, max_steps, camera=camera, rows=rows, pitch_bytes=pitch_px * 4,
+                      debug=dbg, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     return dict(xrgb=frame.cpu().numpy().view(np.uint32), rgb=rgb.cpu().numpy(), dist=dist.cpu().numpy(),
                 id=hid.cpu().numpy().view(np.uint32), steps=steps.cpu().numpy().view(np.uint32),
@@ -119,6 +122,30 @@ def test_frame_matches_oracle(torch_cuda, renderer, scenes, name, w, h):
     # On an FMA host (the GPU box is one) check_against_oracle has already required bit-identical colours and packed
     # pixels; elsewhere the host's other powf variant may move a channel by one step where c*255 straddles an integer.
     assert mism == 0 if HOST_LIBM_IS_FMA_VARIANT else mism <= max(4, w * h // 2000), f"{mism} packed pixels differ"
+
+
+@pytest.mark.parametrize("name,w,h", [
+    ("scene4", 256, 256), ("scene", 200, 120), ("scene2", 160, 120), ("scene3", 130, 70),
+    ("scene4", 97, 61),          # neither dimension a multiple of the 64x16 region: padding lanes at both edges
+    ("scene", 33, 9), ("scene4", 1, 1), ("scene4", 5, 300), ("scene4", 64, 16), ("scene4", 65, 17),
+])
+def test_repeated_view_matches_oracle(torch_cuda, renderer, scenes, name, w, h):
+    """A view rendered again and again (a camera that stands still): from the third frame on its pixels are dealt to the waves
+    of their 64x16 region by what they cost, from the fourth the waves are handed out longest first (lol_gpu.hip) — all four
+    kernel configurations: the fifth frame's pixels, colours, ids, distances and step counts equal the oracle's like the first's."""
+    sc = scenes[name]
+    g = gpu_render(torch_cuda, renderer, sc, w, h, repeat=5)
+    assert renderer.tile_order()["order"] == "lpt" and renderer.tile_order()["decisions"] >= 1
+    mism = check_against_oracle(g, sc, w, h)
+    assert mism == 0 if HOST_LIBM_IS_FMA_VARIANT else mism <= max(4, w * h // 2000), f"{mism} packed pixels differ"
+    # ... and with a row partition (the middle band of three) and a pitched destination
+    part = gpu.Rows(4, 12, 4)
+    if h >= 12:
+        a = gpu_render(torch_cuda, renderer, sc, w, h, rows=part, pitch_px=w + 3, repeat=5)
+        b = gpu_render(torch_cuda, renderer, sc, w, h, rows=part, pitch_px=w + 3)
+        for k in ("xrgb", "rgb", "dist", "id", "steps"):
+            assert np.array_equal(a[k], b[k]), k
+        assert (a["xrgb"][:, w:] == 0x55AA55).all()
 
 
 def test_hit_distance_and_id_bit_exact(torch_cuda, renderer, scenes):

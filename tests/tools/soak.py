@@ -1,4 +1,7 @@
-"""Soak: many random scenes, GPU (spec + interp) vs the CPU oracle.  python tests/tools/soak.py [n] [seed] [stress | onek]"""
+"""Soak: many random scenes, GPU (spec + interp) vs the CPU oracle.  python tests/tools/soak.py [n] [seed] [stress | onek | still]
+still: every scene is rendered five times under one camera — the first frames in a fixed order and through rectangles, the
+later ones with their pixels dealt to waves by cost and the waves handed out longest first (lol_gpu.hip) — and the LAST frame is
+what is held against the oracle (pixels, colours, ids, distances, step counts)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -11,6 +14,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 stress = len(sys.argv) > 3 and sys.argv[3] == "stress"
 onek = len(sys.argv) > 3 and sys.argv[3] == "onek"      # every smooth union of a scene shares one k: the interpreter folds its pops (MOPB_POST)
+still = len(sys.argv) > 3 and sys.argv[3] == "still"
 rng = np.random.default_rng(seed)
 
 
@@ -57,8 +61,10 @@ for i in range(n):
     w, h = int(rng.integers(17, 90)), int(rng.integers(9, 60))
     for m, r in rs.items():
         try:
-            g = gpu_render(torch, r, sc, w, h)
+            g = gpu_render(torch, r, sc, w, h, repeat=5 if still else 1)
             check_against_oracle(g, sc, w, h)
+            if still:
+                assert r.tile_order()["order"] == "lpt", r.tile_order()
         except AssertionError as e:
             bad += 1
             print(f"FAIL scene {i} mode {m} {w}x{h}: {str(e)[:200]}\n{text}\n", flush=True)
