@@ -126,12 +126,23 @@ def pmc_issue(kernel: str, workload: str, pixels_per_launch: int, kernel_key: st
             "transcendental_share_of_valu": rec.get("transcendental_share_of_valu")}
 
 
-def lane_efficiency_model(workload: str):
-    """Lane efficiency of the 16x4 wave footprint on this workload: needed SDF evaluations / evaluations the waves execute
-    (a wave runs the maximum over its 64 lanes), from the oracle's per-pixel step counts (tools/divergence.py; the PMC cannot
-    see it: finished lanes are predicated, not masked).  The newest profiles/r*_divergence.json of this workload."""
+def lane_efficiency_model(workload: str, dealt: bool = False):
+    """Lane efficiency on this workload: needed SDF evaluations / evaluations the waves execute (a wave runs the maximum over
+    its 64 lanes), from per-pixel step counts (the PMC cannot see it: finished lanes are predicated, not masked).  `dealt`: the
+    waves of a view that repeats — pixels dealt by cost inside 64x16 regions (tests/tools/sorted_region_model.py on the oracle's
+    counts, newest profiles/r*_sorted_region_model.json); else the 16x4 rectangles (tools/divergence.py, r*_divergence.json)."""
     import glob
     size = "%dx%d" % (WORKLOADS[workload]["w"], WORKLOADS[workload]["h"])
+    if dealt:
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sorted_region_model*.json")), reverse=True):
+            try:
+                d = json.load(open(path))
+            except (OSError, ValueError):
+                continue
+            if d.get("scene") == WORKLOADS[workload]["scene"] + ".lol" and d.get("size") == size and "64x16" in d:
+                return {"lane_efficiency": round(d["64x16"]["by_total"]["lane_efficiency"], 4),
+                        "rectangles_16x4": round(d["64x16"]["now"]["lane_efficiency"], 4),
+                        "source": "profiles/" + os.path.basename(path) + " (pixels dealt to waves by cost inside 64x16 regions; oracle step counts of sampled strips)"}
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_divergence*.json")), reverse=True):
         try:
             d = json.load(open(path))
@@ -143,7 +154,7 @@ def lane_efficiency_model(workload: str):
     return None
 
 
-def valu_fields(kernel: str, workload: str, px_per_launch: int, kernel_key: str, kernel_mpix: float, ctr, flops_sdf: float) -> dict:
+def valu_fields(kernel: str, workload: str, px_per_launch: int, kernel_key: str, kernel_mpix: float, ctr, flops_sdf: float, dealt: bool = False) -> dict:
     """`valu`: the machine first — issue_frac = 2.0 cycles (a SIMD issues one wave64 VALU instruction per 2 cycles at best:
     32 lanes per cycle) / the cycles per VALU instruction the PMC passes measured on THIS kernel code; VALU instructions
     per pixel; lane efficiency of the wave footprint — then, without any fraction, what the measured rate is worth in the
@@ -162,7 +173,7 @@ def valu_fields(kernel: str, workload: str, px_per_launch: int, kernel_key: str,
         out.update(issue_frac=None, cycles_per_valu_instruction=None, valu_instructions_per_pixel=None,
                    issue_source="profiles/pmc_traffic.json holds no PMC passes of this kernel code / workload: not quoted "
                                 "(re-run tools/final_profile.sh)")
-    lane = lane_efficiency_model(workload)
+    lane = lane_efficiency_model(workload, dealt) or (lane_efficiency_model(workload) if dealt else None)
     out["lane_efficiency"] = lane["lane_efficiency"] if lane else None
     out["lane_efficiency_detail"] = lane
     if ctr is not None and ctr.pixels:
@@ -845,7 +856,10 @@ def main():
                          "algorithmic_bytes": px_per_launch * BYTES_PER_PIXEL,
                          "kernel_ms_avg": round(k_avg, 4), "pixels_per_launch": px_per_launch,
                          "bytes_per_pixel": BYTES_PER_PIXEL,
-                         "note": "north_star names the HBM-write roofline; the path is FP32-VALU-bound, see `valu`"},
+                         "note": "north_star names the HBM-write roofline; the path is FP32-VALU-bound, see `valu`.  `traffic` above the "
+                                 "algorithmic bytes is what the scheduling tables of a repeated view move (DESIGN.md §3.9: a 4-byte pixel-table "
+                                 "entry read and a 4-byte store of its own per lane) — memory traffic, of which this path uses about 1 % of the "
+                                 "peak, traded for lanes that finish together"},
         }
         if world > 1 or (pipe is not None and not pipe.single):
             out.update(per_rank_fields(rank_stats, dt / max(steps, 1) * 1e3))
@@ -869,7 +883,7 @@ def main():
             base, ctr = cpu_baseline(sc, cfg, gpu_frame=local.cpu().numpy().view(np.uint32))
             out["cpu_baseline"] = base
             out["valu"] = valu_fields(r.kernel_name(), name, px_per_launch, r.kernel_key(), px_per_launch / (k_avg * 1e-3) / 1e6,
-                                      ctr, flops_per_sdf(r.program))
+                                      ctr, flops_per_sdf(r.program), dealt=tile["order"] == "lpt")
         if startup is not None:
             out["startup"] = startup
         if world == 1 and local is not None and os.environ.get("LOL_BENCH_HOST_SURFACE", "1") != "0":

@@ -260,11 +260,14 @@ int         lol_gpu_set_cull(lol_gpu* ctx, int enable);
 /*
  * The order in which a launch hands out its tiles of 16x4 pixels.  Same pixels in every order; the time differs, because a
  * frame is one launch of blocks that differ 100x in cost and ends with its slowest waves running on half-empty SIMDs.
- *   LOL_GPU_TILES_LPT (the default): longest tiles first, while the camera stands still.  A frame under the same camera as
- *     the frame before it goes through an order table and reports how long each tile's wave ran; a counting sort on the
- *     device (three small kernels on the frame's stream) orders the tiles of the following frames by decreasing cost — list
- *     scheduling with costs that are exact, because nothing moved.  scene4 at 4K +8 % over the better of the two fixed
- *     orders, scene.lol at 1080p +30 %, the bands of an 8-way split of the 8K frame +16 %.  A frame whose
+ *   LOL_GPU_TILES_LPT (the default): while the camera stands still, a frame is scheduled by what the frame before it cost.
+ *     A frame under the same camera as the frame before it goes through tables: the pixels of every 64x16 region are dealt
+ *     to the region's sixteen waves by the SDF evaluations they needed (a wave runs every loop to its slowest lane), every
+ *     wave reports how long it ran, and a counting sort on the device (three small kernels on the frame's stream) hands the
+ *     waves of the following frames out longest first — scheduling with costs that are exact, because nothing moved.  Only
+ *     the schedule is reused: every pixel is computed from scratch in every frame, and comes out the same.  scene4 at 4K
+ *     +24 % over the better of the two fixed orders, scene.lol at 1080p +40 %, the bands of an 8-way split of the 8K frame
+ *     +34 %.  A frame whose
  *     camera differs from its predecessor's is launched in the better fixed order (as LOL_GPU_TILES_AUTO finds it), with
  *     no table, cost or sort: stale costs are worse than no costs (the reference's arrow keys turn the camera 5.7 degrees
  *     a frame).  The tables live on the stream the first such frame was launched on; frames of the same geometry on

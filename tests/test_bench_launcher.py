@@ -54,9 +54,10 @@ def test_pmc_traffic_is_only_quoted_for_the_code_it_was_measured_on():
     for kernel, r in rec.items():
         assert r["kernel_key"] and len(r["kernel_key"]) == 16 and min(r["dispatches_per_counter"].values()) >= 100
         got, why = bench.pmc_traffic(kernel, r["workload"], r["pixels_per_launch"], r["kernel_key"])
-        # 4 B per pixel + what longest-tiles-first adds: one 4-byte order entry read and one 4-byte cost written per tile (stored XCD by
-        # XCD, so each XCD's L2 moves them as whole lines): 1.057 x the algorithmic bytes (it was 1.39 x in block order)
-        assert got == r["traffic_bytes"] and 0 <= got / r["algorithmic_bytes"] - 1 < 0.08
+        # 4 B per pixel + what the scheduling tables of a repeated view move: a 4-byte pixel-table entry read per
+        # lane (33 MB for C3) and every lane storing its own 4 bytes (sectors written 1.7 times on average): 2.8 x the algorithmic
+        # bytes, about 1 % of the HBM peak at this frame rate — the trade the round-3 review asked for
+        assert got == r["traffic_bytes"] and 1.0 <= got / r["algorithmic_bytes"] < 3.2
         assert bench.pmc_traffic(kernel, r["workload"], r["pixels_per_launch"], "0" * 16)[0] is None
         assert "another" in bench.pmc_traffic(kernel, "c2", r["pixels_per_launch"], r["kernel_key"])[1]
         assert bench.pmc_traffic(kernel, r["workload"], 1234, r["kernel_key"])[0] is None
