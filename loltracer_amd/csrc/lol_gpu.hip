@@ -1347,10 +1347,11 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
 	{
 		Dl_info info;
 		if (dladdr(reinterpret_cast<void*>(&hiprtcCompileProgram), &info) && info.dli_fname) compiler = info.dli_fname;
+		compiler = std::to_string(rtc_major) + "." + std::to_string(rtc_minor) + " " + compiler;
 		const char* any = getenv("LOL_GPU_CACHE_ANY_COMPILER");
-		if (any && any[0] == '1') compiler = "*";
+		if (any && any[0] == '1') compiler = "*";         /* its version too: torch's hipRTC and the system's differ in it */
 	}
-	std::string key = "lol_gpu/4|hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) + " " + compiler + "|";
+	std::string key = "lol_gpu/4|hiprtc " + compiler + "|";
 	for (const char* o : opts) { key += o; key += ' '; }
 	key += "|" + src;
 	{

@@ -16,11 +16,14 @@ python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/plain_first.json
 LOL_GPU_SPECIALIZE=0 python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 || exit 1
 LOL_BENCH_HOST_SURFACE=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > $O/stats.log 2>&1 || exit 1
 grep -o '^{.*' $O/stats.log | tail -1 > $O/${TAG}_spec_c3_bench.json
+keyof() { python3 -c "import json,sys; print(json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])['config']['kernel_key'])" $1; }
+[ "$(keyof $O/plain_first.json)" = "$(keyof $O/${TAG}_spec_c3_bench.json)" ] || { echo "the profiled run compiled its own kernel ($(keyof $O/${TAG}_spec_c3_bench.json)), not the plain run's ($(keyof $O/plain_first.json))"; exit 1; }
 cp "$(find $O/stats -name "*kernel_stats.csv" | head -1)" $O/${TAG}_spec_c3_kernel_stats.csv
 BP="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
 pmc() { # name, counters...  → one rocprofv3 pass in a directory of its own ($PFX = which kernel the bench times)
 	n=$1; shift
 	timeout -k 10 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/${PFX}_$n -- $BP > $O/${PFX}_$n.log 2>&1 || return 1
+	[ -z "$WANT" ] || grep -q "\"kernel_key\": \"$WANT\"" $O/${PFX}_$n.log || { echo "pass $n ran another kernel than $WANT"; return 1; }
 	cp "$(find $O/${PFX}_$n -name "*counter_collection.csv" | head -1)" $O/${TAG}_${PFX}_pmc_${n}_counter_collection.csv
 }
 passes() {
@@ -33,12 +36,12 @@ passes() {
 	pmc sq3 SQ_INSTS_VALU_TRANS_F32 SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_IFETCH SQC_ICACHE_REQ SQC_ICACHE_MISSES || return 1
 }
 key() { $BP 2> /dev/null | python3 -c "import json,sys; c=json.loads(sys.stdin.read())['config']; print(c['kernel'], c['kernel_key'])"; }
-PFX=spec
+PFX=spec; WANT=$(keyof $O/plain_first.json)
 passes || exit 1
 set -- $(key); [ "$1" = lol_render_spec ] || { echo "expected lol_render_spec, bench timed $1"; exit 1; }
 python3 $R/tools/pmc_summary.py --kernel lol_render_spec --kernel-key $2 --min-dispatches 100 --workload c3 --pixels 8294400 --out $O/pmc_traffic.json $O/${TAG}_spec_pmc_*_counter_collection.csv > $O/pmc_spec.txt || exit 1
 export LOL_GPU_SPECIALIZE=0
-PFX=interp
+PFX=interp; WANT=
 passes || exit 1
 set -- $(key); [ "$1" = render_interp ] || { echo "expected render_interp, bench timed $1"; exit 1; }
 python3 $R/tools/pmc_summary.py --merge --kernel render_interp --kernel-key $2 --min-dispatches 100 --workload c3 --pixels 8294400 --out $O/pmc_traffic.json $O/${TAG}_interp_pmc_*_counter_collection.csv > $O/pmc_interp.txt || exit 1
