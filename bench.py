@@ -329,6 +329,37 @@ def both_kernels(r, sc, spec_frame, w, h, max_steps, fc, stream, spec_ms, px, fr
     return out
 
 
+def scheduling_rates(r, spec_frame, w, h, max_steps, fc, stream, scheduled_ms, px, frames: int = 5) -> dict:
+    """What the timed frames owe to the repeated view.  `value` is quoted on the workload BASELINE.json names —
+    one camera, frame after frame — and while the camera stands still the library schedules a frame by what the frame before
+    cost (every pixel still computed from scratch).  A frame with a NEW camera has no such tables and runs in a fixed tile
+    order: the same frame is timed here in both fixed orders on the same context, and compared."""
+    out = {"repeated_view_mpixels_per_s": round(px / (scheduled_ms * 1e-3) / 1e6, 1)}
+    buf = torch.zeros_like(spec_frame)
+    best = None
+    for order in ("rows", "cols"):
+        r.set_tile_order(order)
+        ev = []
+        for i in range(2 + frames):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r.render_into(buf.data_ptr(), w, h, max_steps, stream=stream, frame_camera=fc)
+            e1.record()
+            if i >= 2:
+                ev.append((e0, e1))
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+        out[f"fixed_{order}_mpixels_per_s"] = round(px / (ms * 1e-3) / 1e6, 1)
+        out[f"fixed_{order}_frame_equal"] = bool(torch.equal(buf, spec_frame))
+        best = ms if best is None else min(best, ms)
+    r.set_tile_order("lpt")
+    out["new_view_mpixels_per_s"] = round(px / (best * 1e-3) / 1e6, 1)
+    out["note"] = ("repeated view: pixels dealt to waves by the previous frame's per-pixel evaluation counts, waves handed out longest "
+                   "first (schedule only; no pixel value is reused); new view: the better fixed tile order, which is what every frame "
+                   "of a moving camera gets (the orbit workload measures that case)")
+    return out
+
+
 def startup_times(sc: S.Scene, w: int, h: int, max_steps: int, device: int) -> dict:
     """Tiered start-up (lol_gpu_upload_program), on contexts of their own BEFORE anything else has compiled
     this scene in this process: how long render_prepare's part takes with the scene compiler really running (disk cache
@@ -879,6 +910,8 @@ def main():
             out["implied_mpixels_per_s_if_root_is_the_critical_path"] = round(w * h / (dt / steps) / 1e6, 1)
         if world == 1 and not orbit and local is not None:       # (local is None in the 1-rank gather rehearsal)
             out["kernels"] = both_kernels(r, sc, local, w, h, max_steps, cams[0], stream, k_avg, px_per_launch)
+        if world == 1 and not orbit and local is not None and tile["mode"] == "lpt":
+            out["scheduling"] = scheduling_rates(r, local, w, h, max_steps, cams[0], stream, k_avg, px_per_launch)
         if world == 1 and not args.no_cpu_baseline and not orbit and local is not None:
             base, ctr = cpu_baseline(sc, cfg, gpu_frame=local.cpu().numpy().view(np.uint32))
             out["cpu_baseline"] = base

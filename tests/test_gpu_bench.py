@@ -67,6 +67,11 @@ def test_default_line_carries_roofline_cpu_baseline_and_both_kernels():
     # the order of the tiles is the LIBRARY's business: its default, longest tiles first, with the sorts it has done so far
     assert out["tile_order"] == "lpt" and out["tile_order_mode"] == "lpt" and out["tile_order_decided_by"].startswith("liblol_gpu")
     assert out["tile_order_sorts_or_decisions"] >= 2
+    # what the repeated view buys is on the record: the same frame in the two fixed orders (= any frame with a new camera)
+    sch = out["scheduling"]
+    assert sch["fixed_rows_frame_equal"] is True and sch["fixed_cols_frame_equal"] is True
+    assert sch["new_view_mpixels_per_s"] == max(sch["fixed_rows_mpixels_per_s"], sch["fixed_cols_mpixels_per_s"])
+    assert sch["repeated_view_mpixels_per_s"] > sch["new_view_mpixels_per_s"] > 0
     # `valu` describes the machine; nothing in it called a fraction exceeds 1
     v = out["valu"]
     assert "frac" not in v and v["reference_equivalent_tops"] > 0 and 0 < v["lane_efficiency"] <= 1
