@@ -329,7 +329,7 @@ def both_kernels(r, sc, spec_frame, w, h, max_steps, fc, stream, spec_ms, px, fr
     return out
 
 
-def scheduling_rates(r, spec_frame, w, h, max_steps, fc, stream, scheduled_ms, px, frames: int = 5) -> dict:
+def scheduling_rates(r, spec_frame, w, h, max_steps, fc, stream, scheduled_ms, px, frames: int = 10, warm: int = 16) -> dict:
     """What the timed frames owe to the repeated view.  `value` is quoted on the workload BASELINE.json names —
     one camera, frame after frame — and while the camera stands still the library schedules a frame by what the frame before
     cost (every pixel still computed from scratch).  A frame with a NEW camera has no such tables and runs in a fixed tile
@@ -337,15 +337,15 @@ def scheduling_rates(r, spec_frame, w, h, max_steps, fc, stream, scheduled_ms, p
     out = {"repeated_view_mpixels_per_s": round(px / (scheduled_ms * 1e-3) / 1e6, 1)}
     buf = torch.zeros_like(spec_frame)
     best = None
-    for order in ("rows", "cols"):
+    for order in ("rows", "cols", "rows"):                # (rows twice: the first series also absorbs what is left of the ramp)
         r.set_tile_order(order)
         ev = []
-        for i in range(2 + frames):
+        for i in range(warm + frames):                    # (the device has idled while the other context was torn down: let it ramp)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             r.render_into(buf.data_ptr(), w, h, max_steps, stream=stream, frame_camera=fc)
             e1.record()
-            if i >= 2:
+            if i >= warm:
                 ev.append((e0, e1))
         torch.cuda.synchronize()
         ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)

@@ -12,6 +12,10 @@ B="python3 $R/bench.py --steps 20 --warmup 5"
 # compiles: one plain run first fills the on-disk code-object cache, the profiled runs load from it, and the recorded
 # kernel_key is the one the driver's own `python bench.py` will see.
 export LOL_GPU_CACHE_DIR=$O/code_cache LOL_GPU_CACHE_ANY_COMPILER=1      # a cache of this recipe's own, shared by all its runs
+# (the start-up leg compiles the scene with the disk cache switched off and the process then keeps THAT code object: the plain
+#  run would store nothing, a profiled run would use the other compiler's — so all of these go without that leg, and a plain run
+#  at the end records it)
+export LOL_BENCH_STARTUP=0
 python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/plain_first.json 2> /dev/null || exit 1
 LOL_GPU_SPECIALIZE=0 python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 || exit 1
 LOL_BENCH_HOST_SURFACE=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > $O/stats.log 2>&1 || exit 1
@@ -52,5 +56,7 @@ for n in write fetch sq sq2 sq3; do
 	if cmp -s $O/${TAG}_spec_pmc_${n}_counter_collection.csv $O/${TAG}_interp_pmc_${n}_counter_collection.csv; then echo "spec and interp $n CSVs are identical"; exit 1; fi
 done
 cd $R
+unset LOL_BENCH_STARTUP
+python3 bench.py 2> /dev/null | grep -o '^{.*' > $O/${TAG}_spec_c3_plain_bench.json
 for w in c2 c4 orbit; do python3 bench.py --no-cpu-baseline --workload $w 2> /dev/null | grep -o '^{.*' > $O/${TAG}_spec_${w}_1gpu_bench.json; done
 ls $O | grep -v "^spec_\|^interp_\|^stats$"
