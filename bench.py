@@ -910,7 +910,7 @@ def main():
             out["implied_mpixels_per_s_if_root_is_the_critical_path"] = round(w * h / (dt / steps) / 1e6, 1)
         if world == 1 and not orbit and local is not None:       # (local is None in the 1-rank gather rehearsal)
             out["kernels"] = both_kernels(r, sc, local, w, h, max_steps, cams[0], stream, k_avg, px_per_launch)
-        if world == 1 and not orbit and local is not None and tile["mode"] == "lpt":
+        if world == 1 and not orbit and local is not None and tile["mode"] == "lpt" and os.environ.get("LOL_BENCH_SCHEDULING", "1") != "0":
             out["scheduling"] = scheduling_rates(r, local, w, h, max_steps, cams[0], stream, k_avg, px_per_launch)
         if world == 1 and not args.no_cpu_baseline and not orbit and local is not None:
             base, ctr = cpu_baseline(sc, cfg, gpu_frame=local.cpu().numpy().view(np.uint32))

@@ -18,12 +18,9 @@ export LOL_GPU_CACHE_DIR=$O/code_cache LOL_GPU_CACHE_ANY_COMPILER=1      # a cac
 export LOL_BENCH_STARTUP=0
 python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/plain_first.json 2> /dev/null || exit 1
 LOL_GPU_SPECIALIZE=0 python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 || exit 1
-LOL_BENCH_HOST_SURFACE=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > $O/stats.log 2>&1 || exit 1
-grep -o '^{.*' $O/stats.log | tail -1 > $O/${TAG}_spec_c3_bench.json
 keyof() { python3 -c "import json,sys; print(json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])['config']['kernel_key'])" $1; }
-[ "$(keyof $O/plain_first.json)" = "$(keyof $O/${TAG}_spec_c3_bench.json)" ] || { echo "the profiled run compiled its own kernel ($(keyof $O/${TAG}_spec_c3_bench.json)), not the plain run's ($(keyof $O/plain_first.json))"; exit 1; }
-cp "$(find $O/stats -name "*kernel_stats.csv" | head -1)" $O/${TAG}_spec_c3_kernel_stats.csv
 BP="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+export LOL_BENCH_SCHEDULING=0        # the counter passes average over dispatches: no fixed-order frames of the `scheduling` leg among them
 pmc() { # name, counters...  → one rocprofv3 pass in a directory of its own ($PFX = which kernel the bench times)
 	n=$1; shift
 	timeout -k 10 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/${PFX}_$n -- $BP > $O/${PFX}_$n.log 2>&1 || return 1
@@ -49,14 +46,23 @@ PFX=interp; WANT=
 passes || exit 1
 set -- $(key); [ "$1" = render_interp ] || { echo "expected render_interp, bench timed $1"; exit 1; }
 python3 $R/tools/pmc_summary.py --merge --kernel render_interp --kernel-key $2 --min-dispatches 100 --workload c3 --pixels 8294400 --out $O/pmc_traffic.json $O/${TAG}_interp_pmc_*_counter_collection.csv > $O/pmc_interp.txt || exit 1
-python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline 2> /dev/null | grep -o '^{.*' > $O/${TAG}_interp_c3_bench.json
+# the counter summary of THIS run is what the records below quote (`roofline.traffic`, `valu.issue_frac`): bench.py reads
+# profiles/pmc_traffic.json, so it goes there now — on the box; the same file is copied into the repository afterwards
+cp $O/pmc_traffic.json $R/profiles/pmc_traffic.json
+LOL_BENCH_SCHEDULING=1 python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline 2> /dev/null | grep -o '^{.*' > $O/${TAG}_interp_c3_bench.json
 unset LOL_GPU_SPECIALIZE
+# kernel-trace statistics of the bench's own frames only (no `scheduling` / host-surface legs: their frames are other frames),
+# so that the average can be held against the HIP-event average in the record
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > $O/stats.log 2>&1 || exit 1
+grep -o '^{.*' $O/stats.log | tail -1 > $O/${TAG}_spec_c3_bench.json
+[ "$(keyof $O/plain_first.json)" = "$(keyof $O/${TAG}_spec_c3_bench.json)" ] || { echo "the profiled run compiled its own kernel ($(keyof $O/${TAG}_spec_c3_bench.json)), not the plain run's ($(keyof $O/plain_first.json))"; exit 1; }
+cp "$(find $O/stats -name "*kernel_stats.csv" | head -1)" $O/${TAG}_spec_c3_kernel_stats.csv
 # the passes of the two kernels must not be copies of one another (round 2's were: one output directory for both)
 for n in write fetch sq sq2 sq3; do
 	if cmp -s $O/${TAG}_spec_pmc_${n}_counter_collection.csv $O/${TAG}_interp_pmc_${n}_counter_collection.csv; then echo "spec and interp $n CSVs are identical"; exit 1; fi
 done
 cd $R
-unset LOL_BENCH_STARTUP
+unset LOL_BENCH_STARTUP LOL_BENCH_SCHEDULING LOL_BENCH_HOST_SURFACE
 python3 bench.py 2> /dev/null | grep -o '^{.*' > $O/${TAG}_spec_c3_plain_bench.json
 for w in c2 c4 orbit; do python3 bench.py --no-cpu-baseline --workload $w 2> /dev/null | grep -o '^{.*' > $O/${TAG}_spec_${w}_1gpu_bench.json; done
 ls $O | grep -v "^spec_\|^interp_\|^stats$"
