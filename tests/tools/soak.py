@@ -1,4 +1,4 @@
-"""Soak: many random scenes, GPU (spec + interp) vs the CPU oracle.  python tests/tools/soak.py [n] [seed] [stress | onek | still]
+"""Soak: many random scenes, GPU (spec + interp) vs the CPU oracle.  python tests/tools/soak.py [n] [seed] [stress] [onek] [still]
 still: every scene is rendered five times under one camera — the first frames in a fixed order and through rectangles, the
 later ones with their pixels dealt to waves by cost and the waves handed out longest first (lol_gpu.hip) — and the LAST frame is
 what is held against the oracle (pixels, colours, ids, distances, step counts)."""
@@ -12,9 +12,10 @@ from loltracer_amd import gpu, scene as S
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-stress = len(sys.argv) > 3 and sys.argv[3] == "stress"
-onek = len(sys.argv) > 3 and sys.argv[3] == "onek"      # every smooth union of a scene shares one k: the interpreter folds its pops (MOPB_POST)
-still = len(sys.argv) > 3 and sys.argv[3] == "still"
+modes = sys.argv[3:]                                    # any of: stress onek still (e.g. "still stress": the repeated view of the stress scenes)
+stress = "stress" in modes
+onek = "onek" in modes                                  # every smooth union of a scene shares one k: the interpreter folds its pops (MOPB_POST)
+still = "still" in modes
 rng = np.random.default_rng(seed)
 
 
