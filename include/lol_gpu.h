@@ -226,6 +226,12 @@ int         lol_gpu_verify_smin_no_fixup(lol_gpu* ctx, float k, unsigned long lo
  * those instructions; this sweeps 2^32 quotients of that box on the device against '/' (seed 0: the fixed exponent corners a
  * context checks before it uses the shortcut; other seeds: pseudo-random exponents and divisor mantissas).  0 = equal. */
 int         lol_gpu_verify_shadow_division(lol_gpu* ctx, uint32_t seed, unsigned long long* mismatches);
+/* Gamma and quantisation of a colour channel — Uint8 v = powf(c, 1 / 2.2f) * 255 (naive_renderer.c:231-232, renderer.h:17-22) —
+ * through a table of 256 thresholds instead of the powf (lol_kernel.h, gamma_u8_table): used by frames only after this sweep of
+ * every float in [0, 1] found no difference on the context's device (it runs at the first upload; LOL_GPU_GAMMA_TABLE=0 keeps the
+ * powf).  *mismatches = floats on which the two routes differ (0 = proven, ~0 = could not run); table (may be NULL): the 257
+ * thresholds, T[k] = the smallest c whose channel value is >= k, T[0] = 0, T[256] = +inf. */
+int         lol_gpu_verify_gamma_table(lol_gpu* ctx, unsigned long long* mismatches, float* table);
 /*
  * Escaped rays are shaded with material #0 (naive_renderer.c:103-112).  When that material has
  * diffuse == specular == 0, shininess >= 0 and all light intensities are finite, their colour is exactly

@@ -169,6 +169,9 @@ struct lol_gpu {
 	struct DivProof { uint32_t k_bits; bool ok, no_fixup_ok; };
 	std::vector<DivProof> div_verified;  /* per smoothness constant: smin_h_fast proven / proven without v_div_fixup too */
 	unsigned long long* d_bad = nullptr; /* mismatch counter of the verification kernels */
+	float*       d_gamma = nullptr;      /* gamma thresholds (lol_kernel.h, gamma_u8_table): GAMMA_LEVELS + 1 floats */
+	int          gamma_verified = -1;    /* -1 not run, 1 the table route == the powf route for every float in [0, 1] on this device, 0 not */
+	bool         gamma_table = false;    /* frames of the current scene use it (want_fast at the last upload) */
 	int          wave_w = LOL_WAVE_W, wave_h = LOL_WAVE_H, waves_x = LOL_WAVES_X;   /* footprint of the spec kernel */
 	/* lol_gpu_set_tile_order.  AUTO: the first frames of a (scene, size, partition) alternate between the two orders, each
 	 * between two events on its launch stream; later frames collect the finished ones without waiting (tile_auto_*) */
@@ -411,6 +414,37 @@ __global__ __launch_bounds__(VERIFY_THREADS) void verify_fdiv_kernel(uint32_t se
 	if (n_bad) atomicAdd(bad, (unsigned long long)n_bad);
 }
 
+/* The gamma staircase (lol_kernel.h, "gamma + quantisation").  Thread k finds T[k], the smallest float in [0, 1] whose channel
+ * value (Uint8)(powf(c, 1 / 2.2f) * 255) is >= k, by bisection over the bit patterns (for floats >= +0 the order of the bits is
+ * the order of the values) — which presumes the staircase monotone; verify_gamma_kernel then proves table route == powf route
+ * for EVERY c, and with it the presumption. */
+__global__ __launch_bounds__(lol::GAMMA_LEVELS) void gamma_thresholds_kernel(float* T) {
+	const uint32_t k = threadIdx.x;
+	if (k == 0) { T[0] = 0.f; T[lol::GAMMA_LEVELS] = __builtin_inff(); return; }
+	uint32_t lo = 0u, hi = 0x3f800000u;                 /* value(lo) = 0 < k <= 255 = value(hi) */
+	while (hi - lo > 1u) {
+		const uint32_t mid = lo + (hi - lo) / 2u;
+		if (lol::gamma_u8_exact(__builtin_bit_cast(float, mid)) >= k) hi = mid; else lo = mid;
+	}
+	T[k] = __builtin_bit_cast(float, hi);
+}
+/* every float in [+0, 1] — bit patterns 0 ... 0x3f800000 — through both routes */
+constexpr unsigned GAMMA_VERIFY_BLOCKS = 16384;         /* x VERIFY_THREADS x VERIFY_ITERS = 2^30 > 0x3f800000 */
+__global__ __launch_bounds__(VERIFY_THREADS) void verify_gamma_kernel(const float* T, unsigned long long* bad) {
+	__shared__ float t[lol::GAMMA_LEVELS + 1];
+	for (uint32_t i = threadIdx.x; i <= (uint32_t)lol::GAMMA_LEVELS; i += VERIFY_THREADS) t[i] = T[i];
+	__syncthreads();
+	const uint32_t base = blockIdx.x * VERIFY_THREADS + threadIdx.x;
+	unsigned n = 0;
+	for (uint32_t it = 0; it < VERIFY_ITERS; it++) {
+		const uint32_t bits = base + it * (GAMMA_VERIFY_BLOCKS * VERIFY_THREADS);
+		if (bits > 0x3f800000u) continue;
+		const float c = __builtin_bit_cast(float, bits);
+		if (lol::gamma_u8_table(c, t) != lol::gamma_u8_exact(c)) n++;
+	}
+	if (n) atomicAdd(bad, (unsigned long long)n);
+}
+
 /* diagnostic: out[i] = powf_glibc(x[i], y[i]) — lets the tests compare the device's powf with the CPU's */
 __global__ __launch_bounds__(256) void powf_batch_kernel(const float* x, const float* y, float* out, size_t n) {
 	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -435,6 +469,20 @@ unsigned long long run_verify(lol_gpu* ctx, int sqrt_kind, float k, unsigned lon
 	return bad[0];
 }
 
+/* builds the gamma table of this context (once) and proves it; mismatch count, ~0ull when the check could not run */
+unsigned long long run_verify_gamma(lol_gpu* ctx) {
+	if (!ctx->d_bad && hipMalloc(reinterpret_cast<void**>(&ctx->d_bad), 2 * sizeof(unsigned long long)) != hipSuccess) return ~0ull;
+	const bool fresh = ctx->d_gamma == nullptr;         /* (a table frames may be reading is proven again, not rebuilt) */
+	if (fresh && hipMalloc(reinterpret_cast<void**>(&ctx->d_gamma), (lol::GAMMA_LEVELS + 1) * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); ctx->d_gamma = nullptr; return ~0ull; }
+	unsigned long long bad[2] = { 0, 0 };
+	if (hipMemcpy(ctx->d_bad, bad, sizeof bad, hipMemcpyHostToDevice) != hipSuccess) return ~0ull;
+	if (fresh) hipLaunchKernelGGL(gamma_thresholds_kernel, dim3(1), dim3(lol::GAMMA_LEVELS), 0, ctx->stream, ctx->d_gamma);
+	hipLaunchKernelGGL(verify_gamma_kernel, dim3(GAMMA_VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, ctx->d_gamma, ctx->d_bad);
+	if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return ~0ull;
+	if (hipMemcpy(bad, ctx->d_bad, sizeof bad, hipMemcpyDeviceToHost) != hipSuccess) return ~0ull;
+	return bad[0];
+}
+
 /* ------------------------------------------------- scene → HIP source (the "JIT") */
 
 std::string fbits(float v) {
@@ -452,6 +500,7 @@ struct FastPaths {
 	std::vector<float> div_ok;            /* smoothness constants k whose smin_h_fast verified */
 	std::vector<float> div_nf_ok;         /* ... and verified without v_div_fixup as well (smin_h_fast<false>) */
 	bool fdiv_ok = false;                 /* fdiv_fast == '/' over the sweep of verify_fdiv_kernel: the shadow march may use it */
+	bool gamma_ok = false;                /* the gamma table route == the powf route for every float in [0, 1] (verify_gamma_kernel) */
 	bool has(float k) const {
 		for (float v : div_ok) if (memcmp(&v, &k, 4) == 0) return true;
 		return false;
@@ -1442,6 +1491,14 @@ FastPaths prove_fast_paths(lol_gpu* ctx, const lol_program& prog) {
 	}
 	fast.sqrt_kind = ctx->sqrt_verified;
 	fast.sqrt_tiny_ok = ctx->sqrt_tiny_ok;
+	/* gamma + quantisation through the table (lol_kernel.h); LOL_GPU_GAMMA_TABLE=0: through powf (A/B runs) */
+	{
+		const char* genv = getenv("LOL_GPU_GAMMA_TABLE");
+		if (!(genv && genv[0] == '0')) {
+			if (ctx->gamma_verified < 0) ctx->gamma_verified = run_verify_gamma(ctx) == 0 ? 1 : 0;
+			fast.gamma_ok = ctx->gamma_verified == 1;
+		}
+	}
 	/* The shadow march's division shortcut (lol_kernel.h, fdiv_fast) is OFF unless LOL_GPU_SHADOW_FDIV=1: exact, but it bought
 	 * C3 0.95 % in a same-call A/B (7854 vs 7779 Mpixels/s, profiles/r4_ab_fdiv.txt), below the 1.5 % the review set as the bar
 	 * for keeping it in the default kernel.  Asked for, it is still only used after this device's own sweep agrees. */
@@ -1671,6 +1728,7 @@ void lol_gpu_destroy(lol_gpu* ctx) {
 	}
 
 	if (ctx->d_bad) (void)hipFree(ctx->d_bad);
+	if (ctx->d_gamma) (void)hipFree(ctx->d_gamma);
 	if (ctx->tiles.have_events) for (hipEvent_t e : ctx->tiles.ev) (void)hipEventDestroy(e);
 	lpt_release(ctx);
 	delete ctx;
@@ -2162,6 +2220,16 @@ int lol_gpu_verify_smin_no_fixup(lol_gpu* ctx, float k, unsigned long long* mism
 	return LOL_GPU_OK;
 }
 
+/* ... and for the gamma table (lol_kernel.h, gamma_u8_table): floats in [0, 1] on which the table route and the powf route
+ * give different channel values; 0 = proven, ~0 = could not run.  table (may be NULL) receives the 257 thresholds. */
+int lol_gpu_verify_gamma_table(lol_gpu* ctx, unsigned long long* mismatches, float* table) {
+	if (!ctx || !mismatches) return LOL_GPU_ERR_ARG;
+	LOL_HIP(ctx, hipSetDevice(ctx->device));
+	*mismatches = run_verify_gamma(ctx);
+	if (table && ctx->d_gamma) LOL_HIP(ctx, hipMemcpy(table, ctx->d_gamma, (lol::GAMMA_LEVELS + 1) * sizeof(float), hipMemcpyDeviceToHost));
+	return LOL_GPU_OK;
+}
+
 const char* lol_gpu_specialize_log(const lol_gpu* ctx) { return ctx ? ctx->spec_log.c_str() : ""; }
 
 int lol_gpu_specialize_wait(lol_gpu* ctx) {
@@ -2273,10 +2341,11 @@ int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog) {
 	ctx->finite_scene = shadow_settle_ok(*prog);
 	ctx->interp_sqrt_kind = fast.sqrt_kind == 3 ? 3 : 0;
 	ctx->shadow_fdiv = fast.fdiv_ok;
+	ctx->gamma_table = fast.gamma_ok;
 	{
 		/* what render_interp executes = this build's code (lol_kernel.h AND this file: record layout, flags) + the lists */
 		std::string id = std::string(LOL_BUILD_ID) + "|" + fnv_hex(mops.data(), mops.size() * 4) + "|" + std::to_string(ctx->interp_sqrt_kind) +
-		                 (ctx->shadow_fdiv ? "|fdiv" : "");
+		                 (ctx->shadow_fdiv ? "|fdiv" : "") + (ctx->gamma_table ? "|gamma" : "");
 		ctx->interp_key = fnv_hex(id.data(), id.size());
 	}
 	resolve_skips(ctx);
@@ -2332,6 +2401,7 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	L.ambient[0] = P.ambient_color.x; L.ambient[1] = P.ambient_color.y; L.ambient[2] = P.ambient_color.z;
 	L.flags = (ctx->miss_skip ? lol::FLAG_MISS_SKIP : 0u) | (ctx->dark_skip ? lol::FLAG_DARK_SKIP : 0u) |
 	          (ctx->shadow_settle && camera_sane(*cam) ? lol::FLAG_SHADOW_SETTLED | (ctx->shadow_fdiv ? lol::FLAG_SHADOW_FDIV : 0u) : 0u);
+	if (ctx->gamma_table) { L.flags |= lol::FLAG_GAMMA_TABLE; L.gamma_table = ctx->d_gamma; }
 	L.dst = static_cast<uint32_t*>(dst);
 	L.pitch_px = (uint32_t)(pitch_bytes / 4);
 	L.fmt_shift = ctx->fmt_shift; L.fmt_loss = ctx->fmt_loss; L.fmt_amask = ctx->fmt_amask;

@@ -71,6 +71,8 @@ constexpr u32 FLAG_SHADOW_SETTLED = 4u;   /* a shadow march ends as soon as its 
 constexpr u32 FLAG_TILE_TABLE = 32u;      /* a one-dimensional grid of one-wave blocks: block b shades the 64 pixels of wave slot Launch::tile_order[b] of the
                                            * pixel table Launch::lane_pixels (pixels dealt to waves by cost, waves handed out longest first: lol_gpu.hip) */
 constexpr u32 FLAG_SHADOW_FDIV = 16u;     /* with FLAG_SHADOW_SETTLED: 50 s / t by fdiv_fast where the Sdf policy allows it (soft_shadow) */
+constexpr u32 FLAG_GAMMA_TABLE = 64u;     /* gamma + quantisation of a channel through Launch::gamma_table (gamma_u8_table), proven equal to the
+                                           * powf route on this device for every float in [0, 1] (lol_gpu.hip, verify_gamma_kernel) */
 
 /* = lol_frame_camera */
 struct Cam { float origin[3], dir[3], right[3], up[3]; float width, height; };
@@ -110,6 +112,7 @@ struct Launch {
 	u32    tile_stride;          /* both tables are indexed by tile_slot(block): ceil(blocks / 8) */
 	const u32* lane_pixels;
 	unsigned short* pixel_cost;
+	const float* gamma_table;    /* FLAG_GAMMA_TABLE: GAMMA_LEVELS + 1 thresholds (gamma_u8_table) */
 };
 constexpr u32 LANE_PADDING = 1u << 31;
 
@@ -121,15 +124,16 @@ constexpr u32 LANE_PADDING = 1u << 31;
 struct LaunchTail {
 	u32*   dst; u32 pitch_px; u32 fmt_shift, fmt_loss, fmt_amask;
 	float* dbg_rgb; float* dbg_hit_dist; u32* dbg_hit_id; u32* dbg_steps;
+	const float* gamma_table;
 };
 __device__ __forceinline__ LaunchTail launch_tail(const Launch& L0) {
 #if defined(__HIP_DEVICE_COMPILE__)
 	typedef const __attribute__((address_space(4))) Launch* kernarg_ptr;
 	kernarg_ptr L = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
 	asm volatile("" : "+s"(L));                    /* opaque: these loads are not merged with the ones at kernel entry */
-	return { L->dst, L->pitch_px, L->fmt_shift, L->fmt_loss, L->fmt_amask, L->dbg_rgb, L->dbg_hit_dist, L->dbg_hit_id, L->dbg_steps };
+	return { L->dst, L->pitch_px, L->fmt_shift, L->fmt_loss, L->fmt_amask, L->dbg_rgb, L->dbg_hit_dist, L->dbg_hit_id, L->dbg_steps, L->gamma_table };
 #else
-	return { L0.dst, L0.pitch_px, L0.fmt_shift, L0.fmt_loss, L0.fmt_amask, L0.dbg_rgb, L0.dbg_hit_dist, L0.dbg_hit_id, L0.dbg_steps };
+	return { L0.dst, L0.pitch_px, L0.fmt_shift, L0.fmt_loss, L0.fmt_amask, L0.dbg_rgb, L0.dbg_hit_dist, L0.dbg_hit_id, L0.dbg_steps, L0.gamma_table };
 #endif
 }
 
@@ -326,6 +330,29 @@ __device__ __noinline__ float powf_glibc(float x, float y) {
 	res = __builtin_fma(zz, rr2, res);
 	res = res * sc;
 	return (float)res;
+}
+
+/* ---------------------------------------------------------------- gamma + quantisation
+ * What a surface receives of a colour channel is 8 bits: Uint8 r = powf(c, 1 / 2.2f) * 255 (naive_renderer.c:231-232,
+ * renderer.h:17-22), c in [+0, 1] after v3clamp.  As a function of c that is a staircase of 256 steps, so the 8 bits can be had
+ * without the powf (5 % of a C3 frame went into the five powf of a pixel): GAMMA_LEVELS + 1 thresholds — T[k] = the smallest
+ * c whose exact value is >= k, T[0] = 0, T[256] = +inf, found on the device with powf_glibc itself — an estimate of k from the
+ * hardware's log2 / exp2, and two comparisons that correct an estimate one step off.  Used only after the device has run every
+ * float in [0, 1] (2^30 of them) through both routes and found no difference (lol_gpu.hip: verify_gamma_kernel — which also
+ * proves the staircase monotone and the estimate never more than one step off).  The float colour itself (diagnostics:
+ * lol_gpu_debug::rgb) still comes from powf_glibc. */
+constexpr int GAMMA_LEVELS = 256;
+__device__ __forceinline__ u32 gamma_u8_exact(float c) { return (u32)(powf_glibc(c, 1.f / 2.2f) * 255.f) & 0xFFu; }
+__device__ __forceinline__ u32 gamma_u8_table(float c, const float* T) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	const float a = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(c) * (1.f / 2.2f)) * 255.f;      /* c = +0: exp2(-inf) = 0 */
+#else
+	const float a = 0.f;
+#endif
+	u32 k = (u32)a;
+	k = k < (u32)GAMMA_LEVELS - 1u ? k : (u32)GAMMA_LEVELS - 1u;
+	const float lo = T[k], hi = T[k + 1u];
+	return k + (c >= hi ? 1u : 0u) - (c < lo ? 1u : 0u);
 }
 
 /* ---------------------------------------------------------------- fast exact paths
@@ -911,7 +938,7 @@ __host__ __device__ inline u32 common_lds_dwords(u32 n_lights, u32 n_materials, 
 	return (tables_in_lds(n_lights, n_materials, n_roots) ? table_dwords(n_lights, n_materials, n_roots) : 0u) + TILE_W * TILE_H;
 }
 
-struct Pixel { V3 rgb; Hit hit; u32 shadow_steps; };      /* rgb: post-gamma colour; packed into the surface's format by store_pixel */
+struct Pixel { V3 rgb; Hit hit; u32 shadow_steps; };      /* rgb: the clamped colour BEFORE gamma; store_pixel applies gamma and packs it into the surface's format */
 
 /* frame row of local row r of this launch's part (the inverse: lol_gpu_part_frame_row) */
 __device__ __forceinline__ int frame_row(const Launch& L, int r) {
@@ -1008,7 +1035,13 @@ __device__ __forceinline__ Pixel shade_pixel(const Launch& L, Sdf& sdf, const u3
 			V3 refl = sub(scale(n, 2.f * dot(light_dir, n)), light_dir);
 			V3 Id = mul(scale(lds_v3(lp + 3), shadow * di), m_diff);
 			total = add(total, Id);
-			float si = di * powf_glibc(clampf_(dot(refl, camera_dir), 0.f, 1.f), shininess);
+			/* The specular term is I * (shadow * si) * colour.  Under FLAG_DARK_SKIP's conditions (finite intensities and colours,
+			 * shininess >= 0: powf of a base in [0, 1] is finite) a lane with di == 0 or shadow == 0 contributes +-0 whatever the
+			 * powf returns, and +-0 leaves the running sum as it is: a wave in which no lane has both skips the call (the lanes that
+			 * do not need it take si = 0, which gives the same +-0). */
+			float si = 0.f;
+			if (!(L.flags & FLAG_DARK_SKIP) || vote(needed && shadow != 0.f) != 0)      /* (needed: di > 0, and not an escaped lane under FLAG_MISS_SKIP — its material's specular colour is 0) */
+				si = di * powf_glibc(clampf_(dot(refl, camera_dir), 0.f, 1.f), shininess);
 			V3 Is = mul(scale(lds_v3(lp + 6), shadow * si), m_spec);
 			total = add(total, Is);
 		}
@@ -1017,10 +1050,7 @@ __device__ __forceinline__ Pixel shade_pixel(const Launch& L, Sdf& sdf, const u3
 	/* v3clamp: max(min(v, 1), 0) — NaN → 1 (vec.h:63-65) */
 	V3 c = { maxf_(minf_(total.x, 1.f), 0.f), maxf_(minf_(total.y, 1.f), 0.f), maxf_(minf_(total.z, 1.f), 0.f) };
 
-	/* gamma + colorf_to_pixfmt, naive_renderer.c:231-232, renderer.h:17-22 */
-	const float g = 1.f / 2.2f;
-	c = { powf_glibc(c.x, g), powf_glibc(c.y, g), powf_glibc(c.z, g) };
-	return { c, hit, shadow_steps };
+	return { c, hit, shadow_steps };      /* gamma + colorf_to_pixfmt: store_pixel */
 }
 
 /* Pack the lane's colour for the surface, write it (and the optional diagnostics).  Every thread of the block must call this. */
@@ -1030,7 +1060,17 @@ __device__ __forceinline__ void store_pixel(const Launch& L, const Pixel& P, u32
 	/* colorf_to_pixfmt, renderer.h:17-22: Uint8 r = colorf.x * 255 …; SDL_MapRGB(fmt, r, g, b) for a non-palettised format
 	 * (SDL2 src/video/SDL_pixels.c): (r >> Rloss) << Rshift | (g >> Gloss) << Gshift | (b >> Bloss) << Bshift | Amask.
 	 * XRGB8888 = shifts 16 / 8 / 0, no loss, no alpha. */
-	const u32 r8 = (u32)(P.rgb.x * 255.f) & 0xFFu, g8 = (u32)(P.rgb.y * 255.f) & 0xFFu, b8 = (u32)(P.rgb.z * 255.f) & 0xFFu;
+	/* gamma, naive_renderer.c:231-232: the float colour through powf (always for the diagnostics), the 8 bits through the
+	 * proven table when the launch has one */
+	const bool by_table = (L.flags & FLAG_GAMMA_TABLE) != 0u;
+	V3 post = P.rgb;
+	if (!by_table || T.dbg_rgb) {
+		const float g = 1.f / 2.2f;
+		post = { powf_glibc(P.rgb.x, g), powf_glibc(P.rgb.y, g), powf_glibc(P.rgb.z, g) };
+	}
+	u32 r8, g8, b8;
+	if (by_table) { r8 = gamma_u8_table(P.rgb.x, T.gamma_table); g8 = gamma_u8_table(P.rgb.y, T.gamma_table); b8 = gamma_u8_table(P.rgb.z, T.gamma_table); }
+	else { r8 = (u32)(post.x * 255.f) & 0xFFu; g8 = (u32)(post.y * 255.f) & 0xFFu; b8 = (u32)(post.z * 255.f) & 0xFFu; }
 	const u32 px = (r8 >> (T.fmt_loss & 0xFFu)) << (T.fmt_shift & 0xFFu) |
 	               (g8 >> (T.fmt_loss >> 8 & 0xFFu)) << (T.fmt_shift >> 8 & 0xFFu) |
 	               (b8 >> (T.fmt_loss >> 16 & 0xFFu)) << (T.fmt_shift >> 16 & 0xFFu) | T.fmt_amask;
@@ -1059,7 +1099,7 @@ __device__ __forceinline__ void store_pixel(const Launch& L, const Pixel& P, u32
 #endif
 		if (!(e & LANE_PADDING)) {
 			const unsigned long long o = (unsigned long long)gr * L.w + gx;
-			if (T.dbg_rgb) { T.dbg_rgb[o * 3 + 0] = P.rgb.x; T.dbg_rgb[o * 3 + 1] = P.rgb.y; T.dbg_rgb[o * 3 + 2] = P.rgb.z; }
+			if (T.dbg_rgb) { T.dbg_rgb[o * 3 + 0] = post.x; T.dbg_rgb[o * 3 + 1] = post.y; T.dbg_rgb[o * 3 + 2] = post.z; }
 			if (T.dbg_hit_dist) T.dbg_hit_dist[o] = P.hit.dist;
 			if (T.dbg_hit_id) T.dbg_hit_id[o] = P.hit.id;
 			if (T.dbg_steps) T.dbg_steps[o] = (P.hit.steps & 0xFFFFu) | (P.shadow_steps << 16);
@@ -1087,7 +1127,7 @@ __device__ __forceinline__ void store_pixel(const Launch& L, const Pixel& P, u32
 	const int gx = bx * TILE_W + tx, gr = by * TILE_H + ty;
 	if (gx < L.w && gr < L.n_rows) {
 		unsigned long long o = (unsigned long long)gr * L.w + gx;
-		if (T.dbg_rgb) { T.dbg_rgb[o * 3 + 0] = P.rgb.x; T.dbg_rgb[o * 3 + 1] = P.rgb.y; T.dbg_rgb[o * 3 + 2] = P.rgb.z; }
+		if (T.dbg_rgb) { T.dbg_rgb[o * 3 + 0] = post.x; T.dbg_rgb[o * 3 + 1] = post.y; T.dbg_rgb[o * 3 + 2] = post.z; }
 		if (T.dbg_hit_dist) T.dbg_hit_dist[o] = P.hit.dist;
 		if (T.dbg_hit_id) T.dbg_hit_id[o] = P.hit.id;
 		if (T.dbg_steps) T.dbg_steps[o] = (P.hit.steps & 0xFFFFu) | (P.shadow_steps << 16);

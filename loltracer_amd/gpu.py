@@ -168,6 +168,8 @@ def gpu_lib() -> C.CDLL:
         lib.lol_gpu_verify_smin_no_fixup.restype = C.c_int
         lib.lol_gpu_verify_shadow_division.argtypes = [vp, C.c_uint32, P(C.c_ulonglong)]
         lib.lol_gpu_verify_shadow_division.restype = C.c_int
+        lib.lol_gpu_verify_gamma_table.argtypes = [vp, P(C.c_ulonglong), P(C.c_float)]
+        lib.lol_gpu_verify_gamma_table.restype = C.c_int
         lib.lol_gpu_powf_batch.argtypes = [vp, vp, vp, vp, C.c_size_t, vp]
         lib.lol_gpu_powf_batch.restype = C.c_int
         lib.lol_gpu_set_miss_skip.argtypes = [vp, C.c_int]
@@ -255,7 +257,7 @@ EXPORTED_SYMBOLS = [
     "lol_gpu_abi_version", "lol_gpu_device_count", "lol_gpu_create", "lol_gpu_destroy", "lol_gpu_error", "lol_gpu_upload_program",
     "lol_gpu_part_rows", "lol_gpu_render_device", "lol_gpu_render_host", "lol_gpu_sync", "lol_gpu_malloc",
     "lol_gpu_free", "lol_gpu_memcpy_d2h", "lol_gpu_kernel_name", "lol_gpu_set_specialize",
-    "lol_gpu_specialize_log", "lol_gpu_specialize_wait", "lol_gpu_specialize_state", "lol_gpu_multi_specialize_wait", "lol_gpu_compile_offline", "lol_gpu_verify_fast_paths", "lol_gpu_verify_smin_no_fixup", "lol_gpu_verify_shadow_division", "lol_gpu_set_miss_skip",
+    "lol_gpu_specialize_log", "lol_gpu_specialize_wait", "lol_gpu_specialize_state", "lol_gpu_multi_specialize_wait", "lol_gpu_compile_offline", "lol_gpu_verify_fast_paths", "lol_gpu_verify_smin_no_fixup", "lol_gpu_verify_shadow_division", "lol_gpu_verify_gamma_table", "lol_gpu_set_miss_skip",
     "lol_gpu_miss_skip_active", "lol_gpu_set_exact_skips", "lol_gpu_powf_batch", "lol_gpu_device", "lol_gpu_sdf_batch", "lol_gpu_set_cull", "lol_gpu_set_tile_order", "lol_gpu_tile_order", "lol_gpu_cull_bounds", "lol_gpu_cull_bounds_clusters",
     "lol_gpu_render_host_begin", "lol_gpu_render_host_end", "lol_gpu_render_host_pending",
     "lol_gpu_multi_create", "lol_gpu_multi_destroy", "lol_gpu_multi_error", "lol_gpu_multi_device_count",
@@ -423,6 +425,14 @@ class Renderer:
         n = C.c_ulonglong()
         self._check(self._lib.lol_gpu_verify_shadow_division(self._ctx, seed, C.byref(n)))
         return n.value
+
+    def verify_gamma_table(self):
+        """(mismatches, thresholds): floats in [0, 1] on which gamma through the table and through powf give different channel
+        values (0 means proven), and the 257 thresholds of the table."""
+        n = C.c_ulonglong()
+        t = (C.c_float * 257)()
+        self._check(self._lib.lol_gpu_verify_gamma_table(self._ctx, C.byref(n), t))
+        return n.value, list(t)
 
     def powf_batch(self, x_ptr: int, y_ptr: int, out_ptr: int, n: int, stream: int | None = None):
         """out[i] = the kernel's powf(x[i], y[i]) on device arrays (diagnostic for tests)."""

@@ -78,3 +78,52 @@ def test_random_pairs_including_specials(ctx):
     y = np.concatenate([y, ys.ravel(), rng.uniform(-60, 60, 1 << 20).astype(np.float32)])
     ok = same_bits(device_powf(torch, r, x, y), O.powf(x, y))
     assert ok.all(), (x[~ok][:5], y[~ok][:5])
+
+
+def test_gamma_table_equals_powf_for_every_colour_input(ctx):
+    """Gamma + quantisation through the 256 thresholds (lol_kernel.h: gamma_u8_table) against (Uint8)(powf(c, 1/2.2f) * 255) for
+    EVERY float c in [0, 1], on the device (the sweep a context runs before its frames use the table), and the thresholds
+    themselves against the CPU's powf: T[k] is the first float whose channel value reaches k."""
+    import ctypes
+    torch, r = ctx
+    bad, T = r.verify_gamma_table()
+    assert bad == 0
+    T = np.array(T, dtype=np.float32)
+    assert T[0] == 0.0 and np.isinf(T[256]) and T[256] > 0 and T[255] <= 1.0
+    assert np.all(np.diff(T[:256]) > 0), "thresholds strictly increasing"
+    assert abs(float(T[1]) - (1 / 255) ** 2.2) < 1e-7 and abs(float(T[128]) - (128 / 255) ** 2.2) < 1e-5
+    if has_fma():
+        libm = ctypes.CDLL("libm.so.6")
+        libm.powf.restype = ctypes.c_float
+        libm.powf.argtypes = [ctypes.c_float, ctypes.c_float]
+        g = np.float32(1.0) / np.float32(2.2)
+
+        def level(c):
+            return int(np.float32(libm.powf(float(c), float(g))) * np.float32(255.0)) & 0xFF
+        for k in range(1, 256):
+            below = np.nextafter(T[k], np.float32(0.0), dtype=np.float32)
+            assert level(T[k]) == k and level(below) == k - 1, k
+
+
+def test_frames_with_and_without_the_gamma_table_are_the_same(ctx):
+    """A frame whose 8 bits come from the table (the default) equals the frame of a context that keeps powf (specialize mode 3 /
+    0: no shortcuts), with and without the diagnostics buffers (with them the float colour is computed as well)."""
+    import oracle_lib  # noqa: F401  (tests/ on the path)
+    from loltracer_amd import scene as S
+    from test_gpu_parity import gpu_render
+    torch, _ = ctx
+    sc = S.Scene.parse_file(os.path.join(os.path.dirname(__file__), "golden", "scenes", "scene4.lol"))
+    w, h = 333, 187
+    frames = {}
+    for mode in (1, 3, 4, 0):
+        r = gpu.Renderer(0, specialize=mode)
+        try:
+            frames[mode] = gpu_render(torch, r, sc, w, h)["xrgb"]
+            plain = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+            r.render_into(plain.data_ptr(), w, h, 256)      # no diagnostics: the table route alone (modes 1, 4)
+            r.sync()
+            assert np.array_equal(plain.cpu().numpy().view(np.uint32), frames[mode][:, :w]), mode
+        finally:
+            r.close()
+    for mode in (3, 4, 0):
+        assert np.array_equal(frames[1], frames[mode]), mode
