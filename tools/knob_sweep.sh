@@ -9,3 +9,8 @@ run LOL_GPU_SMIN_SAT=2
 run LOL_GPU_SCHED=default
 run LOL_GPU_SHADOW_FDIV=1
 run X=0
+run X=0
+for n in 1 2 3 5 0; do run LOL_GPU_SAT_CULL_MIN_PRIMS=$n; done
+for n in 1 2 4 8; do run LOL_GPU_CULL_CLUSTERS=$n; done
+run LOL_GPU_NAN_FLAG=0
+run X=0
