@@ -17,10 +17,14 @@
  *                   these GPUs, each writing its bands into the surface,
  *                   include/lol_gpu.h lol_gpu_multi_*), --parts-per-device N,
  *                   --root-band-rows N (the first device's smaller share),
- *                   --max-steps N, --tile-columns / --tile-rows (the order in
+ *                   --max-steps N, --tile-columns / --tile-rows (pin the order in
  *                   which a launch hands out its tiles, lol_gpu_set_tile_order;
- *                   without either the library times both orders on the first
- *                   frames of a scene and surface size and keeps the faster), and
+ *                   without either the library's default applies: a frame under the
+ *                   camera of the frame before it is scheduled by what that frame
+ *                   cost, any other frame runs in the better of the two fixed orders),
+ *                   --wait-kernel (render_prepare returns only when the scene's own
+ *                   kernel is in place, as the tracing JIT's does; without it the
+ *                   first frames render on the interpreter kernel: benchmarks), and
  *                   --dump-kernel BASE, the counterpart of the JIT renderer's
  *                   -j/--jitdump (tracing_jit_renderer.dasc:424-433): writes the
  *                   scene-specialised kernel as BASE.hip (generated source) and
@@ -80,7 +84,7 @@ void render_prepare(struct render_data* data, int argc, const char* argv[]) {
 	struct hip_renderer* r = calloc(1, sizeof *r);
 	int device = 0;
 	int devices[LOL_GPU_MULTI_MAX_DEVICES], n_devices = 0;
-	int parts_per_device = 0, root_band = -1, tile_order = LOL_GPU_TILES_AUTO;
+	int parts_per_device = 0, root_band = -1, tile_order = -1 /* the library's default: LOL_GPU_TILES_LPT */, wait_kernel = 0;
 	const char* dump = NULL;
 	HOST_PRIVATE(data) = r;
 	if (!r) { fprintf(stderr, "hip_renderer: out of memory\n"); return; }
@@ -98,6 +102,7 @@ void render_prepare(struct render_data* data, int argc, const char* argv[]) {
 		if (!strcmp(argv[i], "--pipeline")) { r->pipeline = 1; continue; }
 		if (!strcmp(argv[i], "--tile-columns")) { tile_order = LOL_GPU_TILES_COLS; continue; }
 		if (!strcmp(argv[i], "--tile-rows")) { tile_order = LOL_GPU_TILES_ROWS; continue; }
+		if (!strcmp(argv[i], "--wait-kernel")) { wait_kernel = 1; continue; }      /* render_prepare returns with the scene's own kernel in place (benchmarks) */
 		if (!(is_device || is_devices || is_steps || is_dump || is_ppd || is_root)) continue;      /* the host's own flags */
 		if (i + 1 >= argc) { fprintf(stderr, "hip_renderer: %s needs a value, ignored\n", argv[i]); break; }
 		const char* v = argv[++i];
@@ -140,15 +145,17 @@ void render_prepare(struct render_data* data, int argc, const char* argv[]) {
 			fprintf(stderr, "hip_renderer: --parts-per-device %d refused\n", parts_per_device);
 		if (root_band >= 0 && lol_gpu_multi_set_root_band_rows(r->multi, root_band) != LOL_GPU_OK)
 			fprintf(stderr, "hip_renderer: --root-band-rows %d refused\n", root_band);
-		(void)lol_gpu_multi_set_tile_order(r->multi, tile_order);
+		if (tile_order >= 0) (void)lol_gpu_multi_set_tile_order(r->multi, tile_order);
 		st = lol_gpu_multi_upload_program(r->multi, &r->program);
 		if (st != LOL_GPU_OK) { fprintf(stderr, "hip_renderer: %s\n", lol_gpu_multi_error(r->multi)); return; }
+		if (wait_kernel) (void)lol_gpu_multi_specialize_wait(r->multi);
 	} else {
 		st = lol_gpu_create(device, &r->gpu);
 		if (st != LOL_GPU_OK) { fprintf(stderr, "hip_renderer: no usable HIP device %d (status %d)\n", device, st); return; }
 		st = lol_gpu_upload_program(r->gpu, &r->program);
 		if (st != LOL_GPU_OK) { fprintf(stderr, "hip_renderer: %s\n", lol_gpu_error(r->gpu)); return; }
-		(void)lol_gpu_set_tile_order(r->gpu, tile_order);
+		if (tile_order >= 0) (void)lol_gpu_set_tile_order(r->gpu, tile_order);
+		if (wait_kernel) (void)lol_gpu_specialize_wait(r->gpu);
 	}
 	r->ready = 1;
 }
