@@ -22,6 +22,8 @@
  *                   without either the library's default applies: a frame under the
  *                   camera of the frame before it is scheduled by what that frame
  *                   cost, any other frame runs in the better of the two fixed orders),
+ *                   --report (one line on stdout at render_destroy: kernel, its key,
+ *                   tile order mode / order in use / sorts so far),
  *                   --wait-kernel (render_prepare returns only when the scene's own
  *                   kernel is in place, as the tracing JIT's does; without it the
  *                   first frames render on the interpreter kernel: benchmarks), and
@@ -62,6 +64,7 @@ struct hip_renderer {
 	int         have_format;    /* the surface's pixel format has been handed to the library ... */
 	lol_gpu_pixel_format format;/* ... and was this */
 	int         format_refused; /* ... or was refused (reported once) */
+	int         report;         /* --report: one line about what the library did, at render_destroy */
 };
 
 /* surf->format → the library (colorf_to_pixfmt maps through the SURFACE's format, renderer.h:17-22; the host re-fetches
@@ -102,6 +105,7 @@ void render_prepare(struct render_data* data, int argc, const char* argv[]) {
 		if (!strcmp(argv[i], "--pipeline")) { r->pipeline = 1; continue; }
 		if (!strcmp(argv[i], "--tile-columns")) { tile_order = LOL_GPU_TILES_COLS; continue; }
 		if (!strcmp(argv[i], "--tile-rows")) { tile_order = LOL_GPU_TILES_ROWS; continue; }
+		if (!strcmp(argv[i], "--report")) { r->report = 1; continue; }
 		if (!strcmp(argv[i], "--wait-kernel")) { wait_kernel = 1; continue; }      /* render_prepare returns with the scene's own kernel in place (benchmarks) */
 		if (!(is_device || is_devices || is_steps || is_dump || is_ppd || is_root)) continue;      /* the host's own flags */
 		if (i + 1 >= argc) { fprintf(stderr, "hip_renderer: %s needs a value, ignored\n", argv[i]); break; }
@@ -215,6 +219,15 @@ int render_thread(void* ptr) {
 void render_destroy(struct render_data* data) {
 	struct hip_renderer* r = HOST_PRIVATE(data);
 	if (!r) return;
+	if (r->report && (r->gpu || r->multi)) {
+		/* the counterpart of the frame log (main.c:196-204) for what happens below the boundary */
+		lol_gpu* g = r->gpu ? r->gpu : lol_gpu_multi_context(r->multi, 0);
+		lol_gpu_tile_order_info t;
+		static const char* const names[] = { "rows", "columns", "auto", "lpt" };
+		if (g && lol_gpu_tile_order(g, &t) == LOL_GPU_OK)
+			printf("hip_renderer: kernel %s (%s), tile order mode %s, in use %s, %d sort(s) / decision(s)\n", lol_gpu_kernel_name(g),
+			       lol_gpu_kernel_key(g), names[t.mode & 3], names[t.order & 3], t.decisions);
+	}
 	lol_gpu_multi_destroy(r->multi);
 	lol_gpu_destroy(r->gpu);
 	lol_program_free(&r->program);

@@ -54,6 +54,28 @@ def test_c_host_renders_through_the_plugin(tmp_path, scenes, threads):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("flags", [[], ["--pipeline"], ["--devices", "0"]])
+def test_c_host_gets_the_librarys_scheduling_without_asking(tmp_path, scenes, flags):
+    """A host that passes no tile-order flag gets the library's default (lol_gpu.h: LOL_GPU_TILES_LPT): with a camera that
+    stands still the frames are scheduled by what the frames before cost (sorts > 0) and the surface still holds the oracle's
+    frame; --tile-rows pins the fixed order.  (Round 4's adapter pinned the fixed-order trial by mistake.)"""
+    out = tmp_path / "f.ppm"
+    w, h = 200, 120
+    base = [HOST, "2", SCENE4, "--size", f"{w}x{h}", "--frames", "9", "--wait-kernel", "--report", "--out", str(out)]
+    p = subprocess.run(base + flags, capture_output=True, text=True, timeout=180)
+    assert p.returncode == 0 and "hip_renderer" not in p.stderr, p.stderr
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("hip_renderer: kernel")]
+    assert line and "kernel lol_render_spec" in line[0] and "tile order mode lpt, in use lpt" in line[0], p.stdout
+    assert int(line[0].split(",")[-1].split()[0]) >= 1, line[0]
+    img = read_ppm(out).astype(np.int32)
+    ox, _, _ = O.render(scenes["scene4"], w, h, threads=4)
+    want = np.stack([(ox >> 16) & 0xFF, (ox >> 8) & 0xFF, ox & 0xFF], axis=-1).astype(np.int32)
+    assert np.abs(img - want).max() <= 1
+    p = subprocess.run(base + flags + ["--tile-rows"], capture_output=True, text=True, timeout=180)
+    assert p.returncode == 0 and "tile order mode rows, in use rows" in p.stdout, p.stdout
+
+
+@pytest.mark.gpu
 def test_c_host_max_steps_flag(tmp_path, scenes):
     out = tmp_path / "f.ppm"
     w, h = 96, 54
