@@ -637,7 +637,10 @@ def main():
     sc = S.Scene.parse_file(os.path.join(ROOT, "tests", "golden", "scenes", cfg["scene"] + ".lol"))
     startup = None
     if world == 1 and not emulate and os.environ.get("LOL_BENCH_STARTUP", "1") != "0":
-        startup = startup_times(sc, w, h, max_steps, local_rank)      # before this process has compiled the scene
+        try:
+            startup = startup_times(sc, w, h, max_steps, local_rank)  # before this process has compiled the scene
+        except Exception as e:                                    # noqa: BLE001 — an extra of the record must not cost the line
+            startup = {"error": f"{type(e).__name__}: {e}"}
     r = gpu.Renderer(local_rank)
     r.prepare(sc)                                     # render_prepare: flatten + upload once; waits for the scene's own kernel
     # A side stream: its handle is non-NULL (NULL means "the context's own stream" in lol_gpu.h), and
@@ -908,21 +911,34 @@ def main():
             out["emulated_world"] = emulate
             out["root_kernel_ms"] = round(k_avg, 4)
             out["implied_mpixels_per_s_if_root_is_the_critical_path"] = round(w * h / (dt / steps) / 1e6, 1)
+        # The legs below come after the timed region and only add to the record: one that fails says so in its place instead
+        # of taking the line — the metric the driver reads — down with it.
+        def leg(key, fn):
+            try:
+                fn()
+            except Exception as e:                              # noqa: BLE001 — whatever went wrong, the record says it
+                out[key] = {"error": f"{type(e).__name__}: {e}"}
+                print(f"[bench] the `{key}` leg failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+
         if world == 1 and not orbit and local is not None:       # (local is None in the 1-rank gather rehearsal)
-            out["kernels"] = both_kernels(r, sc, local, w, h, max_steps, cams[0], stream, k_avg, px_per_launch)
+            leg("kernels", lambda: out.__setitem__("kernels", both_kernels(r, sc, local, w, h, max_steps, cams[0], stream, k_avg, px_per_launch)))
         if world == 1 and not orbit and local is not None and tile["mode"] == "lpt" and os.environ.get("LOL_BENCH_SCHEDULING", "1") != "0":
-            out["scheduling"] = scheduling_rates(r, local, w, h, max_steps, cams[0], stream, k_avg, px_per_launch)
+            leg("scheduling", lambda: out.__setitem__("scheduling", scheduling_rates(r, local, w, h, max_steps, cams[0], stream, k_avg, px_per_launch)))
         if world == 1 and not args.no_cpu_baseline and not orbit and local is not None:
-            base, ctr = cpu_baseline(sc, cfg, gpu_frame=local.cpu().numpy().view(np.uint32))
-            out["cpu_baseline"] = base
-            out["valu"] = valu_fields(r.kernel_name(), name, px_per_launch, r.kernel_key(), px_per_launch / (k_avg * 1e-3) / 1e6,
-                                      ctr, flops_per_sdf(r.program), dealt=tile["order"] == "lpt")
+            def cpu_leg():
+                base, ctr = cpu_baseline(sc, cfg, gpu_frame=local.cpu().numpy().view(np.uint32))
+                out["cpu_baseline"] = base
+                out["valu"] = valu_fields(r.kernel_name(), name, px_per_launch, r.kernel_key(), px_per_launch / (k_avg * 1e-3) / 1e6,
+                                          ctr, flops_per_sdf(r.program), dealt=tile["order"] == "lpt")
+            leg("cpu_baseline", cpu_leg)
         if startup is not None:
             out["startup"] = startup
         if world == 1 and local is not None and os.environ.get("LOL_BENCH_HOST_SURFACE", "1") != "0":
-            torch.cuda.synchronize()
-            hs_cams = [orbit_camera(i, 256) for i in range(0, 256, 16)] if orbit else None
-            out["host_surface"] = host_surface_rates(r, sc, cfg, hs_cams)
+            def host_leg():
+                torch.cuda.synchronize()
+                hs_cams = [orbit_camera(i, 256) for i in range(0, 256, 16)] if orbit else None
+                out["host_surface"] = host_surface_rates(r, sc, cfg, hs_cams)
+            leg("host_surface", host_leg)
         sys.stdout.flush()
         os.write(record_fd, (json.dumps(out) + "\n").encode())
 
