@@ -277,6 +277,15 @@ def test_scene_beyond_the_old_capacity(torch_cuda, mode, name):
     assert np.array_equal(g["rgb"].view(np.uint32), g2["rgb"].view(np.uint32)) and np.array_equal(g["dist"].view(np.uint32), g2["dist"].view(np.uint32))
     assert np.array_equal(g["steps"] & 0xFFFF, g2["steps"] & 0xFFFF) and ((g2["steps"] >> 16) <= (g["steps"] >> 16)).all()
     assert ((g2["steps"] >> 16) < (g["steps"] >> 16)).any()
+    # ... and the same view again and again: the scheduled frame (pixels dealt by cost, waves longest first) of the kernels that
+    # read their tables from global memory — a frame wider than one region, neither dimension a multiple of it
+    w2, h2 = 70, 20
+    first = gpu_render(torch_cuda, r, sc, w2, h2)
+    fifth = gpu_render(torch_cuda, r, sc, w2, h2, repeat=5)
+    assert r.tile_order()["order"] == "lpt" and r.tile_order()["decisions"] >= 1
+    for k in ("xrgb", "id", "steps"):
+        assert np.array_equal(first[k], fifth[k]), k
+    assert np.array_equal(first["rgb"].view(np.uint32), fifth["rgb"].view(np.uint32)) and np.array_equal(first["dist"].view(np.uint32), fifth["dist"].view(np.uint32))
     r.close()
 
 
