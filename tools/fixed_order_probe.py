@@ -1,3 +1,6 @@
+"""Diagnostic (round 4): C3 frames in the fixed tile orders and in the scheduled mode, per-frame HIP events against wall clock,
+with short and long warm-ups — how bench.py's `scheduling` leg came to warm up for 16 frames (a device that has idled for a
+moment renders its first frames 8 % slow).  python tools/fixed_order_probe.py (on the GPU box)"""
 import os, sys, time, json
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch, bench
