@@ -469,6 +469,14 @@ unsigned long long run_verify(lol_gpu* ctx, int sqrt_kind, float k, unsigned lon
 	return bad[0];
 }
 
+/* the thresholds alone (a context whose device another context of this process has proven) */
+bool build_gamma_table(lol_gpu* ctx) {
+	if (ctx->d_gamma) return true;
+	if (hipMalloc(reinterpret_cast<void**>(&ctx->d_gamma), (lol::GAMMA_LEVELS + 1) * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); ctx->d_gamma = nullptr; return false; }
+	hipLaunchKernelGGL(gamma_thresholds_kernel, dim3(1), dim3(lol::GAMMA_LEVELS), 0, ctx->stream, ctx->d_gamma);
+	return hipGetLastError() == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
+}
+
 /* builds the gamma table of this context (once) and proves it; mismatch count, ~0ull when the check could not run */
 unsigned long long run_verify_gamma(lol_gpu* ctx) {
 	if (!ctx->d_bad && hipMalloc(reinterpret_cast<void**>(&ctx->d_bad), 2 * sizeof(unsigned long long)) != hipSuccess) return ~0ull;
@@ -1478,10 +1486,48 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
 }
 
 /* Prove, on this device, the shortcuts `prog` could use (results are cached per context). */
+/* What one context has proven about a device holds for every context of this process on that device: same silicon, same
+ * code.  (A second context of a host — a second window, the ranks of a test — then spends its render_prepare on the scene.) */
+struct DeviceProofs {
+	int  sqrt_verified = -1; bool sqrt_tiny_ok = false;
+	int  fdiv_verified = -1, gamma_verified = -1;
+	std::vector<lol_gpu::DivProof> div;
+};
+std::mutex g_proofs_mutex;
+std::unordered_map<int, DeviceProofs> g_proofs;
+
+void proofs_from_process(lol_gpu* ctx) {
+	std::lock_guard<std::mutex> lock(g_proofs_mutex);
+	auto it = g_proofs.find(ctx->device);
+	if (it == g_proofs.end()) return;
+	const DeviceProofs& P = it->second;
+	if (ctx->sqrt_verified < 0 && P.sqrt_verified >= 0) { ctx->sqrt_verified = P.sqrt_verified; ctx->sqrt_tiny_ok = P.sqrt_tiny_ok; }
+	if (ctx->fdiv_verified < 0) ctx->fdiv_verified = P.fdiv_verified;
+	if (ctx->gamma_verified < 0) ctx->gamma_verified = P.gamma_verified;
+	for (const auto& e : P.div) {
+		bool known = false;
+		for (const auto& c : ctx->div_verified) known = known || c.k_bits == e.k_bits;
+		if (!known) ctx->div_verified.push_back(e);
+	}
+}
+void proofs_to_process(const lol_gpu* ctx) {
+	std::lock_guard<std::mutex> lock(g_proofs_mutex);
+	DeviceProofs& P = g_proofs[ctx->device];
+	if (ctx->sqrt_verified >= 0) { P.sqrt_verified = ctx->sqrt_verified; P.sqrt_tiny_ok = ctx->sqrt_tiny_ok; }
+	if (ctx->fdiv_verified >= 0) P.fdiv_verified = ctx->fdiv_verified;
+	if (ctx->gamma_verified >= 0) P.gamma_verified = ctx->gamma_verified;
+	for (const auto& e : ctx->div_verified) {
+		bool known = false;
+		for (const auto& c : P.div) known = known || c.k_bits == e.k_bits;
+		if (!known) P.div.push_back(e);
+	}
+}
+
 FastPaths prove_fast_paths(lol_gpu* ctx, const lol_program& prog) {
 	FastPaths fast;
 	const char* fenv = getenv("LOL_GPU_FAST");
 	if (!ctx->want_fast || (fenv && fenv[0] == '0')) return fast;
+	proofs_from_process(ctx);
 	if (ctx->sqrt_verified < 0) {
 		ctx->sqrt_verified = 0;                     /* cheapest proven sequence wins */
 		for (int kind = 3; kind >= 1 && !ctx->sqrt_verified; kind--) {
@@ -1496,6 +1542,7 @@ FastPaths prove_fast_paths(lol_gpu* ctx, const lol_program& prog) {
 		const char* genv = getenv("LOL_GPU_GAMMA_TABLE");
 		if (!(genv && genv[0] == '0')) {
 			if (ctx->gamma_verified < 0) ctx->gamma_verified = run_verify_gamma(ctx) == 0 ? 1 : 0;
+			else if (ctx->gamma_verified == 1 && !ctx->d_gamma && !build_gamma_table(ctx)) ctx->gamma_verified = 0;      /* proven by another context of this device: only the table */
 			fast.gamma_ok = ctx->gamma_verified == 1;
 		}
 	}
@@ -1524,6 +1571,7 @@ FastPaths prove_fast_paths(lol_gpu* ctx, const lol_program& prog) {
 		/* LOL_GPU_SMIN_FIXUP=1: keep v_div_fixup in every blend factor (A/B runs) */
 		if (nf && !fast.has_nf(o.f[0]) && !(getenv("LOL_GPU_SMIN_FIXUP") && getenv("LOL_GPU_SMIN_FIXUP")[0] == '1')) fast.div_nf_ok.push_back(o.f[0]);
 	}
+	proofs_to_process(ctx);
 	return fast;
 }
 
