@@ -15,7 +15,9 @@ XRGB8888) rendered from the scene already resident on the device, into a device 
           The root also receives and un-interleaves the whole frame, so its bands may be less tall than the
           others' (loltracer_amd.multi.Partition; LOL_BENCH_ROOT_SHARE = auto | equal | BAND,ROOT_BAND: `auto`
           times a few frames of each candidate split during set-up and keeps the fastest).
-  orbit   256-frame camera orbit of scene4 at 3840x2160, frames striped over ranks, no collective.
+  orbit   256-frame camera orbit of scene4 at 3840x2160, frames striped over ranks, no collective.  A rank's frames are
+          independent, so it keeps LOL_BENCH_FRAMES_IN_FLIGHT of them (default 3) in flight on the library's own streams
+          (lol_gpu_set_frames_in_flight): the next frame's first waves fill the tail of the last one's launch.
   --transport cabi       ONE process drives all N devices through lol_gpu_multi_* (the in-process path the
                          reference's C host calls: band partition + RCCL send/recv group + assembly kernel).
   --emulate-root-of N    one GPU plays rank 0 of an N-rank run: renders the root's share of C4, gathers through a
@@ -174,7 +176,8 @@ def valu_fields(kernel: str, workload: str, px_per_launch: int, kernel_key: str,
                    issue_source="profiles/pmc_traffic.json holds no PMC passes of this kernel code / workload: not quoted "
                                 "(re-run tools/final_profile.sh)")
     lane = lane_efficiency_model(workload, dealt) or (lane_efficiency_model(workload) if dealt else None)
-    out["lane_efficiency"] = lane["lane_efficiency"] if lane else None
+    # a MODEL from the oracle's per-pixel step counts (the PMC cannot see predicated lanes), not a measurement of the dealt waves
+    out["lane_efficiency_modelled"] = lane["lane_efficiency"] if lane else None
     out["lane_efficiency_detail"] = lane
     if ctr is not None and ctr.pixels:
         fpp = (ctr.sdf_evals * flops_sdf + ctr.march_steps * 9 + ctr.shadow_steps * 12) / ctr.pixels
@@ -401,6 +404,56 @@ def startup_times(sc: S.Scene, w: int, h: int, max_steps: int, device: int) -> d
     return out
 
 
+def env_record() -> dict:
+    """What of the environment took part in this line: the library's A/B switches that were honoured (lol_gpu_tuning_switches:
+    only beside LOL_GPU_TUNING=1) and this file's own LOL_BENCH_* variables."""
+    return {"lol_gpu_tuning_switches": gpu.tuning_switches() or None,
+            "lol_bench": {k: v for k, v in sorted(os.environ.items()) if k.startswith("LOL_BENCH_")} or None}
+
+
+def frames_in_flight_rates(r, sc, cfg, frames: int = 48) -> dict:
+    """Frames in flight (lol_gpu_set_frames_in_flight).  `value` keeps the reference's frame loop: frame i+1 is
+    launched when frame i is done with the stream (main.c:189-194).  A host whose frames are independent may keep several
+    in flight; this leg renders the SAME workload with 1, 2 and 3 frames in flight on the library's own streams, for a camera
+    that stands still (scheduled per stream) and for one that moves every frame (a short arc of the orbit; fixed tile order),
+    wall clock over `frames` frames after a ramp, frames compared with the one-stream frames.  Never part of `value`."""
+    w, h, ms = cfg["w"], cfg["h"], cfg["max_steps"]
+    moving = [sc.frame_camera(w, h, orbit_camera(i, 256)) for i in range(0, 2 * frames, 2)] if cfg["scene"] == "scene4" else None
+    still = [sc.frame_camera(w, h)]
+    out = {"frames": frames}
+    ring = [torch.zeros((h, w), dtype=torch.int32, device="cuda") for _ in range(4)]
+    ref = {}
+    for label, cams in (("still_camera", still), ("moving_camera", moving)):
+        if cams is None:
+            continue
+        res = {}
+        for n in (1, 2, 3):
+            r.set_frames_in_flight(n)
+
+            def run(k):
+                for i in range(k):
+                    r.render_into(ring[i % n].data_ptr(), w, h, ms, frame_camera=cams[i % len(cams)])
+                r.sync()
+            run(40 if label == "still_camera" else 16)
+            best = None
+            for _ in range(2):
+                t0 = time.perf_counter()
+                run(frames)
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            res[f"{n}_in_flight_mpixels_per_s"] = round(frames * w * h / best / 1e6, 1)
+            last = ring[(frames - 1) % n]
+            if n == 1:
+                ref[label] = last.clone()
+            else:
+                res[f"{n}_in_flight_last_frame_equal"] = bool(torch.equal(last, ref[label]))
+        out[label] = res
+    r.set_frames_in_flight(1)
+    out["note"] = ("the library's own streams in turn (stream == NULL), a ring of n destinations; still camera: every stream keeps its own "
+                   "scheduling tables; moving camera: 2 orbit frames per step (2.8 degrees), fixed tile order")
+    return out
+
+
 def launcher_command(n: int, argv: list, port: int) -> list:
     """The command `python bench.py --gpus N` runs for N > 1: one rank per GPU under torch.distributed.run
     (the same form the driver uses), rendezvous on 127.0.0.1."""
@@ -455,8 +508,25 @@ def host_surface_rates(r, sc, cfg, cams, frames: int = 12):
         r.render_host_end(surf.ctypes.data, pitch, w, h)
     out["pipelined_mpixels_per_s"] = rate(time.perf_counter() - t0)
     r.render_host_end(surf.ctypes.data, pitch, w, h)
-    # synchronous per frame (kernel, then the copy) and with two frames in flight (the copy under the next frame's kernel)
-    out["host_surface_mpixels_per_s"] = {"sync": out["sync_mpixels_per_s"], "pipelined": out["pipelined_mpixels_per_s"]}
+    # ... and with three (lol_gpu_set_frames_in_flight(3): the surface lags two frames, three kernels may overlap)
+    try:
+        r.set_frames_in_flight(3)
+        for i in range(3):
+            r.render_host_begin(w, h, ms, camera=cam_list[i % len(cam_list)])
+        r.render_host_end(surf.ctypes.data, pitch, w, h)
+        t0 = time.perf_counter()
+        for i in range(frames):
+            r.render_host_begin(w, h, ms, camera=cam_list[(i + 3) % len(cam_list)])
+            r.render_host_end(surf.ctypes.data, pitch, w, h)
+        out["pipelined_3_mpixels_per_s"] = rate(time.perf_counter() - t0)
+        r.render_host_end(surf.ctypes.data, pitch, w, h)
+        r.render_host_end(surf.ctypes.data, pitch, w, h)
+    finally:
+        r.set_frames_in_flight(1)
+    # synchronous per frame (kernel, then the copy), with two frames in flight (the copy under the next frame's kernel, whose first
+    # waves fill the tail of this one's launch: consecutive kernels on different streams) and with three
+    out["host_surface_mpixels_per_s"] = {"sync": out["sync_mpixels_per_s"], "pipelined": out["pipelined_mpixels_per_s"],
+                                         "pipelined_3": out.get("pipelined_3_mpixels_per_s")}
     return out
 
 
@@ -693,33 +763,49 @@ def main():
         cams = [sc.frame_camera(w, h, orbit_camera(i, frames_total)) for i in my_frames]
     else:
         cams = [sc.frame_camera(w, h)]
-    local = torch.zeros((h, w), dtype=torch.int32, device=dev) if not piped else None
+    # The orbit's frames are independent (BASELINE.json config 5: "frames striped", no per-frame collective): a rank keeps
+    # several in flight on the library's own streams (lol_gpu_set_frames_in_flight), each into a destination of its own.  Every
+    # other workload keeps the reference's loop — one frame after the other on one stream (main.c:189-194).
+    fif = max(1, min(4, int(os.environ.get("LOL_BENCH_FRAMES_IN_FLIGHT", "3")))) if orbit else 1
+    if fif > 1:
+        r.set_frames_in_flight(fif)
+    ring = [torch.zeros((h, w), dtype=torch.int32, device=dev) for _ in range(fif)] if not piped else None
+    local = ring[0] if ring else None
+    ext_streams = {}
 
     def launch(dst_tensor, fc, timed):
         P = state["P"]
+        # the frame's stream: the side stream — or, with frames in flight, whichever of the library's own streams is next
+        # (events are recorded there: torch.cuda.Event.record() alone sees only torch's current stream)
+        if fif > 1:
+            handle = r.next_stream()
+            ev_stream = ext_streams.get(handle) or ext_streams.setdefault(handle, torch.cuda.ExternalStream(handle, device=dev))
+            s_arg = None
+        else:
+            ev_stream, s_arg = side, stream
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            e0.record(ev_stream)
         if P is None:
-            r.render_into(dst_tensor.data_ptr(), w, h, max_steps, stream=stream, frame_camera=fc)
+            r.render_into(dst_tensor.data_ptr(), w, h, max_steps, stream=s_arg, frame_camera=fc)
         elif P.rank_rows[rank]:                      # ONE launch: this rank's band of every cycle, compactly
-            r.render_into(dst_tensor.data_ptr(), w, h, max_steps, rows=gpu.Rows(*P.geometry[rank]), stream=stream,
+            r.render_into(dst_tensor.data_ptr(), w, h, max_steps, rows=gpu.Rows(*P.geometry[rank]), stream=s_arg,
                           frame_camera=fc)
         if timed:
-            e1.record()
+            e1.record(ev_stream)
             kernel_ms.append((e0, e1))
 
     def step(i, timed):
         fc = cams[i % len(cams)]
         if not piped:
-            launch(local, fc, timed)
+            launch(ring[i % fif], fc, timed)
         else:
             state["pipe"].submit(lambda part: launch(part, fc, timed))
 
     def fence():
         if state["pipe"] is not None:
             state["pipe"].drain()
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()                      # (the whole device: the library's own streams too)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -760,7 +846,7 @@ def main():
     # A fixed frame count per workload (every rank issues the same number of gathers), none for the 256-frame orbit.
     # The order in which a launch hands out its tiles is the LIBRARY's business (lol_gpu_set_tile_order; its default: longest
     # tiles first, from the costs the tiles of the frames before reported — sorted on the device, on the frame's own stream, a
-    # few small kernels every fourth frame that are part of what is timed), so the rate reported here is the rate a host gets
+    # few small kernels every sixteenth frame (LPT_RESORT) that are part of what is timed), so the rate reported here is the rate a host gets
     # through the boundary with no tuning of its own.  LOL_BENCH_TILE_ORDER = rows | cols | auto pins another mode (A/B runs).
     want_order = os.environ.get("LOL_BENCH_TILE_ORDER", "lpt")      # the library's default: longest tiles first
     if want_order not in ("rows", "cols", "auto", "lpt"):
@@ -790,6 +876,8 @@ def main():
     if force_pipe and world == 1 and rank == 0:
         print("[force-pipe] 1-rank nccl gather path completed", file=sys.stderr, flush=True)
     # ---- everything below is outside the timed region ----
+    if fif > 1:
+        r.set_frames_in_flight(1)
     # Correctness of what was just timed, by default (LOL_BENCH_CHECK=0 skips it; the driver's plain `bench.py --gpus N` gets it):
     # partitioned frames: the frame assembled on rank 0 from every rank's bands == ONE launch of the whole frame on rank 0;
     # the orbit: every rank's first and last frame == rank 0's own render of the same cameras (compared by checksum).
@@ -865,11 +953,16 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt / steps_reported * 1e3, 4), "higher_is_better": True,
             "scaling": "weak" if orbit else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{name}: tests/golden/scenes/{cfg['scene']}.lol {w}x{h}, {max_steps} march steps"
-                                   + (f", {cfg['frames']}-frame orbit striped over ranks" if orbit else
+                                   + (f", {cfg['frames']}-frame orbit striped over ranks, a new camera every frame, {fif} frame(s) in flight per rank" if orbit else
                                       (f", rows in bands of {band} ({P.root_band or band} for rank 0) over {P.world} ranks + RCCL gather to rank 0"
-                                       if P is not None else ", one kernel launch per frame")),
-                       "width": w, "height": h, "max_steps": max_steps, "band_rows": band,
-                       "kernel": r.kernel_name(), "kernel_key": r.kernel_key(), "transport": "dist"},
+                                       if P is not None else ", one kernel launch per frame")
+                                      + ", STILL CAMERA: the same view frame after frame (every pixel computed again in every frame; the "
+                                        "library schedules a frame by what the frame before it cost — `value_new_view` is the rate of a frame "
+                                        "whose camera has just moved)"),
+                       "width": w, "height": h, "max_steps": max_steps, "band_rows": band, "frames_in_flight": fif,
+                       "camera": "moving (orbit)" if orbit else "still (repeated view)",
+                       "kernel": r.kernel_name(), "kernel_key": r.kernel_key(), "transport": "dist",
+                       "env": env_record()},
             # what the process group really is: ranks seen by torch.distributed and its backend ("nccl" = RCCL)
             "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
             "backend": dist.get_backend() if dist.is_initialized() else None,
@@ -922,8 +1015,20 @@ def main():
 
         if world == 1 and not orbit and local is not None:       # (local is None in the 1-rank gather rehearsal)
             leg("kernels", lambda: out.__setitem__("kernels", both_kernels(r, sc, local, w, h, max_steps, cams[0], stream, k_avg, px_per_launch)))
+        # `value` is the rate of a view that REPEATS (the workload BASELINE.json names: one camera); the rate of a frame whose camera
+        # has just moved stands beside it at the top level: the same frame in the better fixed tile order, same context, same run
+        out["value_new_view"] = None
+        if orbit:
+            out["value_new_view"] = out["value"]          # every frame of the orbit has a new camera
         if world == 1 and not orbit and local is not None and tile["mode"] == "lpt" and os.environ.get("LOL_BENCH_SCHEDULING", "1") != "0":
-            leg("scheduling", lambda: out.__setitem__("scheduling", scheduling_rates(r, local, w, h, max_steps, cams[0], stream, k_avg, px_per_launch)))
+            def sched_leg():
+                out["scheduling"] = scheduling_rates(r, local, w, h, max_steps, cams[0], stream, k_avg, px_per_launch)
+                out["value_new_view"] = out["scheduling"]["new_view_mpixels_per_s"]
+                out["value_new_view_note"] = ("Mpixels/s of the same frame when its camera has just moved: no costs of a frame before, the better "
+                                              "of the two fixed tile orders (`scheduling`); `value` is the repeated view")
+            leg("scheduling", sched_leg)
+        if world == 1 and not orbit and local is not None and os.environ.get("LOL_BENCH_FRAMES_IN_FLIGHT_LEG", "1") != "0":
+            leg("frames_in_flight", lambda: out.__setitem__("frames_in_flight", frames_in_flight_rates(r, sc, cfg)))
         if world == 1 and not args.no_cpu_baseline and not orbit and local is not None:
             def cpu_leg():
                 base, ctr = cpu_baseline(sc, cfg, gpu_frame=local.cpu().numpy().view(np.uint32))

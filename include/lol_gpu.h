@@ -34,10 +34,11 @@ extern "C" {
 /*
  * Version of this binary interface.  It changes whenever an entry point changes its arguments or a structure its layout
  * (4: lol_program carries pointers + counts instead of fixed-capacity arrays; lol_gpu_render_host_end takes the surface's
- * size; lol_gpu_rows is {band, cycle, offset}).  A host compiled against another version must not run: hip_renderer.c
+ * size; lol_gpu_rows is {band, cycle, offset}.  5: lol_gpu_set_frames_in_flight / lol_gpu_next_stream; render_host_begin
+ * takes up to four frames; lol_gpu_tuning_switches).  A host compiled against another version must not run: hip_renderer.c
  * and the Python mirror compare lol_gpu_abi_version() of the library they loaded with the macro they were built with.
  */
-#define LOL_GPU_ABI_VERSION 4
+#define LOL_GPU_ABI_VERSION 5
 int lol_gpu_abi_version(void);
 
 typedef struct lol_gpu lol_gpu;      /* one renderer context = one device + one scene */
@@ -163,6 +164,11 @@ int lol_gpu_render_host(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h,
  * end() takes the size of the surface it is given and refuses (LOL_GPU_ERR_ARG, nothing written, frame kept) a frame
  * of another size; lol_gpu_render_host_pending_size() tells the size of the oldest queued frame beforehand and
  * lol_gpu_render_host_discard() drops every queued frame.  Frames of different sizes may be in flight together.
+ *
+ * The kernels of consecutive frames are queued on different streams of the context (round 5), so frame i+1's first waves
+ * fill the tail of frame i's launch — the overlap the reference's sequential loop (main.c:189-194) cannot have and a host
+ * with the next camera in hand can: what a MOVING camera gains from having frames in flight (the copy is hidden either
+ * way).  After lol_gpu_set_frames_in_flight(ctx, n) up to n (<= 4) frames may be begun and not yet ended.
  */
 int lol_gpu_render_host_begin(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h, int max_steps);
 int lol_gpu_render_host_end(lol_gpu* ctx, void* host_pixels, size_t pitch_bytes, int w, int h);
@@ -170,8 +176,27 @@ int lol_gpu_render_host_pending(const lol_gpu* ctx);
 int lol_gpu_render_host_pending_size(const lol_gpu* ctx, int* w, int* h);   /* 0 x 0 when nothing is queued */
 int lol_gpu_render_host_discard(lol_gpu* ctx);
 
-/* Wait for everything issued on the context's own stream. */
+/* Wait for everything issued on the context's own stream(s). */
 int lol_gpu_sync(lol_gpu* ctx);
+
+/*
+ * Frames in flight.  The reference renders frame i+1 when frame i has been shown (main.c:189-194); a frame here is ONE
+ * launch that ends with its slowest waves on half-empty SIMDs, and a host whose frames are independent — an orbit, a
+ * recorded path, the stripes of BASELINE.json's config 5 — loses that tail once per frame.  With n > 1 the frames launched
+ * on the context's own stream (stream == NULL in lol_gpu_render_device) go to n streams of the context in turn, so up to n
+ * of them run together and the next frame's first waves fill the last one's tail (+9 % scene4 at 4K, +13 % its orbit, +67 %
+ * scene.lol at 1080p: profiles/r4_stream_overlap_ab.jsonl).  What the caller takes on: frames that may be in flight
+ * together need destinations of their own — frame i and frame i + n share a stream, so a ring of n destinations is safe —
+ * and only lol_gpu_sync() (or an event recorded on lol_gpu_next_stream() after the launch) says when a frame is there.
+ * A repeated view keeps its schedule on every stream (lol_gpu_set_tile_order: one set of tables per stream).
+ * n = 1 (the default) is the sequential behaviour.  Also the number of frames lol_gpu_render_host_begin accepts before an
+ * _end (never fewer than two).  1 <= n <= 4.  Waits for the frames in flight before it changes the rotation.
+ */
+int   lol_gpu_set_frames_in_flight(lol_gpu* ctx, int n);
+int   lol_gpu_frames_in_flight(const lol_gpu* ctx);
+/* The hipStream_t (as void*) the NEXT frame launched with stream == NULL will be queued on: for hosts that bracket their
+ * frames with events of their own. */
+void* lol_gpu_next_stream(lol_gpu* ctx);
 
 /* Raw device memory helpers so a C host needs no HIP headers. */
 int lol_gpu_malloc(lol_gpu* ctx, size_t bytes, void** out);
@@ -186,6 +211,13 @@ const char* lol_gpu_kernel_name(const lol_gpu* ctx);
  * the square-root variant}: everything that decides which instructions the interpreter executes.  Profiles record it
  * (profiles/pmc_traffic.json) so that a counter figure is only ever quoted for the code it was measured on. */
 const char* lol_gpu_kernel_key(const lol_gpu* ctx);
+/* The tuning switches in effect in this process, "NAME=value NAME=value ..." ("" when none).  The library has two dozen
+ * LOL_GPU_* environment switches for A/B runs (INTEGRATION.md lists them) — compiler options of the scene's kernel among
+ * them.  They are honoured ONLY in a process that also sets LOL_GPU_TUNING=1; one that is set without it is ignored and
+ * reported once on stderr; every one that took effect is listed here, in lol_gpu_specialize_log() and in bench.py's
+ * record, so that a number can never silently come from a shell's leftovers.  (Not fenced: LOL_GPU_CACHE_DIR, LOL_GPU_ROCTX —
+ * where code objects are kept, whether frames are marked: neither changes what is computed.) */
+const char* lol_gpu_tuning_switches(void);
 /* Frame ranges pushed to roctx so far by this process (LOL_GPU_ROCTX=1 marks every frame launch for
  * `rocprofv3 --marker-trace`, the counterpart of the reference's -j/--jitdump aid); 0 when not asked for, -1 when asked
  * for but no roctx library could be loaded (also reported once on stderr). */

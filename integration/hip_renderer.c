@@ -10,9 +10,12 @@
  *                   flatten the scene, upload it.  Renderer flags start at
  *                   argv[3] (main.c:223-242): --device N (one GPU),
  *                   --pipeline (one GPU: the copy of frame i into the surface runs
- *                   under frame i+1's kernel; the surface then shows frame i-1;
- *                   the first frame, and the first one after the window changed
- *                   size, are delivered at once),
+ *                   under frame i+1's kernel, and frame i+1's first waves fill the tail
+ *                   of frame i's launch: consecutive kernels go to different streams;
+ *                   the surface then shows frame i-1; the first frame, and the first one
+ *                   after the window changed size, are delivered at once),
+ *                   --pipeline-depth N (2 = --pipeline; 3, 4: the surface shows frame
+ *                   i-2, i-3 and that many kernels overlap),
  *                   --devices A,B,... (the frame's rows are dealt in bands over
  *                   these GPUs, each writing its bands into the surface,
  *                   include/lol_gpu.h lol_gpu_multi_*), --parts-per-device N,
@@ -58,7 +61,8 @@ struct hip_renderer {
 	lol_gpu_multi* multi;      /* --devices A,B,...: used instead of `gpu` */
 	lol_program    program;
 	int         max_steps;      /* MAX_STEPS, naive_renderer.c:49 */
-	int         pipeline;       /* --pipeline: frame i's copy into the surface overlaps frame i+1's kernel (one frame of latency) */
+	int         pipeline;       /* --pipeline: frame i's copy into the surface overlaps frame i+1's kernel (one frame of latency);
+	                             * --pipeline-depth N: N frames queued before the oldest is delivered (N - 1 frames of latency) */
 	int         shown_w, shown_h;/* --pipeline: size of the surface that last received a frame */
 	int         ready;
 	int         have_format;    /* the surface's pixel format has been handed to the library ... */
@@ -102,7 +106,12 @@ void render_prepare(struct render_data* data, int argc, const char* argv[]) {
 		const int is_device = !strcmp(argv[i], "--device"), is_devices = !strcmp(argv[i], "--devices");
 		const int is_steps = !strcmp(argv[i], "--max-steps"), is_dump = !strcmp(argv[i], "--dump-kernel");
 		const int is_ppd = !strcmp(argv[i], "--parts-per-device"), is_root = !strcmp(argv[i], "--root-band-rows");
-		if (!strcmp(argv[i], "--pipeline")) { r->pipeline = 1; continue; }
+		if (!strcmp(argv[i], "--pipeline")) { if (r->pipeline < 2) r->pipeline = 2; continue; }
+		if (!strcmp(argv[i], "--pipeline-depth") && i + 1 < argc) {
+			const int d = atoi(argv[++i]);
+			if (d >= 2 && d <= 4) r->pipeline = d; else fprintf(stderr, "hip_renderer: --pipeline-depth wants 2, 3 or 4\n");
+			continue;
+		}
 		if (!strcmp(argv[i], "--tile-columns")) { tile_order = LOL_GPU_TILES_COLS; continue; }
 		if (!strcmp(argv[i], "--tile-rows")) { tile_order = LOL_GPU_TILES_ROWS; continue; }
 		if (!strcmp(argv[i], "--report")) { r->report = 1; continue; }
@@ -159,6 +168,10 @@ void render_prepare(struct render_data* data, int argc, const char* argv[]) {
 		st = lol_gpu_upload_program(r->gpu, &r->program);
 		if (st != LOL_GPU_OK) { fprintf(stderr, "hip_renderer: %s\n", lol_gpu_error(r->gpu)); return; }
 		if (tile_order >= 0) (void)lol_gpu_set_tile_order(r->gpu, tile_order);
+		if (r->pipeline > 2 && lol_gpu_set_frames_in_flight(r->gpu, r->pipeline) != LOL_GPU_OK) {
+			fprintf(stderr, "hip_renderer: %s; two frames in flight\n", lol_gpu_error(r->gpu));
+			r->pipeline = 2;
+		}
 		if (wait_kernel) (void)lol_gpu_specialize_wait(r->gpu);
 	}
 	r->ready = 1;
@@ -201,7 +214,7 @@ int render_thread(void* ptr) {
 						lol_gpu_render_host_discard(r->gpu);
 					const int first = r->shown_w != width || r->shown_h != height;   /* this surface has not been given a frame yet */
 					st = lol_gpu_render_host_begin(r->gpu, &fc, width, height, r->max_steps);
-					if (st == LOL_GPU_OK && (first || lol_gpu_render_host_pending(r->gpu) == 2))
+					if (st == LOL_GPU_OK && (first || lol_gpu_render_host_pending(r->gpu) >= r->pipeline))
 						st = lol_gpu_render_host_end(r->gpu, surf->pixels, (size_t)surf->pitch, width, height);
 					if (st == LOL_GPU_OK) { r->shown_w = width; r->shown_h = height; }
 				} else {

@@ -4,7 +4,7 @@
  * the GPU box).
  *
  *   lol_headless <threads> <scene.lol> [--size WxH] [--frames N] [--out frame.ppm]
- *                [--orbit] [--keys SCRIPT] [--dump-camera FILE] [--pipeline]
+ *                [--orbit] [--keys SCRIPT] [--dump-camera FILE] [--pipeline | --pipeline-depth N]
  *                [--format NAME] [--resize-script WxH,WxH,..] [--dump-frames PREFIX]
  *                [renderer flags: --device N | --devices A,B,.. --max-steps N ...]
  *   --format NAME            pixel format of the surface, as SDL names it: xrgb8888 (default), argb8888, bgrx8888,
@@ -95,7 +95,11 @@ int main(int argc, const char* argv[]) {
 		else if (!strcmp(argv[i], "--orbit")) orbit = 1;
 		else if (!strcmp(argv[i], "--keys") && i + 1 < argc) keys = argv[++i];
 		else if (!strcmp(argv[i], "--dump-camera") && i + 1 < argc) dump_camera = argv[++i];
-		else if (!strcmp(argv[i], "--pipeline")) pipeline = 1;      /* also read by the plug-in: the surface lags one frame */
+		else if (!strcmp(argv[i], "--pipeline")) { if (pipeline < 1) pipeline = 1; }      /* also read by the plug-in: the surface lags one frame */
+		else if (!strcmp(argv[i], "--pipeline-depth") && i + 1 < argc) {                  /* ... or depth - 1 frames */
+			const int d = atoi(argv[++i]);
+			if (d >= 2 && d <= 4) pipeline = d - 1;
+		}
 		else if (!strcmp(argv[i], "--resize-script") && i + 1 < argc) resize_script = argv[++i];
 		else if (!strcmp(argv[i], "--dump-frames") && i + 1 < argc) dump_frames = argv[++i];
 		else if (!strcmp(argv[i], "--format") && i + 1 < argc) {
@@ -152,7 +156,8 @@ int main(int argc, const char* argv[]) {
 	const char* key_at = keys;
 	double tmin = 1e30, tmax = 0, tsum = 0;
 	double* times = calloc((size_t)(frames + pipeline), sizeof *times);
-	/* with --pipeline the plug-in delivers frame i-1 on round i: one extra round (same camera) brings the last frame in */
+	/* with --pipeline the plug-in delivers frame i-1 on round i (i - depth + 1 with --pipeline-depth): extra rounds (same camera)
+	 * bring the last frames in */
 	for (int f = 0; f < frames + pipeline; f++) {
 		if (orbit) orbit_camera(&scene->camera, f < frames ? f : frames - 1, frames);
 		if (keys && f < frames) {                                /* update_camera(), main.c:180 */

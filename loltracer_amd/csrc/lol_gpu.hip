@@ -134,13 +134,16 @@ struct lol_gpu {
 	/* host-surface path */
 	uint32_t*    d_frame = nullptr;      /* framebuffer for lol_gpu_render_host */
 	size_t       frame_bytes = 0;
-	/* lol_gpu_render_host_begin / _end: two frames in flight, one device framebuffer each (sized per slot, so frames of
-	 * different sizes can be in flight while the host's window is being resized) */
-	uint32_t*    d_pipe[2] = { nullptr, nullptr };
-	size_t       pipe_bytes[2] = { 0, 0 };
+	/* lol_gpu_render_host_begin / _end: frames in flight, one device framebuffer each (sized per slot, so frames of
+	 * different sizes can be in flight while the host's window is being resized); slot = frame number % PIPE_SLOTS, and
+	 * the kernel of slot k runs on frame_streams[k % pipe_streams]: consecutive frames overlap */
+	static constexpr int PIPE_SLOTS = 4;
+	uint32_t*    d_pipe[PIPE_SLOTS] = { nullptr, nullptr, nullptr, nullptr };
+	size_t       pipe_bytes[PIPE_SLOTS] = { 0, 0, 0, 0 };
 	hipStream_t  copy_stream = nullptr;
-	hipEvent_t   pipe_rendered[2] = { nullptr, nullptr }, pipe_copied[2] = { nullptr, nullptr };
-	int          pipe_w[2] = { 0, 0 }, pipe_h[2] = { 0, 0 };
+	hipEvent_t   pipe_rendered[PIPE_SLOTS] = { nullptr, nullptr, nullptr, nullptr }, pipe_copied[PIPE_SLOTS] = { nullptr, nullptr, nullptr, nullptr };
+	hipStream_t  pipe_stream[PIPE_SLOTS] = { nullptr, nullptr, nullptr, nullptr };   /* the stream the slot's kernel was queued on */
+	int          pipe_w[PIPE_SLOTS] = { 0, 0, 0, 0 }, pipe_h[PIPE_SLOTS] = { 0, 0, 0, 0 };
 	unsigned     pipe_begun = 0, pipe_ended = 0;
 	int          want_spec = 1;
 	hipModule_t  spec_module = nullptr;
@@ -195,7 +198,10 @@ struct lol_gpu {
 		float mon_ratio[MONITOR_WINDOW] = {};
 	} tiles;
 	int          generation = 0;         /* uploads so far */
-	/* LOL_GPU_TILES_LPT: longest tiles first ("longest tiles first" below) */
+	/* LOL_GPU_TILES_LPT: longest tiles first ("longest tiles first" below).  One SET of tables per stream that launches frames
+	 * of a repeated view (lpt_table_for_frame): everything about a set happens on its home stream, so frames, the costs they
+	 * write and the sorts that read them are ordered by that stream itself — and frames in flight on several streams
+	 * (lol_gpu_set_frames_in_flight, lol_gpu_render_host_begin) each keep their schedule. */
 	struct TileLpt {
 		int      key[7] = { 0, 0, 0, 0, 0, 0, 0 };   /* w, h, max_steps, band_rows, cycle_rows, offset_rows, generation * 2 + spec */
 		uint32_t n_tiles = 0;
@@ -209,17 +215,69 @@ struct lol_gpu {
 		size_t   cap = 0;                    /* tiles the buffers hold */
 		int      cur = 0;
 		unsigned frames = 0, sorts = 0;      /* frames launched with this key; sorts done */
-		hipStream_t home = nullptr;          /* the stream these tables live on (lpt_table_for_frame) */
-		unsigned foreign = 0;                /* consecutive frames of this key launched on another stream */
+		hipStream_t home = nullptr;          /* the stream these tables live on; nullptr = the set is free */
+		bool     launched = false;           /* a frame (or a table kernel) has been queued on `home` through these tables since the
+		                                      * stream last ran dry: they may be in use whatever `key` says (lpt_retire clears it) */
+		unsigned long long stamp = 0;        /* when the set was last used (the least recently used one makes room for a fifth stream) */
 		lol_frame_camera cam_epoch{};        /* the view the tables' costs belong to */
-		int      last_key[7] = { 0, 0, 0, 0, 0, 0, 0 };
-		lol_frame_camera last_cam{};         /* the frame launched before this one: its key and view (lpt_table_for_frame: `still`) */
-		bool     have_last = false;
-		bool     last_table = false;         /* the last frame was launched through a table (lol_gpu_tile_order) */
-	} lpt;
+	};
+	static constexpr int LPT_SETS = 4;
+	TileLpt      lpt[LPT_SETS];
+	unsigned long long lpt_clock = 0;
+	unsigned     lpt_homeless = 0;       /* consecutive still frames on a stream that has no set while all sets are taken */
+	int          lpt_last_set = -1;      /* the set the last frame went through, or -1: it was launched in a fixed order (lol_gpu_tile_order) */
+	unsigned     lpt_sorts = 0;          /* sorts of all sets so far (lol_gpu_tile_order) */
+	/* the frame launched before this one, on whatever stream: its key and view (lpt_table_for_frame: `still`) */
+	int          lpt_last_key[7] = { 0, 0, 0, 0, 0, 0, 0 };
+	lol_frame_camera lpt_last_cam{};
+	bool         lpt_have_last = false;
+	/* Frames in flight (lol_gpu_set_frames_in_flight): frames launched with stream == NULL go round-robin over the first
+	 * n_frame_streams of these; [0] is `stream`.  lol_gpu_render_host_begin's slots use them too. */
+	static constexpr int MAX_FRAME_STREAMS = 4;
+	hipStream_t  frame_streams[MAX_FRAME_STREAMS] = { nullptr, nullptr, nullptr, nullptr };
+	int          n_frame_streams = 1;
+	unsigned     frame_rr = 0;
 	char         err[512] = { 0 };
 	char         kernel_name[64] = "render_interp";
 };
+
+/*
+ * Tuning switches.  Two dozen LOL_GPU_* environment variables select code paths and compiler options for A/B runs (the list:
+ * INTEGRATION.md) — LOL_GPU_RTC_FLAGS appends arbitrary options to the hot kernel's compile, and "-ffp-contract=fast"
+ * inherited from some shell would silently end parity with the reference.  So they are read ONLY in a process that also has
+ * LOL_GPU_TUNING=1 set, every one that was read and found is recorded (lol_gpu_tuning_switches(), the scene compiler's log,
+ * bench.py's `config.env`), and one that is set without LOL_GPU_TUNING=1 is reported once on stderr and ignored.  Not fenced,
+ * because they change where things are kept or what is traced, never what is computed: LOL_GPU_CACHE_DIR, LOL_GPU_ROCTX.
+ */
+static std::mutex g_tuning_mutex;
+static std::vector<std::pair<std::string, std::string>> g_tuning_seen;      /* switches that took effect: name, value */
+static std::vector<std::string> g_tuning_ignored;                           /* set, but LOL_GPU_TUNING=1 was not */
+static std::string g_tuning_text;
+
+__attribute__((visibility("hidden"))) const char* lol_gpu_internal_tuning_env(const char* name) {
+	const char* v = getenv(name);
+	if (!v) return nullptr;
+	const char* on = getenv("LOL_GPU_TUNING");
+	std::lock_guard<std::mutex> lock(g_tuning_mutex);
+	if (!(on && on[0] == '1' && !on[1])) {
+		if (std::find(g_tuning_ignored.begin(), g_tuning_ignored.end(), name) == g_tuning_ignored.end()) {
+			g_tuning_ignored.push_back(name);
+			fprintf(stderr, "lol_gpu: %s is set but LOL_GPU_TUNING=1 is not: ignored (tuning switches are for A/B runs)\n", name);
+		}
+		return nullptr;
+	}
+	for (auto& e : g_tuning_seen) if (e.first == name) { e.second = v; return v; }
+	g_tuning_seen.emplace_back(name, v);
+	return v;
+}
+static inline const char* tuning_env(const char* name) { return lol_gpu_internal_tuning_env(name); }
+
+extern "C" const char* lol_gpu_tuning_switches(void) {
+	std::lock_guard<std::mutex> lock(g_tuning_mutex);
+	g_tuning_text.clear();
+	for (const auto& e : g_tuning_seen) { if (!g_tuning_text.empty()) g_tuning_text += ' '; g_tuning_text += e.first + "=" + e.second; }
+	return g_tuning_text.c_str();
+}
 
 namespace {
 
@@ -662,7 +720,7 @@ void cluster_bounds(const lol_program& P, RootBound& R) {
 	auto sane = [](double v) { return v - v == 0.0 && fabs(v) < 1e15; };
 	if (!a.ok || !b.ok || !sane(a.r) || !sane(b.r)) return;
 	if (fmax(a.r, b.r) > 0.75 * R.r) return;
-	if (const char* e = getenv("LOL_GPU_CULL_TWO_SPHERES")) if (e[0] == '0') return;      /* A/B runs */
+	if (const char* e = tuning_env("LOL_GPU_CULL_TWO_SPHERES")) if (e[0] == '0') return;      /* A/B runs */
 	R.clusters = { a, b };
 }
 
@@ -711,7 +769,7 @@ struct CullPlan {
 };
 
 bool culling_enabled(int want) {
-	const char* e = getenv("LOL_GPU_CULL");
+	const char* e = tuning_env("LOL_GPU_CULL");
 	return want && !(e && e[0] == '0');
 }
 
@@ -767,10 +825,10 @@ CullPlan plan_culling(const std::vector<RootBound>& roots, bool enabled) {
 	plan.n_unbounded = plan.order.size();
 	if (!enabled || bounded.empty()) return plan;
 	/* LOL_GPU_CULL_CLUSTERS=0: one run of all bounded objects in scene order, no spatial clusters (for A/B runs) */
-	const char* e = getenv("LOL_GPU_CULL_CLUSTERS");
+	const char* e = tuning_env("LOL_GPU_CULL_CLUSTERS");
 	const size_t leaf_max = (e && atoi(e) == 0) ? (size_t)-1 : (e && atoi(e) > 1 ? (size_t)atoi(e) : 3);
 	uint32_t min_prims = 1;
-	if (const char* m = getenv("LOL_GPU_CULL_MIN_PRIMS")) min_prims = (uint32_t)std::max(1, atoi(m));
+	if (const char* m = tuning_env("LOL_GPU_CULL_MIN_PRIMS")) min_prims = (uint32_t)std::max(1, atoi(m));
 	kd_build(roots, bounded, 0, bounded.size(), plan.n_unbounded, plan.n_unbounded > 0, leaf_max, min_prims, plan);
 	plan.order.insert(plan.order.end(), bounded.begin(), bounded.end());
 	/* outer runs before inner ones at the same position (kd_build emits parents first; keep that order stable) */
@@ -822,9 +880,9 @@ std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast, co
 	 * every test, is fastest here too — a test is one turn of a scalar loop inside the rare TAIL branch). */
 	/* deep: operand stacks beyond the 4-bit slot fields — slots travel in words of their own and pops are not fused (lol_kernel.h, MOP_DEEP_FROM) */
 	const bool deep = interp_stack_class(P.max_stack) == lol::MOP_DEEP_SLOTS;
-	const bool fuse_pops = !deep && !(getenv("LOL_GPU_INTERP_FUSE_POPS") && getenv("LOL_GPU_INTERP_FUSE_POPS")[0] == '0');     /* A/B switch */
+	const bool fuse_pops = !deep && !(tuning_env("LOL_GPU_INTERP_FUSE_POPS") && tuning_env("LOL_GPU_INTERP_FUSE_POPS")[0] == '0');     /* A/B switch */
 	uint32_t min_prims = 1;
-	if (const char* e = getenv("LOL_GPU_INTERP_CULL_MIN_PRIMS")) min_prims = (uint32_t)std::max(1, atoi(e));
+	if (const char* e = tuning_env("LOL_GPU_INTERP_CULL_MIN_PRIMS")) min_prims = (uint32_t)std::max(1, atoi(e));
 	std::vector<CullInterval> ivs;
 	for (const CullInterval& iv : plan.intervals) {
 		uint32_t prims = 0;
@@ -942,11 +1000,11 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 	 * instructions, and where it keeps failing that is pure overhead.  Never testing is always allowed — the
 	 * test only ever permits a skip — so this changes no result.  `cool` lives in the Sdf struct, wave-uniform. */
 	int cooldown = 3;
-	if (const char* e = getenv("LOL_GPU_CULL_COOLDOWN")) cooldown = atoi(e);
+	if (const char* e = tuning_env("LOL_GPU_CULL_COOLDOWN")) cooldown = atoi(e);
 	/* LOL_GPU_SMIN_SAT=0: smooth minima without the per-wave saturation shortcut (sminf_fastdiv_sat), for A/B runs */
-	const bool smin_sat = !(getenv("LOL_GPU_SMIN_SAT") && atoi(getenv("LOL_GPU_SMIN_SAT")) == 0);
+	const bool smin_sat = !(tuning_env("LOL_GPU_SMIN_SAT") && atoi(tuning_env("LOL_GPU_SMIN_SAT")) == 0);
 	/* LOL_GPU_NAN_FLAG=0: every sphere keeps the range tracker (A/B runs) */
-	const bool nan_flag = fast && fast->sqrt_tiny_ok && !(getenv("LOL_GPU_NAN_FLAG") && atoi(getenv("LOL_GPU_NAN_FLAG")) == 0);
+	const bool nan_flag = fast && fast->sqrt_tiny_ok && !(tuning_env("LOL_GPU_NAN_FLAG") && atoi(tuning_env("LOL_GPU_NAN_FLAG")) == 0);
 	bool object_has_nr = false;
 	/* LOL_GPU_SAT_CULL_MIN_PRIMS: `a` operands of a smooth union with at least this many primitives get a saturation-
 	 * culling test (see emit_node below); 0 = none.  Measured (tools/tree_scene_ab.py, balanced trees of spheres at
@@ -954,7 +1012,7 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 	 * 232 -> 405 Mpixels/s, 256 spheres 127 -> 166 at 32 (375 / 157 at 16); with a test on every operand scene4
 	 * loses 14 %, a 32-sphere tree 30 %. */
 	int sat_cull_min_prims = 32;
-	if (const char* e = getenv("LOL_GPU_SAT_CULL_MIN_PRIMS")) sat_cull_min_prims = atoi(e);
+	if (const char* e = tuning_env("LOL_GPU_SAT_CULL_MIN_PRIMS")) sat_cull_min_prims = atoi(e);
 	/* one test = one bounding sphere; a run guarded by several (an object's two cluster spheres) is skipped where ALL pass */
 	auto open_test = [&](const CullInterval& iv, bool with_cooldown) {
 		const std::vector<CullTest> one = { iv.test };
@@ -1074,7 +1132,7 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 			if (fx[0]) object_has_nr = true;
 			/* the arithmetic shortcut only where the SDF is inlined: in the out-of-line function its four-way branching
 			 * costs more than it saves (504-op chain: 100 -> 42 Mpixels/s) */
-			const bool sat_arith = smin_sat && (!out_of_line || (getenv("LOL_GPU_SMIN_SAT") && atoi(getenv("LOL_GPU_SMIN_SAT")) == 2)) && ks > 0.f;
+			const bool sat_arith = smin_sat && (!out_of_line || (tuning_env("LOL_GPU_SMIN_SAT") && atoi(tuning_env("LOL_GPU_SMIN_SAT")) == 2)) && ks > 0.f;
 			const std::string kk = fbits(o.f[0]), k2 = fbits(2.0f * o.f[0]), hrk = fbits(0.5f * (1.0f / o.f[0])), kss = fbits(ks);
 			if (proven && ks > 0.f && sat_cull_min_prims > 0 && nodes[n.a].bound.ok && nodes[n.a].prims >= (uint32_t)sat_cull_min_prims) {
 				const int b = emit_node(n.b);
@@ -1155,7 +1213,7 @@ constexpr uint32_t LOL_SPEC_MAX_OPS = 16384;           /* specialise(): larger s
 
 bool spec_out_of_line(const lol_program& P) {
 	uint32_t limit = LOL_SPEC_INLINE_MAX_OPS;
-	if (const char* e = getenv("LOL_GPU_SPEC_INLINE_MAX")) limit = (uint32_t)strtoul(e, nullptr, 10);
+	if (const char* e = tuning_env("LOL_GPU_SPEC_INLINE_MAX")) limit = (uint32_t)strtoul(e, nullptr, 10);
 	return P.n_ops > limit;
 }
 
@@ -1173,7 +1231,7 @@ std::string generate_source(const lol_program& P, const FastPaths* fast, bool cu
 	 * kept (64 VGPRs: 4640 vs 4530 Mpixels/s unconstrained), a 44-op chain at >= 6, chains of 142+ ops at >= 4
 	 * (128 VGPRs: 427 vs 400 Mpixels/s at 8).  LOL_GPU_WAVES_PER_EU="min,max" overrides. */
 	int waves_lo = P.n_ops <= 32 ? 8 : P.n_ops <= 96 ? 6 : 4, waves_hi = 8;
-	if (const char* e = getenv("LOL_GPU_WAVES_PER_EU")) {
+	if (const char* e = tuning_env("LOL_GPU_WAVES_PER_EU")) {
 		int lo = 0, hi = 0;
 		if (sscanf(e, "%d,%d", &lo, &hi) == 2 && lo >= 1 && hi >= lo && hi <= 8) { waves_lo = lo; waves_hi = hi; }
 	}
@@ -1339,7 +1397,7 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
                   std::string& log, std::string* src_out = nullptr, const int* shape = nullptr, bool cull = true) {
 	std::string src = generate_source(P, fast, cull);
 	if (src_out) *src_out = src;
-	if (const char* dump = getenv("LOL_GPU_DUMP_SPEC_SOURCE"))       /* debugging aid: the source as really generated on this device */
+	if (const char* dump = tuning_env("LOL_GPU_DUMP_SPEC_SOURCE"))       /* debugging aid: the source as really generated on this device */
 		if (FILE* f = fopen(dump, "w")) { fputs(src.c_str(), f); fclose(f); }
 	int rtc_major = 0, rtc_minor = 0;
 	(void)hiprtcVersion(&rtc_major, &rtc_minor);
@@ -1348,7 +1406,7 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
 	std::string arch_opt = "--offload-arch=" + arch;
 	/* -ffp-contract=off: no FMA contraction (the reference has none); the rest are hipcc's defaults made explicit */
 	std::vector<std::string> extra;                     /* LOL_GPU_RTC_FLAGS: extra hipRTC options, for tuning experiments */
-	if (const char* e = getenv("LOL_GPU_RTC_FLAGS")) {
+	if (const char* e = tuning_env("LOL_GPU_RTC_FLAGS")) {
 		std::string cur;
 		for (const char* c = e;; c++) {
 			if (*c == ' ' || *c == 0) { if (!cur.empty()) extra.push_back(cur); cur.clear(); if (!*c) break; }
@@ -1366,7 +1424,7 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
 	 * elsewhere, LOL_GPU_SCHED=default leaves it out. */
 	std::vector<const char*> opts = { arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
 	                                  "-fno-slp-vectorize" };
-	const char* sched = getenv("LOL_GPU_SCHED");
+	const char* sched = tuning_env("LOL_GPU_SCHED");
 	if (rtc_major >= 9 && !(sched && !strcmp(sched, "default"))) {
 		opts.push_back("-mllvm"); opts.push_back("-amdgpu-sched-strategy=max-ilp");
 		/* ... and no post-RA scheduling pass: it re-orders the ILP-friendly schedule after register allocation and
@@ -1384,7 +1442,7 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
 		 * With the factor 0 no register is reserved and the branch relaxation scavenges a dead one at the branch, correctly.
 		 * has_return_clobbering_branch() below refuses any code object that still shows the pattern. */
 		/* (LOL_GPU_LONG_BRANCH_REG=1 leaves LLVM's default in place: for the test that sees the tripwire refuse the result) */
-		const char* lbr = getenv("LOL_GPU_LONG_BRANCH_REG");
+		const char* lbr = tuning_env("LOL_GPU_LONG_BRANCH_REG");
 		if (!(lbr && lbr[0] == '1')) { opts.push_back("-mllvm"); opts.push_back("-amdgpu-long-branch-factor=0"); }
 	}
 	char d0[32], d1[32], d2[32];
@@ -1405,7 +1463,7 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
 		Dl_info info;
 		if (dladdr(reinterpret_cast<void*>(&hiprtcCompileProgram), &info) && info.dli_fname) compiler = info.dli_fname;
 		compiler = std::to_string(rtc_major) + "." + std::to_string(rtc_minor) + " " + compiler;
-		const char* any = getenv("LOL_GPU_CACHE_ANY_COMPILER");
+		const char* any = tuning_env("LOL_GPU_CACHE_ANY_COMPILER");
 		if (any && any[0] == '1') compiler = "*";         /* its version too: torch's hipRTC and the system's differ in it */
 	}
 	std::string key = "lol_gpu/4|hiprtc " + compiler + "|";
@@ -1525,7 +1583,7 @@ void proofs_to_process(const lol_gpu* ctx) {
 
 FastPaths prove_fast_paths(lol_gpu* ctx, const lol_program& prog) {
 	FastPaths fast;
-	const char* fenv = getenv("LOL_GPU_FAST");
+	const char* fenv = tuning_env("LOL_GPU_FAST");
 	if (!ctx->want_fast || (fenv && fenv[0] == '0')) return fast;
 	proofs_from_process(ctx);
 	if (ctx->sqrt_verified < 0) {
@@ -1539,7 +1597,7 @@ FastPaths prove_fast_paths(lol_gpu* ctx, const lol_program& prog) {
 	fast.sqrt_tiny_ok = ctx->sqrt_tiny_ok;
 	/* gamma + quantisation through the table (lol_kernel.h); LOL_GPU_GAMMA_TABLE=0: through powf (A/B runs) */
 	{
-		const char* genv = getenv("LOL_GPU_GAMMA_TABLE");
+		const char* genv = tuning_env("LOL_GPU_GAMMA_TABLE");
 		if (!(genv && genv[0] == '0')) {
 			if (ctx->gamma_verified < 0) ctx->gamma_verified = run_verify_gamma(ctx) == 0 ? 1 : 0;
 			else if (ctx->gamma_verified == 1 && !ctx->d_gamma && !build_gamma_table(ctx)) ctx->gamma_verified = 0;      /* proven by another context of this device: only the table */
@@ -1549,7 +1607,7 @@ FastPaths prove_fast_paths(lol_gpu* ctx, const lol_program& prog) {
 	/* The shadow march's division shortcut (lol_kernel.h, fdiv_fast) is OFF unless LOL_GPU_SHADOW_FDIV=1: exact, but it bought
 	 * C3 0.95 % in a same-call A/B (7854 vs 7779 Mpixels/s, profiles/r4_ab_fdiv.txt), below the 1.5 % the review set as the bar
 	 * for keeping it in the default kernel.  Asked for, it is still only used after this device's own sweep agrees. */
-	if (getenv("LOL_GPU_SHADOW_FDIV") && getenv("LOL_GPU_SHADOW_FDIV")[0] == '1') {
+	if (tuning_env("LOL_GPU_SHADOW_FDIV") && tuning_env("LOL_GPU_SHADOW_FDIV")[0] == '1') {
 		if (ctx->fdiv_verified < 0) ctx->fdiv_verified = run_verify(ctx, -1, 0.f) == 0 ? 1 : 0;      /* (seed 0 travels as the bits of k = 0) */
 		fast.fdiv_ok = ctx->fdiv_verified == 1;
 	}
@@ -1569,7 +1627,7 @@ FastPaths prove_fast_paths(lol_gpu* ctx, const lol_program& prog) {
 		}
 		if (ok && !fast.has(o.f[0])) fast.div_ok.push_back(o.f[0]);
 		/* LOL_GPU_SMIN_FIXUP=1: keep v_div_fixup in every blend factor (A/B runs) */
-		if (nf && !fast.has_nf(o.f[0]) && !(getenv("LOL_GPU_SMIN_FIXUP") && getenv("LOL_GPU_SMIN_FIXUP")[0] == '1')) fast.div_nf_ok.push_back(o.f[0]);
+		if (nf && !fast.has_nf(o.f[0]) && !(tuning_env("LOL_GPU_SMIN_FIXUP") && tuning_env("LOL_GPU_SMIN_FIXUP")[0] == '1')) fast.div_nf_ok.push_back(o.f[0]);
 	}
 	proofs_to_process(ctx);
 	return fast;
@@ -1610,14 +1668,14 @@ void start_specialise(lol_gpu* ctx, const FastPaths& fast) {
 	ctx->spec_state = 0;
 	if (ctx->job) { ctx->old_jobs.push_back(ctx->job); ctx->job = nullptr; }      /* a compile of the scene before: its result is not wanted any more */
 	reap(ctx, false);
-	const char* env = getenv("LOL_GPU_SPECIALIZE");
+	const char* env = tuning_env("LOL_GPU_SPECIALIZE");
 	if (!ctx->want_spec || (env && env[0] == '0')) return;
 	/* every program up to LOL_SPEC_MAX_OPS is specialised, large ones with their SDF out of line (emit_sdf).  Beyond that the
 	 * straight-line source (two SDF bodies of ~150 bytes per op) takes hipRTC minutes, and programs no longer have a
 	 * capacity (lol_scene.h): such a scene renders on the interpreter, which reads it as data.  Not a failure: no complaint. */
 	{
 		uint32_t limit = LOL_SPEC_MAX_OPS;
-		if (const char* e = getenv("LOL_GPU_SPEC_MAX_OPS")) limit = (uint32_t)strtoul(e, nullptr, 10);
+		if (const char* e = tuning_env("LOL_GPU_SPEC_MAX_OPS")) limit = (uint32_t)strtoul(e, nullptr, 10);
 		if (ctx->h_prog.n_ops > limit) {
 			char b[160];
 			snprintf(b, sizeof b, "%u ops: above the %u the scene compiler takes on (LOL_GPU_SPEC_MAX_OPS); rendered by the interpreter", ctx->h_prog.n_ops, limit);
@@ -1643,9 +1701,11 @@ void start_specialise(lol_gpu* ctx, const FastPaths& fast) {
 		snprintf(b, sizeof b, "fast paths proven on device: sqrt=%d, smin divisors=%zu (without div_fixup: %zu)\n", fast.sqrt_kind,
 		         fast.div_ok.size(), fast.div_nf_ok.size());
 		job->note = b;
+		const std::string sw = lol_gpu_tuning_switches();
+		if (!sw.empty()) job->note += "tuning switches in effect (LOL_GPU_TUNING=1): " + sw + "\n";
 	}
 	/* tuning knobs for the pixel footprint of the specialised kernel (defaults: lol_kernel.h LOL_WAVE_W/H, LOL_WAVES_X) */
-	if (const char* e = getenv("LOL_GPU_WAVE_SHAPE")) {
+	if (const char* e = tuning_env("LOL_GPU_WAVE_SHAPE")) {
 		int a = 0, b = 0, c = 0;
 		if (sscanf(e, "%dx%dx%d", &a, &b, &c) == 3 && a > 0 && b > 0 && a * b == 64 && c >= 1 && c <= 16) {
 			job->shape[0] = a; job->shape[1] = b; job->shape[2] = c;
@@ -1671,7 +1731,7 @@ void start_specialise(lol_gpu* ctx, const FastPaths& fast) {
 	};
 	ctx->job = job;
 	ctx->spec_state = 1;
-	const char* async = getenv("LOL_GPU_ASYNC_COMPILE");
+	const char* async = tuning_env("LOL_GPU_ASYNC_COMPILE");
 	bool threaded = !(async && async[0] == '0');
 	/* LOL_GPU_ASYNC_COMPILE=0: the upload itself waits for the compiler (still on the large-stack thread) */
 	bool started = false;
@@ -1744,6 +1804,7 @@ int lol_gpu_create(int device, lol_gpu** out) {
 	ctx->device = device;
 	hipError_t e = hipSetDevice(device);
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+	ctx->frame_streams[0] = ctx->stream;
 	/* (the device tables are sized by the first upload) */
 	if (e != hipSuccess) {
 		fprintf(stderr, "lol_gpu_create: %s\n", hipGetErrorString(e));
@@ -1759,7 +1820,10 @@ static void lpt_release(lol_gpu* ctx);
 void lol_gpu_destroy(lol_gpu* ctx) {
 	if (!ctx) return;
 	if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
-	if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+	for (int i = lol_gpu::MAX_FRAME_STREAMS - 1; i >= 0; i--) {      /* ([0] is ctx->stream) */
+		hipStream_t fs = i ? ctx->frame_streams[i] : ctx->stream;
+		if (fs) { (void)hipStreamSynchronize(fs); (void)hipStreamDestroy(fs); }
+	}
 	if (ctx->job) { ctx->old_jobs.push_back(ctx->job); ctx->job = nullptr; }
 	reap(ctx, true);                         /* a compiler thread still running is waited for: it must not outlive the library */
 	if (ctx->spec_module) (void)hipModuleUnload(ctx->spec_module);
@@ -1769,7 +1833,7 @@ void lol_gpu_destroy(lol_gpu* ctx) {
 	}
 	if (ctx->d_frame) (void)hipFree(ctx->d_frame);
 	if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
-	for (int i = 0; i < 2; i++) {
+	for (int i = 0; i < lol_gpu::PIPE_SLOTS; i++) {
 		if (ctx->d_pipe[i]) (void)hipFree(ctx->d_pipe[i]);
 		if (ctx->pipe_rendered[i]) (void)hipEventDestroy(ctx->pipe_rendered[i]);
 		if (ctx->pipe_copied[i]) (void)hipEventDestroy(ctx->pipe_copied[i]);
@@ -1796,8 +1860,8 @@ int lol_gpu_set_specialize(lol_gpu* ctx, int enable) {
 
 /* which of the wanted skips the uploaded program (and the environment) allows */
 static void resolve_skips(lol_gpu* ctx) {
-	const char* ms = getenv("LOL_GPU_MISS_SKIP");                  /* the environment switches still win */
-	const char* ss = getenv("LOL_GPU_SHADOW_SETTLE");
+	const char* ms = tuning_env("LOL_GPU_MISS_SKIP");                  /* the environment switches still win */
+	const char* ss = tuning_env("LOL_GPU_SHADOW_SETTLE");
 	const unsigned want = (ms && ms[0] == '0') ? 0u : ctx->want_skips;
 	ctx->miss_skip = (want & 1u) && miss_skip_ok(ctx->h_prog);
 	ctx->dark_skip = (want & 2u) && dark_skip_ok(ctx->h_prog);
@@ -1850,8 +1914,11 @@ int lol_gpu_set_tile_order(lol_gpu* ctx, int order) {
 	T.deciding = false;                      /* a running series of trials is abandoned (its events are simply reused) */
 	T.key[0] = 0;                            /* ... and AUTO starts afresh at the next frame */
 	T.chosen = order == LOL_GPU_TILES_COLS ? LOL_GPU_TILES_COLS : LOL_GPU_TILES_ROWS;
-	ctx->lpt.key[0] = 0;                     /* longest-first starts afresh too (its tables stay allocated) */
-	ctx->lpt.have_last = false;
+	/* longest-first starts afresh too: its tables stay allocated, and stay on their streams — frames launched through them may
+	 * still be in flight, and whatever rewrites a set does so on the set's own stream, behind them (TileLpt::launched) */
+	for (lol_gpu::TileLpt& P : ctx->lpt) P.key[0] = 0;
+	ctx->lpt_have_last = false;
+	ctx->lpt_last_set = -1;
 	return LOL_GPU_OK;
 }
 
@@ -1899,7 +1966,7 @@ struct RegionShape { uint32_t w, h; };       /* multiples of 16 x 4; w * h a pow
 static RegionShape region_shape() {
 	static const RegionShape shape = [] {
 		RegionShape r = { 64, 16 };
-		if (const char* e = getenv("LOL_GPU_REGION")) {      /* WxH, for A/B runs */
+		if (const char* e = tuning_env("LOL_GPU_REGION")) {      /* WxH, for A/B runs */
 			unsigned a = 0, b = 0;
 			if (sscanf(e, "%ux%u", &a, &b) == 2 && a % 16 == 0 && b % 4 == 0 && a * b >= 64 && a * b <= 4096 && ((a * b) & (a * b - 1)) == 0) r = { a, b };
 		}
@@ -1999,16 +2066,18 @@ __global__ __launch_bounds__(LPT_THREADS) void lpt_scatter_kernel(const uint32_t
 }
 
 static unsigned lpt_resort_period() {
-	static const unsigned period = [] { const char* e = getenv("LOL_GPU_LPT_RESORT"); const int v = e ? atoi(e) : 0; return v > 0 ? (unsigned)v : LPT_RESORT; }();
+	static const unsigned period = [] { const char* e = tuning_env("LOL_GPU_LPT_RESORT"); const int v = e ? atoi(e) : 0; return v > 0 ? (unsigned)v : LPT_RESORT; }();
 	return period;
 }
 
-static void lpt_release(lol_gpu* ctx) {
-	lol_gpu::TileLpt& T = ctx->lpt;
+static void lpt_release_set(lol_gpu::TileLpt& T) {
 	for (uint32_t** p : { &T.d_order[0], &T.d_order[1], &T.d_cost, &T.d_keys, &T.d_hist, &T.d_lanes })
 		if (*p) { (void)hipFree(*p); *p = nullptr; }
 	if (T.d_pixel_cost) { (void)hipFree(T.d_pixel_cost); T.d_pixel_cost = nullptr; }
 	T.cap = 0; T.lanes_cap = 0; T.pixels_cap = 0; T.n_tiles = 0; T.key[0] = 0;
+}
+static void lpt_release(lol_gpu* ctx) {
+	for (lol_gpu::TileLpt& T : ctx->lpt) { lpt_release_set(T); T.home = nullptr; T.launched = false; }
 }
 
 /* The table for the frame about to be launched on `s` (device current), or nullptr: a launch in one of the fixed orders.
@@ -2031,48 +2100,61 @@ struct FrameTables { const uint32_t* order; uint32_t* cost; const uint32_t* lane
 
 static bool lpt_table_for_frame(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h, int max_steps, const lol_gpu_rows* R, int n_rows,
                                 int block, hipStream_t s, FrameTables* out) {
-	lol_gpu::TileLpt& T = ctx->lpt;
 	const uint32_t REGION_W = region_shape().w, REGION_H = region_shape().h, REGION_WAVES = REGION_W * REGION_H / 64;
 	const uint32_t regions_x = ((uint32_t)w + REGION_W - 1) / REGION_W, regions_y = ((uint32_t)n_rows + REGION_H - 1) / REGION_H;
 	const uint32_t n = regions_x * regions_y * REGION_WAVES;            /* wave slots = blocks of the launch */
 	const size_t n_lanes = (size_t)n * 64, n_pixels = (size_t)w * (size_t)n_rows;
+	ctx->lpt_last_set = -1;
 	if (block != 64 || w > 0xFFFF || n_rows > 0x7FFF || n_lanes > 0xFFFFFFFFull) return false;      /* (an entry is column | row << 16 | flag; one-wave blocks) */
 	const int key[7] = { w, h, max_steps, R->band_rows, R->cycle_rows, R->offset_rows, ctx->generation * 2 + (ctx->spec_fn ? 1 : 0) };
-	/* what the frame before this one was: the same view of the same frame? */
-	const bool still = T.have_last && memcmp(key, T.last_key, sizeof key) == 0 && memcmp(cam, &T.last_cam, sizeof *cam) == 0;
-	memcpy(T.last_key, key, sizeof key);
-	T.last_cam = *cam;
-	T.have_last = true;
+	/* what the frame before this one was (on whatever stream): the same view of the same frame? */
+	const bool still = ctx->lpt_have_last && memcmp(key, ctx->lpt_last_key, sizeof key) == 0 && memcmp(cam, &ctx->lpt_last_cam, sizeof *cam) == 0;
+	memcpy(ctx->lpt_last_key, key, sizeof key);
+	ctx->lpt_last_cam = *cam;
+	ctx->lpt_have_last = true;
 	if (!still) return false;
 	auto ok = [](hipError_t e) { if (e != hipSuccess) (void)hipGetLastError(); return e == hipSuccess; };
+	/* the set that lives on this stream; else a free one; else — once the host has stayed on the new stream for two such
+	 * frames in a row — the least recently used one, after ITS stream has run dry (a fixed order meanwhile) */
+	lol_gpu::TileLpt* Tp = nullptr;
+	for (lol_gpu::TileLpt& P : ctx->lpt) if (P.home == s) Tp = &P;
+	if (!Tp) for (lol_gpu::TileLpt& P : ctx->lpt) if (!P.home && !Tp) Tp = &P;
+	if (!Tp) {
+		if (++ctx->lpt_homeless < 2) return false;
+		for (lol_gpu::TileLpt& P : ctx->lpt) if (!Tp || P.stamp < Tp->stamp) Tp = &P;
+		if (!ok(hipStreamSynchronize(Tp->home))) return false;
+		Tp->launched = false;
+		Tp->key[0] = 0;                                  /* whatever it knew was another stream's schedule */
+	}
+	ctx->lpt_homeless = 0;
+	lol_gpu::TileLpt& T = *Tp;
+	T.home = s;
+	T.stamp = ++ctx->lpt_clock;
 	const bool new_key = memcmp(key, T.key, sizeof key) != 0;
 	if (new_key) {
-		/* frames of the old key may still read the tables, on their stream: drain the device before the tables change hands */
+		/* frames of the old key may still read these tables — on this very stream, so the kernels that rewrite them queue up
+		 * behind those frames; only FREEING the tables needs the stream to have run dry first */
 		const bool grow = n > T.cap || n_lanes > T.lanes_cap || n_pixels > T.pixels_cap;
-		if (T.key[0] && (grow || s != T.home) && !ok(hipDeviceSynchronize())) return false;
 		if (grow) {
-			lpt_release(ctx);
+			if (T.launched && !ok(hipStreamSynchronize(s))) return false;
+			T.launched = false;
+			lpt_release_set(T);
 			const size_t cap = (size_t)n + n / 4 + 1024;      /* (tile_slot reaches 8 * ceil(n / 8) - 1 < n + 8) */
 			const bool good = ok(hipMalloc(reinterpret_cast<void**>(&T.d_order[0]), cap * 4)) && ok(hipMalloc(reinterpret_cast<void**>(&T.d_order[1]), cap * 4)) &&
 			                  ok(hipMalloc(reinterpret_cast<void**>(&T.d_cost), cap * 4)) && ok(hipMalloc(reinterpret_cast<void**>(&T.d_keys), cap * 4)) &&
 			                  ok(hipMalloc(reinterpret_cast<void**>(&T.d_hist), 2 * LPT_BUCKETS * 4)) &&
 			                  ok(hipMalloc(reinterpret_cast<void**>(&T.d_lanes), n_lanes * 4)) &&
 			                  ok(hipMalloc(reinterpret_cast<void**>(&T.d_pixel_cost), n_pixels * 2));
-			if (!good) { lpt_release(ctx); return false; }
+			if (!good) { lpt_release_set(T); T.home = nullptr; return false; }
 			T.cap = cap; T.lanes_cap = n_lanes; T.pixels_cap = n_pixels;
 		}
 		memcpy(T.key, key, sizeof key);
-		T.n_tiles = n; T.home = s; T.foreign = 0;
-	} else if (s != T.home) {
-		/* a frame of this geometry on another stream: a fixed order — unless the host has moved over for good (the second
-		 * such frame in a row): then the tables move with it, once the old stream has run dry */
-		if (++T.foreign < 2 || !ok(hipStreamSynchronize(T.home))) return false;
-		T.home = s;
-		T.foreign = 0;
+		T.n_tiles = n;
 	}
 	const dim3 grid((n + LPT_THREADS - 1) / LPT_THREADS);
 	const uint32_t stride = (n + 7u) >> 3;
 	bool record_pixels = false;
+	T.launched = true;                                   /* (from here on something of this set is queued on s) */
 	if (new_key || memcmp(cam, &T.cam_epoch, sizeof *cam) != 0) {
 		/* a view these tables know nothing about: rectangles, handed out in region order; this frame reports what every
 		 * pixel and every wave cost */
@@ -2095,11 +2177,11 @@ static bool lpt_table_for_frame(lol_gpu* ctx, const lol_frame_camera* cam, int w
 			hipLaunchKernelGGL(lpt_hist_kernel, grid, dim3(LPT_THREADS), 0, s, T.d_cost, T.d_keys, T.d_hist, n, stride);
 			hipLaunchKernelGGL(lpt_scan_kernel, dim3(1), dim3(LPT_BUCKETS), 0, s, T.d_hist);
 			hipLaunchKernelGGL(lpt_scatter_kernel, grid, dim3(LPT_THREADS), 0, s, T.d_keys, T.d_order[T.cur], T.d_order[T.cur ^ 1], T.d_hist, n, stride);
-			if (ok(hipGetLastError())) { T.cur ^= 1; T.sorts++; }
+			if (ok(hipGetLastError())) { T.cur ^= 1; T.sorts++; ctx->lpt_sorts++; }
 		}
 	}
-	T.foreign = 0;
 	T.frames++;
+	ctx->lpt_last_set = (int)(Tp - ctx->lpt);
 	*out = { T.d_order[T.cur], T.d_cost, T.d_lanes, record_pixels ? T.d_pixel_cost : nullptr, n };
 	return true;
 }
@@ -2218,9 +2300,8 @@ int lol_gpu_tile_order(lol_gpu* ctx, lol_gpu_tile_order_info* out) {
 	if (T.mode == LOL_GPU_TILES_LPT) {
 		/* longest first: the last frame went through a table (order LPT; "deciding" until its costs have been sorted once), or
 		 * the camera moves and AUTO's fixed order is in use (its state and trial times) */
-		const lol_gpu::TileLpt& P = ctx->lpt;
-		if (P.last_table) *out = { T.mode, LOL_GPU_TILES_LPT, P.frames < 3 ? 1 : 0, (int32_t)P.sorts, T.typical[0], T.typical[1] };
-		else *out = { T.mode, T.chosen, (T.deciding || P.sorts == 0) ? 1 : 0, (int32_t)P.sorts, T.typical[0], T.typical[1] };
+		if (ctx->lpt_last_set >= 0) *out = { T.mode, LOL_GPU_TILES_LPT, ctx->lpt[ctx->lpt_last_set].frames < 3 ? 1 : 0, (int32_t)ctx->lpt_sorts, T.typical[0], T.typical[1] };
+		else *out = { T.mode, T.chosen, (T.deciding || ctx->lpt_sorts == 0) ? 1 : 0, (int32_t)ctx->lpt_sorts, T.typical[0], T.typical[1] };
 	} else
 		*out = { T.mode, T.chosen, T.deciding ? 1 : 0, T.decisions, T.typical[0], T.typical[1] };
 	return LOL_GPU_OK;
@@ -2458,7 +2539,8 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 		L.dbg_hit_id = dbg->hit_id; L.dbg_steps = dbg->steps;
 	}
 
-	hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;      /* LOL_GPU_STREAM_DEFAULT == hipStreamLegacy */
+	/* LOL_GPU_STREAM_DEFAULT == hipStreamLegacy; NULL = the context's own stream(s), in turn (lol_gpu_set_frames_in_flight) */
+	hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->frame_streams[ctx->frame_rr++ % (unsigned)ctx->n_frame_streams];
 	LOL_HIP(ctx, hipSetDevice(ctx->device));
 	finish_specialise(ctx, false);           /* the frame boundary at which a finished scene kernel takes over */
 	const bool spec = ctx->spec_fn != nullptr;
@@ -2480,7 +2562,7 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 			grid = dim3(F.n_waves, 1);
 		}
 	}
-	ctx->lpt.last_table = table;
+	if (!table) ctx->lpt_last_set = -1;
 	/* (longest-first without a table — the camera moves, or another stream —: the better of the two fixed orders, like AUTO) */
 	if (!table && tile_order_for_frame(ctx, w, h, max_steps, R, dbg != nullptr, &trial) == LOL_GPU_TILES_COLS) {
 		L.flags |= lol::FLAG_TILE_COLS;
@@ -2535,10 +2617,17 @@ int lol_gpu_set_pixel_format(lol_gpu* ctx, const lol_gpu_pixel_format* fmt) {
 	return LOL_GPU_OK;
 }
 
+/* the context's second, third ... frame stream, created when first wanted */
+static int ensure_frame_streams(lol_gpu* ctx, int n) {
+	for (int i = 1; i < n && i < lol_gpu::MAX_FRAME_STREAMS; i++)
+		if (!ctx->frame_streams[i]) LOL_HIP(ctx, hipStreamCreateWithFlags(&ctx->frame_streams[i], hipStreamNonBlocking));
+	return LOL_GPU_OK;
+}
+
 static int ensure_copy_stream(lol_gpu* ctx) {
 	if (ctx->copy_stream) return LOL_GPU_OK;
 	LOL_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-	for (int i = 0; i < 2; i++) {
+	for (int i = 0; i < lol_gpu::PIPE_SLOTS; i++) {
 		LOL_HIP(ctx, hipEventCreateWithFlags(&ctx->pipe_rendered[i], hipEventDisableTiming));
 		LOL_HIP(ctx, hipEventCreateWithFlags(&ctx->pipe_copied[i], hipEventDisableTiming));
 	}
@@ -2571,7 +2660,7 @@ int lol_gpu_render_host(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h,
 		LOL_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_frame), need));
 		ctx->frame_bytes = need;
 	}
-	int st = lol_gpu_render_device(ctx, cam, w, h, max_steps, nullptr, ctx->d_frame, (size_t)w * 4, nullptr, nullptr);
+	int st = lol_gpu_render_device(ctx, cam, w, h, max_steps, nullptr, ctx->d_frame, (size_t)w * 4, nullptr, ctx->stream);
 	if (st != LOL_GPU_OK) return st;
 	LOL_HIP(ctx, hipMemcpy2DAsync(host_pixels, pitch_bytes, ctx->d_frame, (size_t)w * 4, (size_t)w * 4, h,
 	                              hipMemcpyDeviceToHost, ctx->stream));
@@ -2580,39 +2669,56 @@ int lol_gpu_render_host(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h,
 }
 
 /*
- * The host-surface path with two frames in flight: begin() queues frame i+1's kernel while end() copies frame i
+ * The host-surface path with frames in flight: begin() queues frame i+1's kernel while end() copies frame i
  * into the host's surface, so the 33 MB device-to-host copy of a 4K frame (0.6 ms at PCIe Gen5 rates) runs under
- * the next frame's kernel instead of after its own.  Kernels go to the context's stream, copies to a second
- * stream, two device framebuffers alternate.  Measured at the kernel's own rate on C3: the copy hides completely
- * (bench.py `host_surface`).
+ * the next frame's kernel instead of after its own.  Copies go to a stream of their own, one device framebuffer per
+ * frame in flight.
+ *
+ * Round 5: and the KERNELS of consecutive frames go to different streams.  A frame is one launch that ends with its slowest
+ * waves on half-empty SIMDs; the reference's loop cannot start frame i+1 before frame i has been shown
+ * (main.c:189-194), but a host that has handed over the next camera already can: frame i+1's first waves fill frame i's
+ * tail (tools/stream_overlap_ab.py: +9 % C3, +13 % the orbit, +67 % scene.lol at 1080p).  That is what helps a camera that
+ * MOVES, whose frames cannot be scheduled by their predecessors' costs; a camera that stands still keeps its schedule as
+ * well — one set of tables per stream (lpt_table_for_frame).  Frames in flight: two by default, up to PIPE_SLOTS after
+ * lol_gpu_set_frames_in_flight(ctx, n).  What keeps a framebuffer safe is events, not stream order: a slot's kernel
+ * waits for the copy that last read the slot, a slot's copy for the kernel that wrote it.
  */
 int lol_gpu_render_host_begin(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h, int max_steps) {
 	if (!ctx || !cam) return LOL_GPU_ERR_ARG;
 	if (w <= 0 || h <= 0) return fail(ctx, LOL_GPU_ERR_ARG, "bad frame geometry");
-	if (ctx->pipe_begun - ctx->pipe_ended >= 2) return fail(ctx, LOL_GPU_ERR_ARG, "two frames already in flight: call lol_gpu_render_host_end first");
+	const unsigned depth = (unsigned)std::max(2, ctx->n_frame_streams);
+	if (ctx->pipe_begun - ctx->pipe_ended >= depth)
+		return fail(ctx, LOL_GPU_ERR_ARG, depth == 2 ? "two frames already in flight: call lol_gpu_render_host_end first"
+		                                             : "every frame slot is in flight (lol_gpu_set_frames_in_flight): call lol_gpu_render_host_end first");
 	LOL_HIP(ctx, hipSetDevice(ctx->device));
 	{
-		const int st = ensure_copy_stream(ctx);
+		int st = ensure_copy_stream(ctx);
+		if (st == LOL_GPU_OK) st = ensure_frame_streams(ctx, (int)depth);
 		if (st != LOL_GPU_OK) return st;
 	}
-	const int slot = (int)(ctx->pipe_begun & 1u);
+	const int slot = (int)(ctx->pipe_begun % lol_gpu::PIPE_SLOTS);
+	hipStream_t ks = ctx->frame_streams[ctx->pipe_begun % depth];
 	const size_t need = (size_t)w * h * 4;
 	if (need > ctx->pipe_bytes[slot]) {
-		/* the surface grew (main.c:182-187).  This slot's last frame was ended two calls ago; its copy may still run:
-		 * wait for it, then replace this slot's framebuffer only — the frame queued in the OTHER slot stays valid */
+		/* the surface grew (main.c:182-187).  This slot's last frame was ended PIPE_SLOTS calls ago; its copy may still run, and
+		 * so may the kernel of a frame that was discarded: wait for both, then replace this slot's framebuffer only — the
+		 * frames queued in the OTHER slots stay valid */
 		LOL_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
-		LOL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		if (ctx->pipe_stream[slot]) LOL_HIP(ctx, hipStreamSynchronize(ctx->pipe_stream[slot]));
 		if (ctx->d_pipe[slot]) (void)hipFree(ctx->d_pipe[slot]);
 		ctx->d_pipe[slot] = nullptr;
 		ctx->pipe_bytes[slot] = 0;
 		LOL_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_pipe[slot]), need));
 		ctx->pipe_bytes[slot] = need;
 	}
-	/* the copy that last read this framebuffer (two frames ago) must be done before the kernel overwrites it */
-	LOL_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->pipe_copied[slot], 0));
-	int st = lol_gpu_render_device(ctx, cam, w, h, max_steps, nullptr, ctx->d_pipe[slot], (size_t)w * 4, nullptr, nullptr);
+	/* the copy that last read this framebuffer must be done before the kernel overwrites it — and so must the kernel that
+	 * last wrote it, where that one ran on another stream (a frame that was discarded; a changed number of streams) */
+	LOL_HIP(ctx, hipStreamWaitEvent(ks, ctx->pipe_copied[slot], 0));
+	if (ctx->pipe_stream[slot] && ctx->pipe_stream[slot] != ks) LOL_HIP(ctx, hipStreamWaitEvent(ks, ctx->pipe_rendered[slot], 0));
+	int st = lol_gpu_render_device(ctx, cam, w, h, max_steps, nullptr, ctx->d_pipe[slot], (size_t)w * 4, nullptr, ks);
 	if (st != LOL_GPU_OK) return st;
-	LOL_HIP(ctx, hipEventRecord(ctx->pipe_rendered[slot], ctx->stream));
+	LOL_HIP(ctx, hipEventRecord(ctx->pipe_rendered[slot], ks));
+	ctx->pipe_stream[slot] = ks;
 	ctx->pipe_w[slot] = w; ctx->pipe_h[slot] = h;
 	ctx->pipe_begun++;
 	return LOL_GPU_OK;
@@ -2621,7 +2727,7 @@ int lol_gpu_render_host_begin(lol_gpu* ctx, const lol_frame_camera* cam, int w, 
 int lol_gpu_render_host_end(lol_gpu* ctx, void* host_pixels, size_t pitch_bytes, int w, int h) {
 	if (!ctx || !host_pixels) return LOL_GPU_ERR_ARG;
 	if (ctx->pipe_begun == ctx->pipe_ended) return fail(ctx, LOL_GPU_ERR_ARG, "no frame in flight");
-	const int slot = (int)(ctx->pipe_ended & 1u);
+	const int slot = (int)(ctx->pipe_ended % lol_gpu::PIPE_SLOTS);
 	/* the surface's size, as the caller sees it NOW, decides what may be written: a frame queued before a resize
 	 * is never copied into a surface of another size (it stays queued: discard it, or end it into a fitting one) */
 	if (w != ctx->pipe_w[slot] || h != ctx->pipe_h[slot])
@@ -2642,7 +2748,7 @@ int lol_gpu_render_host_pending(const lol_gpu* ctx) { return ctx ? (int)(ctx->pi
 int lol_gpu_render_host_pending_size(const lol_gpu* ctx, int* w, int* h) {
 	if (!ctx || !w || !h) return LOL_GPU_ERR_ARG;
 	const bool any = ctx->pipe_begun != ctx->pipe_ended;
-	const int slot = (int)(ctx->pipe_ended & 1u);
+	const int slot = (int)(ctx->pipe_ended % lol_gpu::PIPE_SLOTS);
 	*w = any ? ctx->pipe_w[slot] : 0;
 	*h = any ? ctx->pipe_h[slot] : 0;
 	return LOL_GPU_OK;
@@ -2655,11 +2761,39 @@ int lol_gpu_render_host_discard(lol_gpu* ctx) {
 	return LOL_GPU_OK;
 }
 
+/* every stream of the context's own: frames in flight may be on any of them */
+static int sync_own_streams(lol_gpu* ctx) {
+	for (hipStream_t fs : ctx->frame_streams) if (fs) LOL_HIP(ctx, hipStreamSynchronize(fs));
+	return LOL_GPU_OK;
+}
+
 int lol_gpu_sync(lol_gpu* ctx) {
 	if (!ctx) return LOL_GPU_ERR_ARG;
 	LOL_HIP(ctx, hipSetDevice(ctx->device));
-	LOL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return sync_own_streams(ctx);
+}
+
+int lol_gpu_set_frames_in_flight(lol_gpu* ctx, int n) {
+	if (!ctx || n < 1 || n > lol_gpu::MAX_FRAME_STREAMS) return LOL_GPU_ERR_ARG;
+	LOL_HIP(ctx, hipSetDevice(ctx->device));
+	{
+		const int st = ensure_frame_streams(ctx, n);
+		if (st != LOL_GPU_OK) return st;
+	}
+	/* a frame queued on a stream that is about to fall out of the rotation stays ordered before whatever comes next */
+	{
+		const int st = sync_own_streams(ctx);
+		if (st != LOL_GPU_OK) return st;
+	}
+	ctx->n_frame_streams = n;
+	ctx->frame_rr = 0;
 	return LOL_GPU_OK;
+}
+
+int lol_gpu_frames_in_flight(const lol_gpu* ctx) { return ctx ? ctx->n_frame_streams : 0; }
+
+void* lol_gpu_next_stream(lol_gpu* ctx) {
+	return ctx ? static_cast<void*>(ctx->frame_streams[ctx->frame_rr % (unsigned)ctx->n_frame_streams]) : nullptr;
 }
 
 int lol_gpu_malloc(lol_gpu* ctx, size_t bytes, void** out) {
@@ -2679,7 +2813,10 @@ int lol_gpu_free(lol_gpu* ctx, void* ptr) {
 int lol_gpu_memcpy_d2h(lol_gpu* ctx, void* host, const void* dev, size_t bytes) {
 	if (!ctx || !host || !dev) return LOL_GPU_ERR_ARG;
 	LOL_HIP(ctx, hipSetDevice(ctx->device));
-	LOL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	{
+		const int st = sync_own_streams(ctx);
+		if (st != LOL_GPU_OK) return st;
+	}
 	LOL_HIP(ctx, hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
 	return LOL_GPU_OK;
 }

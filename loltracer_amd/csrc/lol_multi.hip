@@ -45,6 +45,9 @@
 #include <new>
 #include <thread>
 
+/* lol_gpu.hip: an A/B switch from the environment, honoured only beside LOL_GPU_TUNING=1 and recorded when it is */
+const char* lol_gpu_internal_tuning_env(const char* name);
+
 namespace {
 
 struct Rccl {
@@ -385,7 +388,7 @@ int lol_gpu_multi_create(const int* devices, int n, lol_gpu_multi** out) {
 		for (int s = 0; s < SLOTS && e == hipSuccess; s++) e = hipEventCreateWithFlags(&m->done[s], hipEventDisableTiming);
 		if (e != hipSuccess) return bail("event setup", hipGetErrorString(e));
 	}
-	if (const char* e = getenv("LOL_GPU_MULTI_HOST_VIA_ROOT")) m->host_via_root = e[0] == '1';
+	if (const char* e = lol_gpu_internal_tuning_env("LOL_GPU_MULTI_HOST_VIA_ROOT")) m->host_via_root = e[0] == '1';
 	*out = m;
 	return LOL_GPU_OK;
 }

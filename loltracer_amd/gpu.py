@@ -16,7 +16,7 @@ import os
 from . import scene as S
 
 LOL_GPU_OK = 0
-LOL_GPU_ABI_VERSION = 4          # include/lol_gpu.h
+LOL_GPU_ABI_VERSION = 5          # include/lol_gpu.h
 _STATUS = {0: "ok", -1: "no HIP device", -2: "HIP runtime error", -3: "bad argument",
            -4: "no scene program uploaded", -5: "unsupported"}
 
@@ -142,6 +142,14 @@ def gpu_lib() -> C.CDLL:
         lib.lol_gpu_roctx_ranges.restype = C.c_long
         lib.lol_gpu_sync.argtypes = [vp]
         lib.lol_gpu_sync.restype = C.c_int
+        lib.lol_gpu_set_frames_in_flight.argtypes = [vp, C.c_int]
+        lib.lol_gpu_set_frames_in_flight.restype = C.c_int
+        lib.lol_gpu_frames_in_flight.argtypes = [vp]
+        lib.lol_gpu_frames_in_flight.restype = C.c_int
+        lib.lol_gpu_next_stream.argtypes = [vp]
+        lib.lol_gpu_next_stream.restype = vp
+        lib.lol_gpu_tuning_switches.argtypes = []
+        lib.lol_gpu_tuning_switches.restype = C.c_char_p
         lib.lol_gpu_malloc.argtypes = [vp, C.c_size_t, P(vp)]
         lib.lol_gpu_malloc.restype = C.c_int
         lib.lol_gpu_free.argtypes = [vp, vp]
@@ -269,7 +277,13 @@ EXPORTED_SYMBOLS = [
     "lol_gpu_render_host_pending_size", "lol_gpu_render_host_discard", "lol_gpu_kernel_key", "lol_gpu_roctx_ranges",
     "lol_gpu_assemble_parts_at", "lol_gpu_split_rows", "lol_gpu_multi_set_root_band_rows",
     "lol_gpu_multi_set_pixel_format", "lol_gpu_multi_set_tile_order",
+    "lol_gpu_set_frames_in_flight", "lol_gpu_frames_in_flight", "lol_gpu_next_stream", "lol_gpu_tuning_switches",
 ]
+
+
+def tuning_switches() -> str:
+    """lol_gpu_tuning_switches: the LOL_GPU_* A/B switches this process has honoured so far (needs LOL_GPU_TUNING=1)."""
+    return gpu_lib().lol_gpu_tuning_switches().decode()
 
 
 def compile_offline(program: S.Program, out_base: str, arch: str = "gfx950", assume_fast: bool = False) -> str:
@@ -369,7 +383,8 @@ class Renderer:
                                                   pitch_bytes if pitch_bytes is not None else w * 4))
 
     def render_host_begin(self, w: int, h: int, max_steps: int = 256, camera: S.Camera | None = None):
-        """Queue a frame for the host-surface path (two may be in flight); render_host_end() delivers the oldest."""
+        """Queue a frame for the host-surface path (two may be in flight, up to four after set_frames_in_flight);
+        render_host_end() delivers the oldest."""
         fc = self.scene.frame_camera(w, h, camera)
         self._check(self._lib.lol_gpu_render_host_begin(self._ctx, C.byref(fc), w, h, max_steps))
 
@@ -404,6 +419,18 @@ class Renderer:
 
     def sync(self):
         self._check(self._lib.lol_gpu_sync(self._ctx))
+
+    def set_frames_in_flight(self, n: int):
+        """Frames launched with stream=None go to n streams of the context in turn (1 = sequential, the default; <= 4):
+        consecutive frames overlap.  Give frames that may be in flight together destinations of their own."""
+        self._check(self._lib.lol_gpu_set_frames_in_flight(self._ctx, n))
+
+    def frames_in_flight(self) -> int:
+        return int(self._lib.lol_gpu_frames_in_flight(self._ctx))
+
+    def next_stream(self) -> int:
+        """hipStream_t handle the next frame launched with stream=None goes to (for events around a frame)."""
+        return int(self._lib.lol_gpu_next_stream(self._ctx) or 0)
 
     def kernel_name(self) -> str:
         return self._lib.lol_gpu_kernel_name(self._ctx).decode()
@@ -449,8 +476,9 @@ class Renderer:
         self._check(self._lib.lol_gpu_set_cull(self._ctx, 1 if enable else 0))
 
     def set_tile_order(self, order):
-        """0 / False / "rows", 1 / True / "cols", 2 / "auto" (the default: the library times both on the first frames of a
-        scene and size and keeps the faster) — same pixels either way (lol_gpu.h)."""
+        """0 / False / "rows", 1 / True / "cols", 2 / "auto" (the library times both fixed orders on the first frames of a scene
+        and size and keeps the faster), 3 / "lpt" (the default: a repeated view is scheduled by what the frame before cost, any
+        other frame runs in auto's fixed order) — same pixels either way (lol_gpu.h)."""
         self._check(self._lib.lol_gpu_set_tile_order(self._ctx, _tile_order_arg(order)))
 
     def tile_order(self) -> dict:

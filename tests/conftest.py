@@ -10,6 +10,11 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 SCENES = os.path.join(ROOT, "tests", "golden", "scenes")
 
+# The library honours its LOL_GPU_* A/B switches only beside LOL_GPU_TUNING=1 (include/lol_gpu.h, lol_gpu_tuning_switches): the
+# tests that compare code paths set such switches, so the test session opts in.  tests/test_cabi.py checks the fence itself in
+# processes that do not.
+os.environ.setdefault("LOL_GPU_TUNING", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")

@@ -193,7 +193,7 @@ def test_valu_record_describes_the_machine_and_has_no_fraction_above_one():
     v = bench.valu_fields("lol_render_spec", rec["workload"], rec["pixels_per_launch"], rec["kernel_key"], 7800.0, Ctr, 107.0)
     assert abs(v["issue_frac"] - 2.0 / rec["cycles_per_valu_instruction_per_simd"]) < 1e-3 and 0 < v["issue_frac"] <= 1
     assert abs(v["valu_instructions_per_pixel"] - rec["valu_instructions_per_pixel"]) < 0.1
-    assert 0 < v["lane_efficiency"] <= 1
+    assert 0 < v["lane_efficiency_modelled"] <= 1
     assert "frac" not in v and v["reference_equivalent_tops"] > 0
     for k, x in v.items():
         if k.endswith("frac") and x is not None:

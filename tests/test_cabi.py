@@ -153,6 +153,43 @@ def test_code_objects_are_cached_on_disk(tmp_path, scenes):
     assert "disk cache" not in run("")                            # switched off: compiles, writes nothing
 
 
+def test_tuning_switches_are_fenced_and_recorded(tmp_path):
+    """Round-4 review: LOL_GPU_RTC_FLAGS=-ffp-contract=fast inherited from some shell would silently end parity.  The library's
+    A/B switches are honoured only beside LOL_GPU_TUNING=1: a plain process with the flag set compiles the SAME code object as
+    one without (and says on stderr that it ignored the switch); with LOL_GPU_TUNING=1 the flag takes effect, another code
+    object comes out, and lol_gpu_tuning_switches() names it."""
+    import subprocess
+    import sys
+    code = ("import sys, hashlib; sys.path.insert(0, %r)\n"
+            "from loltracer_amd import gpu, scene as S\n"
+            "sc = S.Scene.parse_file(%r)\n"
+            "gpu.compile_offline(sc.flatten(), sys.argv[1])\n"
+            "print(hashlib.sha1(open(sys.argv[1] + '.co', 'rb').read()).hexdigest(), '|' + gpu.tuning_switches() + '|')\n"
+            ) % (ROOT, os.path.join(ROOT, "tests", "golden", "scenes", "scene.lol"))
+    base = {k: v for k, v in os.environ.items() if not k.startswith("LOL_GPU_")}
+    base["LOL_GPU_CACHE_DIR"] = ""
+
+    def run(tag, **extra):
+        p = subprocess.run([sys.executable, "-c", code, str(tmp_path / tag)], env=dict(base, **extra), capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr
+        digest, switches = p.stdout.split()[0], p.stdout.split("|")[1]
+        return digest, switches, p.stderr
+
+    plain, sw, err = run("plain")
+    assert sw == "" and "LOL_GPU_TUNING" not in err
+    fenced, sw, err = run("fenced", LOL_GPU_RTC_FLAGS="-ffp-contract=fast", LOL_GPU_SCHED="default", LOL_GPU_LONG_BRANCH_REG="1")
+    assert fenced == plain and sw == ""                            # same kernel, nothing in effect ...
+    for name in ("LOL_GPU_RTC_FLAGS", "LOL_GPU_SCHED", "LOL_GPU_LONG_BRANCH_REG"):
+        assert f"{name} is set but LOL_GPU_TUNING=1 is not: ignored" in err      # ... and said so, once each
+        assert err.count(name + " is set") == 1
+    tuned, sw, err = run("tuned", LOL_GPU_TUNING="1", LOL_GPU_RTC_FLAGS="-ffp-contract=fast")
+    assert tuned != plain and "LOL_GPU_RTC_FLAGS=-ffp-contract=fast" in sw and "ignored" not in err
+    again, sw, _ = run("again", LOL_GPU_TUNING="1")                # the opt-in alone changes nothing
+    assert again == plain and sw == ""
+    _, sw, _ = run("yes", LOL_GPU_TUNING="yes", LOL_GPU_SCHED="default")         # only the literal 1 opts in
+    assert sw == ""
+
+
 def test_small_scenes_keep_their_tables_in_lds_and_large_ones_do_not(tmp_path):
     """lights | materials | root_material are staged into LDS per one-wave block while they fit 4 KB (lol_kernel.h,
     TABLES_LDS_MAX_DWORDS) — a field of 250 objects does, as before — and are read from global memory beyond: the generated

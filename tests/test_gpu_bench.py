@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _bench(args, **env):
-    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOL_GPU_TUNING")}      # (a plain process, like the driver's)
     e.update(env)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True, timeout=420)
@@ -50,6 +50,8 @@ def test_orbit_over_two_ranks_checks_frames_against_rank_0():
     assert out["scaling"] == "weak" and out["steps"] == 256 and out["n_ranks_seen"] == 2
     assert out["frames_equal_to_rank0_render"] is True and "[check] 4 orbit frames of 2 ranks" in err
     assert [r["frames"] for r in out["per_rank"]] == [128, 128] and all(r["rows"] == 2160 for r in out["per_rank"])
+    # the orbit's frames are independent: three in flight per rank, every one a new camera
+    assert out["config"]["frames_in_flight"] == 3 and out["value_new_view"] == out["value"] and out["config"]["camera"].startswith("moving")
 
 
 def test_default_line_carries_roofline_cpu_baseline_and_both_kernels():
@@ -72,9 +74,21 @@ def test_default_line_carries_roofline_cpu_baseline_and_both_kernels():
     assert sch["fixed_rows_frame_equal"] is True and sch["fixed_cols_frame_equal"] is True
     assert sch["new_view_mpixels_per_s"] == max(sch["fixed_rows_mpixels_per_s"], sch["fixed_cols_mpixels_per_s"])
     assert sch["repeated_view_mpixels_per_s"] > sch["new_view_mpixels_per_s"] > 0
+    # the one number a reader takes away is labelled: `value` is the repeated view, the rate of a frame with a new camera stands
+    # beside it at the top level, and the workload says "still camera"
+    assert out["value_new_view"] == sch["new_view_mpixels_per_s"] and "STILL CAMERA" in out["config"]["workload"]
+    assert out["config"]["camera"].startswith("still") and out["config"]["frames_in_flight"] == 1
+    # the environment's part in the line: no tuning switch of the library took effect in a plain run
+    assert out["config"]["env"]["lol_gpu_tuning_switches"] is None
+    # frames in flight (never part of `value`): the same workload with 1 / 2 / 3 frames in flight, frames compared
+    fl = out["frames_in_flight"]
+    for cam in ("still_camera", "moving_camera"):
+        assert fl[cam]["2_in_flight_last_frame_equal"] is True and fl[cam]["3_in_flight_last_frame_equal"] is True
+        assert fl[cam]["1_in_flight_mpixels_per_s"] > 0
+    assert out["host_surface"]["host_surface_mpixels_per_s"]["pipelined_3"] > 0
     # `valu` describes the machine; nothing in it called a fraction exceeds 1
     v = out["valu"]
-    assert "frac" not in v and v["reference_equivalent_tops"] > 0 and 0 < v["lane_efficiency"] <= 1
+    assert "frac" not in v and v["reference_equivalent_tops"] > 0 and 0 < v["lane_efficiency_modelled"] <= 1
     assert v["issue_frac"] is None or 0 < v["issue_frac"] <= 1
 
 

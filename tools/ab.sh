@@ -1,3 +1,4 @@
+export LOL_GPU_TUNING=1   # the library honours its A/B switches only beside this (include/lol_gpu.h)
 cd ${GRAFT_REPO_ROOT:?run on the GPU box}; mkdir -p gpurun_out
 run() { echo -n "== $1: "; env $2 timeout -k 10 120 python bench.py --no-cpu-baseline --steps 15 2>&1 | grep -o '"value": [0-9.]*\|"kernel_ms_avg": [0-9.]*' | tr '\n' ' '; echo; }
 for rep in 1 2; do

@@ -1,3 +1,4 @@
+export LOL_GPU_TUNING=1   # the library honours its A/B switches only beside this (include/lol_gpu.h)
 # A/B of gamma + quantisation through the proven table (default) against the powf route (LOL_GPU_GAMMA_TABLE=0); same box, same call.
 R=${GRAFT_REPO_ROOT:?run on the GPU box}; cd $R
 for rep in 1 2; do for wl in c3 c2 c4; do for g in 1 0; do

@@ -1,3 +1,4 @@
+export LOL_GPU_TUNING=1   # the library honours its A/B switches only beside this (include/lol_gpu.h)
 # Knobs tuned in rounds 2 - 3 on rectangle waves, swept again on the dealt waves of round 4 (C3, one call): Mpixels/s, kernel ms
 R=${GRAFT_REPO_ROOT:?run on the GPU box}; cd $R
 run() { v=$(env "$@" LOL_GPU_CACHE_DIR= LOL_BENCH_STARTUP=0 LOL_BENCH_SCHEDULING=0 LOL_BENCH_HOST_SURFACE=0 python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; b=json.loads(sys.stdin.read()); print(b['value'], b['roofline']['kernel_ms_avg'])"); echo "$* : $v"; }

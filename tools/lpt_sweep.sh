@@ -1,3 +1,4 @@
+export LOL_GPU_TUNING=1   # the library honours its A/B switches only beside this (include/lol_gpu.h)
 # sweep of the longest-tiles-first knobs on one box (re-sort period, base order): bash tools/lpt_sweep.sh
 R=${GRAFT_REPO_ROOT:?run on the GPU box}; cd $R
 for base in rows cols; do for per in 1 2 4 8 32; do

@@ -1,3 +1,4 @@
+export LOL_GPU_TUNING=1   # the library honours its A/B switches only beside this (include/lol_gpu.h)
 # the region whose pixels are dealt to waves by cost: sweep of its shape on one box.  bash tools/region_sweep.sh
 R=${GRAFT_REPO_ROOT:?run on the GPU box}; cd $R
 for reg in 16x4 32x8 64x8 32x16 64x16 128x8 64x32 128x16 128x32 256x16 64x64; do

@@ -1,3 +1,4 @@
+export LOL_GPU_TUNING=1   # the library honours its A/B switches only beside this (include/lol_gpu.h)
 # hipRTC option sweep for the specialised kernel (C3 and C2), one process per case (an LLVM that does not know an -mllvm option ends
 # the process): usage on the GPU box: bash tools/rtc_flag_sweep.sh   → one line per case: flags | C3 Mpixels/s | C2 Mpixels/s
 R=${GRAFT_REPO_ROOT:?run on the GPU box}; cd $R

@@ -1,3 +1,4 @@
+export LOL_GPU_TUNING=1   # the library honours its A/B switches only beside this (include/lol_gpu.h)
 # Pixel footprint of a wave of the specialised kernel (LOL_GPU_WAVE_SHAPE=WxHxWAVES) over the BASELINE workloads, one box:
 # usage on the GPU box: bash tools/wave_shape_ab.sh   → one line per shape: C2 C3 C4 orbit Mpixels/s
 R=${GRAFT_REPO_ROOT:?run on the GPU box}; cd $R
