@@ -16,7 +16,7 @@ XRGB8888) rendered from the scene already resident on the device, into a device 
           others' (loltracer_amd.multi.Partition; LOL_BENCH_ROOT_SHARE = auto | equal | BAND,ROOT_BAND: `auto`
           times a few frames of each candidate split during set-up and keeps the fastest).
   orbit   256-frame camera orbit of scene4 at 3840x2160, frames striped over ranks, no collective.  A rank's frames are
-          independent, so it keeps LOL_BENCH_FRAMES_IN_FLIGHT of them (default 3) in flight on the library's own streams
+          independent, so it keeps LOL_BENCH_FRAMES_IN_FLIGHT of them (default 2: measured best) in flight on the library's own streams
           (lol_gpu_set_frames_in_flight): the next frame's first waves fill the tail of the last one's launch.
   --transport cabi       ONE process drives all N devices through lol_gpu_multi_* (the in-process path the
                          reference's C host calls: band partition + RCCL send/recv group + assembly kernel).
@@ -766,7 +766,7 @@ def main():
     # The orbit's frames are independent (BASELINE.json config 5: "frames striped", no per-frame collective): a rank keeps
     # several in flight on the library's own streams (lol_gpu_set_frames_in_flight), each into a destination of its own.  Every
     # other workload keeps the reference's loop — one frame after the other on one stream (main.c:189-194).
-    fif = max(1, min(4, int(os.environ.get("LOL_BENCH_FRAMES_IN_FLIGHT", "3")))) if orbit else 1
+    fif = max(1, min(4, int(os.environ.get("LOL_BENCH_FRAMES_IN_FLIGHT", "2")))) if orbit else 1
     if fif > 1:
         r.set_frames_in_flight(fif)
     ring = [torch.zeros((h, w), dtype=torch.int32, device=dev) for _ in range(fif)] if not piped else None

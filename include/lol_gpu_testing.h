@@ -25,6 +25,11 @@ int lol_gpu_multi_testing_root_stride(lol_gpu_multi* m, int stride);
  * device (which otherwise copies inline): the code every real multi-GPU host runs, reachable on a one-GPU box. */
 int lol_gpu_multi_testing_force_copier_threads(lol_gpu_multi* m, int enable);
 
+/* The check the scene compiler applies to every code object before it may be launched (lol_gpu.hip,
+ * has_return_clobbering_branch): 1 when the bytes hold a branch relaxed through s[30:31] — s_getpc_b64 s[30:31] ...
+ * s_setpc_b64 s[30:31], LLVM's long-branch register bug: a function that never returns — 0 when not.  No device needed. */
+int lol_gpu_testing_has_return_clobbering_branch(const void* code, size_t n_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -102,11 +102,14 @@ struct OwnedProgram {
 	std::vector<lol_light> lights;
 	std::vector<lol_material> materials;
 	std::vector<uint32_t> root_material;
+	/* all or nothing: the copies are made on the side (any of them may throw std::bad_alloc) and swapped in together, so a
+	 * failed assign leaves the old program — tables AND counts — as it was */
 	void assign(const lol_program& src) {
-		ops.assign(src.ops, src.ops + src.n_ops);
-		lights.assign(src.lights, src.lights + src.n_lights);
-		materials.assign(src.materials, src.materials + src.n_materials);
-		root_material.assign(src.root_material, src.root_material + src.n_roots);
+		std::vector<lol_op> o(src.ops, src.ops + src.n_ops);
+		std::vector<lol_light> l(src.lights, src.lights + src.n_lights);
+		std::vector<lol_material> m(src.materials, src.materials + src.n_materials);
+		std::vector<uint32_t> r(src.root_material, src.root_material + src.n_roots);
+		ops.swap(o); lights.swap(l); materials.swap(m); root_material.swap(r);      /* (noexcept) */
 		p = src;
 		p.ops = ops.data(); p.lights = lights.data(); p.materials = materials.data(); p.root_material = root_material.data();
 	}
@@ -145,6 +148,10 @@ struct lol_gpu {
 	hipStream_t  pipe_stream[PIPE_SLOTS] = { nullptr, nullptr, nullptr, nullptr };   /* the stream the slot's kernel was queued on */
 	int          pipe_w[PIPE_SLOTS] = { 0, 0, 0, 0 }, pipe_h[PIPE_SLOTS] = { 0, 0, 0, 0 };
 	unsigned     pipe_begun = 0, pipe_ended = 0;
+	unsigned     pipe_rr = 0;                    /* rotation of the kernels' streams: advanced by every frame whose view is new */
+	hipStream_t  pipe_last_stream = nullptr;     /* ... a frame under the view of the frame before it follows that frame on its stream */
+	lol_frame_camera pipe_last_cam{};
+	int          pipe_last_geom[3] = { 0, 0, 0 };
 	int          want_spec = 1;
 	hipModule_t  spec_module = nullptr;
 	hipFunction_t spec_fn = nullptr;
@@ -1381,17 +1388,37 @@ void disk_cache_store(const std::string& key, const std::vector<char>& code) {
 	if (fclose(f) != 0 || !ok || rename(t.c_str(), path.c_str()) != 0) (void)remove(t.c_str());
 }
 
-/* The long-branch bug described in compile_spec, as it looks in the code: s_getpc_b64 s[30:31]; s_add_u32 s30, s30, <lit>;
- * s_addc_u32 s31, s31, <lit>; s_setpc_b64 s[30:31] — a relaxed branch that goes through the register pair a function returns
- * through.  (A call is s_getpc into some pair + s_swappc_b64 s[30:31], <pair>; a return is a bare s_setpc_b64 s[30:31].) */
-bool has_return_clobbering_branch(const std::vector<char>& code) {
-	const size_t n = code.size() / 4;
-	const uint32_t* w = reinterpret_cast<const uint32_t*>(code.data());
-	if (reinterpret_cast<uintptr_t>(code.data()) % 4) return false;      /* (std::vector<char> storage is suitably aligned) */
-	for (size_t i = 0; i + 6 <= n; i++)
-		if (w[i] == 0xBE9E1C00u && w[i + 1] == 0x801EFF1Eu && w[i + 3] == 0x821FFF1Fu && w[i + 5] == 0xBE801D1Eu) return true;
+/* The long-branch bug described in compile_spec, as it looks in the code: a relaxed branch that goes through s[30:31], the
+ * register pair a function RETURNS through —
+ *     s_getpc_b64 s[30:31];  s_add_u32 s30, s30, <lit>;  s_addc_u32 s31, s31, <lit>;  s_setpc_b64 s[30:31]
+ * (a call is s_getpc into some OTHER pair + s_swappc_b64 s[30:31], <pair>; a return is a bare s_setpc_b64 s[30:31] with no
+ * s_getpc of that pair before it).  Recognised by instruction fields, not by four literal words (round-4 review): SOP1
+ * s_getpc_b64 with SDST = s30, followed within a few instructions by SOP1 s_setpc_b64 with SSRC0 = s30 and no s_swappc_b64
+ * in between — whatever arithmetic (add / sub, literal in either source position, a scavenged temporary, s_nop padding)
+ * sits between the two.  The words are read with memcpy at EVERY byte offset: no assumption about where the buffer or the
+ * text section inside the ELF begins, and nothing that can make the check pass by default.  A false alarm — constants that
+ * happen to spell the two instructions eight dwords apart — only costs the scene its own kernel (the interpreter renders). */
+bool has_return_clobbering_branch(const void* data, size_t n_bytes) {
+	constexpr uint32_t SOP1 = 0xBE800000u, SOP1_MASK = 0xFF800000u;         /* [31:23] = 0b1_0111_1101 */
+	constexpr uint32_t OP_GETPC = 28, OP_SETPC = 29, OP_SWAPPC = 30;        /* SOP1 opcodes (GFX9 / gfx950 encoding), bits [15:8] */
+	constexpr uint32_t RETURN_PAIR = 30;                                    /* s[30:31] */
+	constexpr size_t WINDOW = 12;                                           /* dwords after the s_getpc in which the s_setpc counts */
+	const unsigned char* b = static_cast<const unsigned char*>(data);
+	auto word = [&](size_t at) { uint32_t w; memcpy(&w, b + at, 4); return w; };
+	for (size_t at = 0; at + 8 <= n_bytes; at++) {
+		const uint32_t w = word(at);
+		if ((w & SOP1_MASK) != SOP1 || ((w >> 8) & 0xFF) != OP_GETPC || ((w >> 16) & 0x7F) != RETURN_PAIR) continue;
+		for (size_t k = 1; k <= WINDOW && at + 4 * k + 4 <= n_bytes; k++) {
+			const uint32_t v = word(at + 4 * k);
+			if ((v & SOP1_MASK) != SOP1) continue;
+			const uint32_t op = (v >> 8) & 0xFF;
+			if (op == OP_SWAPPC) break;                                     /* a call: the pair is being written as a link register */
+			if (op == OP_SETPC && (v & 0xFF) == RETURN_PAIR) return true;
+		}
+	}
 	return false;
 }
+bool has_return_clobbering_branch(const std::vector<char>& code) { return has_return_clobbering_branch(code.data(), code.size()); }
 
 bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string& arch, std::vector<char>& code,
                   std::string& log, std::string* src_out = nullptr, const int* shape = nullptr, bool cull = true) {
@@ -1535,6 +1562,15 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
 		code.clear();
 		return false;
 	}
+	if (options_dropped && spec_out_of_line(P)) {
+		/* The retry above also dropped -amdgpu-long-branch-factor=0, the option that KEEPS the compiler from that bug, and an
+		 * out-of-line SDF is where it bites (a function beyond s_cbranch's reach).  The pattern check would be all that is left
+		 * between this code object and a launch that never ends: not enough — the interpreter renders this scene. */
+		log = "this hipRTC refused the -mllvm options (among them the workaround for LLVM's long-branch register bug) and the scene's "
+		      "SDF is out of line: code object refused";
+		code.clear();
+		return false;
+	}
 	{
 		std::lock_guard<std::mutex> lock(g_cache_mutex);
 		g_code_cache[key] = code;
@@ -1644,17 +1680,47 @@ FastPaths prove_fast_paths(lol_gpu* ctx, const lol_program& prog) {
 /* hipRTC is entered by one thread at a time, and the second context that wants the same scene finds it in the cache */
 std::mutex g_rtc_mutex;
 
+/* Runs of the scene compiler whose context is gone before they are.  A run owns everything it touches (its copy of the program,
+ * its code buffer) and hipRTC cannot be interrupted — a field of 5000 ops takes it 40 s, 16,384 ops minutes
+ * (profiles/r4_big_scene_probe.jsonl) — so lol_gpu_destroy does not wait for one (round 4 did: a quitting host hung for as long):
+ * the run is parked here, joined by whichever later call of the library finds it finished, and at the latest when the library
+ * is unloaded (the thread must not outlive the code it runs). */
+struct Orphans {
+	std::mutex mu;
+	std::vector<SpecJob*> jobs;
+	void adopt(SpecJob* j) { std::lock_guard<std::mutex> lock(mu); jobs.push_back(j); }
+	void reap(bool all) {
+		std::vector<SpecJob*> take;
+		{
+			std::lock_guard<std::mutex> lock(mu);
+			for (size_t i = 0; i < jobs.size();) {
+				bool done;
+				{ std::lock_guard<std::mutex> jl(jobs[i]->mu); done = jobs[i]->done; }
+				if (done || all) { take.push_back(jobs[i]); jobs.erase(jobs.begin() + (long)i); } else i++;
+			}
+		}
+		for (SpecJob* j : take) { if (j->th.joinable()) j->th.join(); delete j; }
+	}
+	~Orphans() { reap(true); }
+} g_orphans;
+
+/* the finished compiler runs of programs this context has since replaced; `all`: every run, finished or not — those still at
+ * work are handed to g_orphans instead of being waited for */
 void reap(lol_gpu* ctx, bool all) {
 	for (size_t i = 0; i < ctx->old_jobs.size();) {
 		SpecJob* j = ctx->old_jobs[i];
 		bool done;
 		{ std::lock_guard<std::mutex> lock(j->mu); done = j->done; }
-		if (done || all) {
+		if (done) {
 			if (j->th.joinable()) j->th.join();
 			delete j;
 			ctx->old_jobs.erase(ctx->old_jobs.begin() + (long)i);
+		} else if (all) {
+			g_orphans.adopt(j);
+			ctx->old_jobs.erase(ctx->old_jobs.begin() + (long)i);
 		} else i++;
 	}
+	g_orphans.reap(false);
 }
 
 /* Start compiling the specialised kernel of ctx's (just committed) program.  The previous scene's module is gone already
@@ -1825,7 +1891,7 @@ void lol_gpu_destroy(lol_gpu* ctx) {
 		if (fs) { (void)hipStreamSynchronize(fs); (void)hipStreamDestroy(fs); }
 	}
 	if (ctx->job) { ctx->old_jobs.push_back(ctx->job); ctx->job = nullptr; }
-	reap(ctx, true);                         /* a compiler thread still running is waited for: it must not outlive the library */
+	reap(ctx, true);                         /* a compiler thread still running is parked (g_orphans), not waited for */
 	if (ctx->spec_module) (void)hipModuleUnload(ctx->spec_module);
 	for (int i = 0; i < 2; i++) {
 		if (ctx->d_tables[i]) (void)hipFree(ctx->d_tables[i]);
@@ -2379,7 +2445,18 @@ int lol_gpu_specialize_state(lol_gpu* ctx, double* compile_ms) {
 	return ctx->spec_state;
 }
 
+static int upload_program(lol_gpu* ctx, const lol_program* prog);
+
+/* No exception crosses the C boundary: programs may have 2^20 ops, and the analysis of a scene (culling plan, the interpreter's
+ * lists, the tables) allocates as it goes — a std::bad_alloc anywhere in it is an upload that failed, with the scene the
+ * context had still rendering (every step before the commit works on the side). */
 int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog) {
+	try { return upload_program(ctx, prog); }
+	catch (const std::bad_alloc&) { return fail(ctx, LOL_GPU_ERR_HIP, "out of host memory while preparing the scene"); }
+	catch (...) { return fail(ctx, LOL_GPU_ERR_HIP, "unexpected failure while preparing the scene"); }
+}
+
+static int upload_program(lol_gpu* ctx, const lol_program* prog) {
 	if (!ctx || !prog) return LOL_GPU_ERR_ARG;
 	/* sanity caps (lol_scene.h): counts beyond them are corruption, not scenes; every table a count speaks of must be there */
 	if (prog->n_ops > LOL_MAX_OPS || prog->n_lights > LOL_MAX_LIGHTS || prog->n_materials > LOL_MAX_MATERIALS ||
@@ -2460,27 +2537,30 @@ int lol_gpu_upload_program(lol_gpu* ctx, const lol_program* prog) {
 	if (e == hipSuccess && !mops.empty())
 		e = hipMemcpy(ctx->d_mops[next], mops.data(), mops.size() * 4, hipMemcpyHostToDevice);
 	if (e != hipSuccess) return fail(ctx, LOL_GPU_ERR_HIP, "upload of the scene tables", e);
-	try { ctx->h_own.assign(*prog); }                 /* the last fallible step (host memory); the old scene is intact until here */
-	catch (...) { return fail(ctx, LOL_GPU_ERR_HIP, "out of host memory"); }
-	/* commit */
+	const int interp_sqrt_kind = fast.sqrt_kind == 3 ? 3 : 0;
+	std::string interp_key;
+	{
+		/* what render_interp executes = this build's code (lol_kernel.h AND this file: record layout, flags) + the lists */
+		std::string id = std::string(LOL_BUILD_ID) + "|" + fnv_hex(mops.data(), mops.size() * 4) + "|" + std::to_string(interp_sqrt_kind) +
+		                 (fast.fdiv_ok ? "|fdiv" : "") + (fast.gamma_ok ? "|gamma" : "");
+		interp_key = fnv_hex(id.data(), id.size());
+	}
+	ctx->h_own.assign(*prog);                         /* the last fallible step (host memory; all or nothing itself): the old scene is intact until here */
+	/* commit (nothing below allocates on the way to the new scene being in place) */
 	ctx->generation++;
 	ctx->cur = next;
 	ctx->have_prog = true;
 	ctx->n_mops = n_mops;
 	ctx->finite_scene = shadow_settle_ok(*prog);
-	ctx->interp_sqrt_kind = fast.sqrt_kind == 3 ? 3 : 0;
+	ctx->interp_sqrt_kind = interp_sqrt_kind;
 	ctx->shadow_fdiv = fast.fdiv_ok;
 	ctx->gamma_table = fast.gamma_ok;
-	{
-		/* what render_interp executes = this build's code (lol_kernel.h AND this file: record layout, flags) + the lists */
-		std::string id = std::string(LOL_BUILD_ID) + "|" + fnv_hex(mops.data(), mops.size() * 4) + "|" + std::to_string(ctx->interp_sqrt_kind) +
-		                 (ctx->shadow_fdiv ? "|fdiv" : "") + (ctx->gamma_table ? "|gamma" : "");
-		ctx->interp_key = fnv_hex(id.data(), id.size());
-	}
+	ctx->interp_key.swap(interp_key);
 	resolve_skips(ctx);
 	/* the scene compiler starts on its own thread; the new scene renders on the interpreter until its kernel is there
 	 * (a failed specialisation is not an error either: the interpreter goes on rendering) */
-	start_specialise(ctx, fast);
+	try { start_specialise(ctx, fast); }
+	catch (...) { ctx->spec_state = 0; }              /* (no memory for a compiler run: the interpreter renders the scene) */
 	return LOL_GPU_OK;
 }
 
@@ -2697,7 +2777,15 @@ int lol_gpu_render_host_begin(lol_gpu* ctx, const lol_frame_camera* cam, int w, 
 		if (st != LOL_GPU_OK) return st;
 	}
 	const int slot = (int)(ctx->pipe_begun % lol_gpu::PIPE_SLOTS);
-	hipStream_t ks = ctx->frame_streams[ctx->pipe_begun % depth];
+	/* Which stream.  A frame whose view is NEW goes to the next stream of the rotation: it runs in a fixed tile order, its launch
+	 * has a long tail, and the frame after it fills that tail (the orbit through the C host: 9170 -> 11,000 Mpixels/s).  A frame
+	 * under the SAME view as the frame before it follows that frame on its stream: such frames are scheduled by their
+	 * predecessor's costs and have no tail to fill, and two of them side by side finish together — after which nothing is
+	 * queued while the host waits in _end() for the first one's copy (measured: 1.03 ms per frame on two streams against 0.83
+	 * on one, profiles/r5_frames_in_flight.md). */
+	const int geom[3] = { w, h, max_steps };
+	const bool same_view = ctx->pipe_last_stream && memcmp(geom, ctx->pipe_last_geom, sizeof geom) == 0 && memcmp(cam, &ctx->pipe_last_cam, sizeof *cam) == 0;
+	hipStream_t ks = same_view ? ctx->pipe_last_stream : ctx->frame_streams[ctx->pipe_rr++ % depth];
 	const size_t need = (size_t)w * h * 4;
 	if (need > ctx->pipe_bytes[slot]) {
 		/* the surface grew (main.c:182-187).  This slot's last frame was ended PIPE_SLOTS calls ago; its copy may still run, and
@@ -2719,6 +2807,9 @@ int lol_gpu_render_host_begin(lol_gpu* ctx, const lol_frame_camera* cam, int w, 
 	if (st != LOL_GPU_OK) return st;
 	LOL_HIP(ctx, hipEventRecord(ctx->pipe_rendered[slot], ks));
 	ctx->pipe_stream[slot] = ks;
+	ctx->pipe_last_stream = ks;
+	ctx->pipe_last_cam = *cam;
+	memcpy(ctx->pipe_last_geom, geom, sizeof geom);
 	ctx->pipe_w[slot] = w; ctx->pipe_h[slot] = h;
 	ctx->pipe_begun++;
 	return LOL_GPU_OK;
@@ -2834,6 +2925,11 @@ const char* lol_gpu_kernel_key(const lol_gpu* ctx) {
 }
 
 int lol_gpu_abi_version(void) { return LOL_GPU_ABI_VERSION; }
+
+int lol_gpu_testing_has_return_clobbering_branch(const void* code, size_t n_bytes) {
+	if (!code) return LOL_GPU_ERR_ARG;
+	return has_return_clobbering_branch(code, n_bytes) ? 1 : 0;
+}
 
 int lol_gpu_testing_fail_uploads(lol_gpu* ctx, int n) {
 	if (!ctx || n < 0) return LOL_GPU_ERR_ARG;

@@ -250,6 +250,8 @@ def gpu_lib() -> C.CDLL:
         # include/lol_gpu_testing.h
         lib.lol_gpu_testing_fail_uploads.argtypes = [vp, C.c_int]
         lib.lol_gpu_testing_fail_uploads.restype = C.c_int
+        lib.lol_gpu_testing_has_return_clobbering_branch.argtypes = [C.c_char_p, C.c_size_t]
+        lib.lol_gpu_testing_has_return_clobbering_branch.restype = C.c_int
         lib.lol_gpu_multi_testing_root_stride.argtypes = [vp, C.c_int]
         lib.lol_gpu_multi_testing_root_stride.restype = C.c_int
         lib.lol_gpu_multi_testing_force_copier_threads.argtypes = [vp, C.c_int]
@@ -258,7 +260,7 @@ def gpu_lib() -> C.CDLL:
     return _lib
 
 
-TESTING_SYMBOLS = ["lol_gpu_testing_fail_uploads", "lol_gpu_multi_testing_root_stride",
+TESTING_SYMBOLS = ["lol_gpu_testing_fail_uploads", "lol_gpu_testing_has_return_clobbering_branch", "lol_gpu_multi_testing_root_stride",
                    "lol_gpu_multi_testing_force_copier_threads"]          # include/lol_gpu_testing.h
 
 EXPORTED_SYMBOLS = [

@@ -227,3 +227,47 @@ def test_out_of_line_sdf_beyond_the_short_branch_range_is_compiled_correctly_or_
     with pytest.raises(gpu.GpuError) as e:
         gpu.compile_offline(sc.flatten(), str(tmp_path / "bad"), assume_fast=True)
     assert "return address" in str(e.value)
+    # the checker itself on both code objects: clean with the workaround ...
+    check = gpu.gpu_lib().lol_gpu_testing_has_return_clobbering_branch
+    assert check(code, len(code)) == 0
+
+
+def test_the_long_branch_tripwire_reads_instruction_fields_at_any_offset():
+    """Round-4 review: the trip-wire matched four literal words and passed by default on a misaligned buffer.  It now recognises
+    `s_getpc_b64 s[30:31] ... s_setpc_b64 s[30:31]` by the SOP1 fields — whatever arithmetic sits in between — at every byte
+    offset of the buffer, and tells a relaxed branch from a call (s_swappc_b64) and from a plain return."""
+    import struct
+    check = gpu.gpu_lib().lol_gpu_testing_has_return_clobbering_branch
+
+    def sop1(op, sdst, ssrc0):
+        return 0xBE800000 | sdst << 16 | op << 8 | ssrc0
+
+    def sop2(op, sdst, ssrc1, ssrc0):
+        return 0x80000000 | op << 23 | sdst << 16 | ssrc1 << 8 | ssrc0
+
+    GETPC, SETPC, SWAPPC, LIT = 28, 29, 30, 0xFF
+    S_ADD, S_SUB, S_ADDC, S_SUBB = 0, 1, 4, 5
+    assert sop1(GETPC, 30, 0) == 0xBE9E1C00 and sop1(SETPC, 0, 30) == 0xBE801D1E and sop2(S_ADD, 30, LIT, 30) == 0x801EFF1E      # (round 4's literals)
+    nop = 0xBF800000
+    pad = [nop] * 5
+
+    def has(words, shift=0):
+        buf = b"\x7f" * shift + struct.pack("<%dI" % len(words), *words)
+        return check(buf, len(buf))
+
+    # the sequence LLVM emits, literal in the second source position (what round 4 matched) ...
+    relaxed = [sop1(GETPC, 30, 0), sop2(S_ADD, 30, LIT, 30), 0x00012344, sop2(S_ADDC, 31, LIT, 31), 0, sop1(SETPC, 0, 30)]
+    for shift in (0, 1, 2, 3, 4, 7, 64, 1001):                       # ... found wherever the buffer and the text begin
+        assert has(pad + relaxed + pad, shift) == 1, shift
+    # ... with the literal in the FIRST source position, as a backward branch (sub / subb), with padding in between
+    assert has(pad + [sop1(GETPC, 30, 0), sop2(S_ADD, 30, 30, LIT), 0x40, sop2(S_ADDC, 31, 31, LIT), 0, sop1(SETPC, 0, 30)] + pad) == 1
+    assert has(pad + [sop1(GETPC, 30, 0), sop2(S_SUB, 30, LIT, 30), 0x99990, sop2(S_SUBB, 31, LIT, 31), 0, nop, nop, sop1(SETPC, 0, 30)] + pad) == 1
+    # not the bug: a call through another pair, a plain return, a branch relaxed through a scavenged pair, the two far apart
+    call = [sop1(GETPC, 4, 0), sop2(S_ADD, 4, LIT, 4), 0x1000, sop2(S_ADDC, 5, LIT, 5), 0, sop1(SWAPPC, 30, 4)]
+    assert has(pad + call + pad + [sop1(SETPC, 0, 30)]) == 0
+    assert has(pad + [sop1(SETPC, 0, 30)] + pad) == 0
+    assert has(pad + [sop1(GETPC, 34, 0), sop2(S_ADD, 34, LIT, 34), 0x1000, sop2(S_ADDC, 35, LIT, 35), 0, sop1(SETPC, 0, 34)] + pad) == 0
+    assert has([sop1(GETPC, 30, 0)] + [nop] * 40 + [sop1(SETPC, 0, 30)]) == 0
+    # a call that reuses s[30:31] for the target (getpc, swappc before any setpc) is a call
+    assert has(pad + [sop1(GETPC, 30, 0), sop2(S_ADD, 30, LIT, 30), 0x10, sop2(S_ADDC, 31, LIT, 31), 0, sop1(SWAPPC, 30, 30), sop1(SETPC, 0, 30)] + pad) == 0
+    assert has([]) == 0 and has([sop1(GETPC, 30, 0)]) == 0

@@ -50,8 +50,8 @@ def test_orbit_over_two_ranks_checks_frames_against_rank_0():
     assert out["scaling"] == "weak" and out["steps"] == 256 and out["n_ranks_seen"] == 2
     assert out["frames_equal_to_rank0_render"] is True and "[check] 4 orbit frames of 2 ranks" in err
     assert [r["frames"] for r in out["per_rank"]] == [128, 128] and all(r["rows"] == 2160 for r in out["per_rank"])
-    # the orbit's frames are independent: three in flight per rank, every one a new camera
-    assert out["config"]["frames_in_flight"] == 3 and out["value_new_view"] == out["value"] and out["config"]["camera"].startswith("moving")
+    # the orbit's frames are independent: two in flight per rank, every one a new camera
+    assert out["config"]["frames_in_flight"] == 2 and out["value_new_view"] == out["value"] and out["config"]["camera"].startswith("moving")
 
 
 def test_default_line_carries_roofline_cpu_baseline_and_both_kernels():

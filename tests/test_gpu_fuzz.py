@@ -134,6 +134,36 @@ def test_orbit_frames_match_the_oracle(torch_cuda, scenes):
     r.close()
 
 
+def test_orbit_frames_at_full_size_match_the_oracle_on_sampled_rows(torch_cuda, scenes):
+    """BASELINE config 5 at ITS size (3840x2160; round-4 review: the full-size orbit was only ever compared HIP against HIP): three
+    orbit cameras, five rows each against the oracle — pixels, float colours, ids, distances, step counts — exactly as
+    test_full_size_sampled_rows_and_partition does for config 3.  And the same frames with two of them in flight
+    (lol_gpu_set_frames_in_flight, what bench.py's orbit workload does) are the same frames."""
+    import bench
+    import torch
+    sc = scenes["scene4"]
+    w, h = 3840, 2160
+    r = gpu.Renderer(0)
+    frames = {}
+    for i in (37, 128, 211):
+        cam = bench.orbit_camera(i, 256)
+        g = gpu_render(torch_cuda, r, sc, w, h, camera=cam)
+        for y in (0, 540, 1079, 1620, 2159):
+            sub = {k: (v[y:y + 1] if isinstance(v, np.ndarray) else v) for k, v in g.items()}
+            check_against_oracle(sub, sc, w, h, y0=y, y1=y + 1, camera=cam)
+        frames[i] = g["xrgb"]
+    r.set_frames_in_flight(2)
+    ring = [torch.zeros((h, w), dtype=torch.int32, device="cuda:0") for _ in range(2)]
+    ids = (37, 128, 211, 37)
+    for k in range(0, len(ids), 2):
+        for j in (0, 1):
+            r.render_into(ring[j].data_ptr(), w, h, camera=bench.orbit_camera(ids[k + j], 256))
+        r.sync()
+        for j in (0, 1):
+            assert np.array_equal(ring[j].cpu().numpy().view(np.uint32), frames[ids[k + j]]), (k, j)
+    r.close()
+
+
 def chain_scene(n_unions, seed=3):
     """One object: a right-leaning chain of n smooth unions of spheres (2n + 2 ops), over a plane, lit and in view."""
     rng = np.random.default_rng(seed)
