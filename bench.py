@@ -422,6 +422,7 @@ def frames_in_flight_rates(r, sc, cfg, frames: int = 48) -> dict:
     still = [sc.frame_camera(w, h)]
     out = {"frames": frames}
     ring = [torch.zeros((h, w), dtype=torch.int32, device="cuda") for _ in range(4)]
+    torch.cuda.synchronize()                          # (the fills run on torch's stream, the frames on the library's own)
     ref = {}
     for label, cams in (("still_camera", still), ("moving_camera", moving)):
         if cams is None:

@@ -1216,7 +1216,11 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
  * that compile time and code size (six copies of the SDF) grow linearly while the call overhead stays fixed.
  * LOL_GPU_SPEC_INLINE_MAX overrides. */
 constexpr uint32_t LOL_SPEC_INLINE_MAX_OPS = 256;
-constexpr uint32_t LOL_SPEC_MAX_OPS = 16384;           /* specialise(): larger scenes stay on the interpreter */
+/* specialise(): larger scenes stay on the interpreter.  The scene compiler cannot be interrupted, lol_gpu_destroy has to wait
+ * for it, and a second upload's run queues behind it — so what it takes on is bounded by what was MEASURED as tolerable
+ * (profiles/r4_big_scene_probe.jsonl, fields of N objects on the GPU box: 5.3 s at 1320 ops, 14.6 s at 2640, 40.7 s at 5060,
+ * about n^1.5: a minute at 6500, four at 16,384 — round 4's cap).  LOL_GPU_SPEC_MAX_OPS (a tuning switch) moves it. */
+constexpr uint32_t LOL_SPEC_MAX_OPS = 6144;
 
 bool spec_out_of_line(const lol_program& P) {
 	uint32_t limit = LOL_SPEC_INLINE_MAX_OPS;
@@ -1680,47 +1684,21 @@ FastPaths prove_fast_paths(lol_gpu* ctx, const lol_program& prog) {
 /* hipRTC is entered by one thread at a time, and the second context that wants the same scene finds it in the cache */
 std::mutex g_rtc_mutex;
 
-/* Runs of the scene compiler whose context is gone before they are.  A run owns everything it touches (its copy of the program,
- * its code buffer) and hipRTC cannot be interrupted — a field of 5000 ops takes it 40 s, 16,384 ops minutes
- * (profiles/r4_big_scene_probe.jsonl) — so lol_gpu_destroy does not wait for one (round 4 did: a quitting host hung for as long):
- * the run is parked here, joined by whichever later call of the library finds it finished, and at the latest when the library
- * is unloaded (the thread must not outlive the code it runs). */
-struct Orphans {
-	std::mutex mu;
-	std::vector<SpecJob*> jobs;
-	void adopt(SpecJob* j) { std::lock_guard<std::mutex> lock(mu); jobs.push_back(j); }
-	void reap(bool all) {
-		std::vector<SpecJob*> take;
-		{
-			std::lock_guard<std::mutex> lock(mu);
-			for (size_t i = 0; i < jobs.size();) {
-				bool done;
-				{ std::lock_guard<std::mutex> jl(jobs[i]->mu); done = jobs[i]->done; }
-				if (done || all) { take.push_back(jobs[i]); jobs.erase(jobs.begin() + (long)i); } else i++;
-			}
-		}
-		for (SpecJob* j : take) { if (j->th.joinable()) j->th.join(); delete j; }
-	}
-	~Orphans() { reap(true); }
-} g_orphans;
-
-/* the finished compiler runs of programs this context has since replaced; `all`: every run, finished or not — those still at
- * work are handed to g_orphans instead of being waited for */
+/* the compiler runs of programs this context has since replaced: the finished ones are joined; `all` (lol_gpu_destroy): every
+ * one is waited for.  A run cannot be left behind: hipRTC cannot be interrupted, and a thread still inside it when the process
+ * exits crashes in the compiler's own teardown (comgr is loaded on first use, so its statics go BEFORE this library's — tried in
+ * round 5 with a process-lifetime reaper: the C host segfaulted at exit).  What bounds the wait instead is LOL_SPEC_MAX_OPS. */
 void reap(lol_gpu* ctx, bool all) {
 	for (size_t i = 0; i < ctx->old_jobs.size();) {
 		SpecJob* j = ctx->old_jobs[i];
 		bool done;
 		{ std::lock_guard<std::mutex> lock(j->mu); done = j->done; }
-		if (done) {
+		if (done || all) {
 			if (j->th.joinable()) j->th.join();
 			delete j;
 			ctx->old_jobs.erase(ctx->old_jobs.begin() + (long)i);
-		} else if (all) {
-			g_orphans.adopt(j);
-			ctx->old_jobs.erase(ctx->old_jobs.begin() + (long)i);
 		} else i++;
 	}
-	g_orphans.reap(false);
 }
 
 /* Start compiling the specialised kernel of ctx's (just committed) program.  The previous scene's module is gone already
@@ -1891,7 +1869,7 @@ void lol_gpu_destroy(lol_gpu* ctx) {
 		if (fs) { (void)hipStreamSynchronize(fs); (void)hipStreamDestroy(fs); }
 	}
 	if (ctx->job) { ctx->old_jobs.push_back(ctx->job); ctx->job = nullptr; }
-	reap(ctx, true);                         /* a compiler thread still running is parked (g_orphans), not waited for */
+	reap(ctx, true);                         /* a compiler thread still running is waited for: it must not outlive the library */
 	if (ctx->spec_module) (void)hipModuleUnload(ctx->spec_module);
 	for (int i = 0; i < 2; i++) {
 		if (ctx->d_tables[i]) (void)hipFree(ctx->d_tables[i]);

@@ -41,6 +41,7 @@ def sequential_frames(torch, sc, w, h, cams, specialize=1):
     out = []
     for cam in cams:
         f = torch.zeros((h, w), dtype=torch.int32, device="cuda:0")
+        torch.cuda.synchronize()                          # (the fill runs on torch's stream, the frame on the library's own)
         r.render_into(f.data_ptr(), w, h, camera=cam)
         r.sync()
         out.append(f.cpu().numpy().view(np.uint32))
@@ -66,6 +67,7 @@ def test_frames_on_several_streams_equal_the_sequential_frames(torch_cuda, scene
     r.set_frames_in_flight(n_streams)
     assert r.frames_in_flight() == n_streams
     ring = [torch.full((h, w), 0x5A5A5A, dtype=torch.int32, device="cuda:0") for _ in range(n_streams)]
+    torch.cuda.synchronize()                              # (the fills run on torch's stream, the frames on the library's own)
     seen = set()
     got = []
     for k, cam in enumerate(cams):
@@ -84,6 +86,7 @@ def test_frames_on_several_streams_equal_the_sequential_frames(torch_cuda, scene
     # back to one stream: frames are sequential again and still the same
     r.set_frames_in_flight(1)
     f = torch.zeros((h, w), dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()
     for _ in range(4):
         r.render_into(f.data_ptr(), w, h, camera=orbit(60))
     r.sync()
@@ -106,6 +109,7 @@ def test_a_still_camera_is_scheduled_on_every_stream(torch_cuda, scenes):
     r.prepare(sc)
     r.set_frames_in_flight(3)
     ring = [torch.zeros((h, w), dtype=torch.int32, device="cuda:0") for _ in range(3)]
+    torch.cuda.synchronize()
     for k in range(30):
         r.render_into(ring[k % 3].data_ptr(), w, h)
     r.sync()
@@ -128,6 +132,7 @@ def test_tile_order_reset_with_table_frames_in_flight_on_another_stream(torch_cu
     a, b = torch.cuda.Stream(), torch.cuda.Stream()
     fa = [torch.zeros((h, w), dtype=torch.int32, device="cuda:0") for _ in range(12)]
     fb = [torch.zeros((h, w), dtype=torch.int32, device="cuda:0") for _ in range(12)]
+    torch.cuda.synchronize()
     for f in fa:                                          # the view repeats on A: tables, dealing, sorts
         r.render_into(f.data_ptr(), w, h, stream=a.cuda_stream)
     r.set_tile_order("lpt")                               # reset while those frames are in flight
@@ -151,6 +156,7 @@ def test_more_streams_than_table_sets(torch_cuda, scenes):
     rs.prepare(sc)
     rs.set_tile_order("rows")
     f0 = torch.zeros((h, w), dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()
     rs.render_into(f0.data_ptr(), w, h, max_steps=128)
     rs.sync()
     want = f0.cpu().numpy().view(np.uint32)
@@ -159,6 +165,7 @@ def test_more_streams_than_table_sets(torch_cuda, scenes):
     r.prepare(sc)
     streams = [torch.cuda.Stream() for _ in range(6)]
     frames = [torch.zeros((h, w), dtype=torch.int32, device="cuda:0") for _ in range(6)]
+    torch.cuda.synchronize()
     for rnd in range(6):
         for s, f in zip(streams, frames):
             r.render_into(f.data_ptr(), w, h, max_steps=128, stream=s.cuda_stream)

@@ -154,6 +154,7 @@ def test_orbit_frames_at_full_size_match_the_oracle_on_sampled_rows(torch_cuda, 
         frames[i] = g["xrgb"]
     r.set_frames_in_flight(2)
     ring = [torch.zeros((h, w), dtype=torch.int32, device="cuda:0") for _ in range(2)]
+    torch.cuda.synchronize()                              # (the fills run on torch's stream, the frames on the library's own)
     ids = (37, 128, 211, 37)
     for k in range(0, len(ids), 2):
         for j in (0, 1):
@@ -319,7 +320,7 @@ def test_scene_beyond_the_old_capacity(torch_cuda, mode, name):
     r.close()
 
 
-def test_operand_stack_deeper_than_the_slot_fields(torch_cuda):
+def test_operand_stack_deeper_than_the_slot_fields(torch_cuda, monkeypatch):
     """A balanced smooth-union tree of 4096 spheres in ONE object: operand stack 13 — one more than the interpreter's register
     stacks hold; the deep instantiation (slots in words of their own, lol_kernel.h MOP_DEEP_FROM) renders it like the oracle, and
     so does the specialised kernel, whose straight-line SDF needs no stack at all."""
@@ -337,6 +338,7 @@ def test_operand_stack_deeper_than_the_slot_fields(torch_cuda):
     sc = S.Scene.parse_string(text)
     prog = sc.flatten()
     assert prog.n_ops == 8192 and prog.max_stack == 13
+    monkeypatch.setenv("LOL_GPU_SPEC_MAX_OPS", "16384")          # (above the default cap of 6144 ops: the scene compiler takes it on when told to)
     for mode, name in ((4, "render_interp"), (0, "render_interp"), (1, "lol_render_spec")):
         r = gpu.Renderer(0, specialize=mode)
         r.prepare(sc)
