@@ -888,10 +888,6 @@ std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast, co
 	/* deep: operand stacks beyond the 4-bit slot fields — slots travel in words of their own and pops are not fused (lol_kernel.h, MOP_DEEP_FROM) */
 	const bool deep = interp_stack_class(P.max_stack) == lol::MOP_DEEP_SLOTS;
 	const bool fuse_pops = !deep && !(tuning_env("LOL_GPU_INTERP_FUSE_POPS") && tuning_env("LOL_GPU_INTERP_FUSE_POPS")[0] == '0');     /* A/B switch */
-	/* pairs of spheres under one smooth union as ONE record (lol_kernel.h, MOPB_PAIR); LOL_GPU_INTERP_PAIRS=0: two records, as before */
-	const bool fuse_pairs = !deep && !(tuning_env("LOL_GPU_INTERP_PAIRS") && tuning_env("LOL_GPU_INTERP_PAIRS")[0] == '0');
-	std::vector<size_t> mop_at;                      /* where the macro-op records are (the tests' constants records are not) */
-	std::vector<std::pair<size_t, bool>> pairs;      /* the PAIR records among them, and their operand order */
 	uint32_t min_prims = 1;
 	if (const char* e = tuning_env("LOL_GPU_INTERP_CULL_MIN_PRIMS")) min_prims = (uint32_t)std::max(1, atoi(e));
 	std::vector<CullInterval> ivs;
@@ -930,23 +926,6 @@ std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast, co
 				const uint32_t kind = o.op == LOL_OP_SPHERE ? lol::MOP_SPHERE : o.op == LOL_OP_RBOX ? lol::MOP_RBOX : lol::MOP_PLANE;
 				for (int j = 0; j < 7; j++) m[2 + j] = fbits32(o.f[j]);
 				const lol_op* nx = i + 1 < R.top ? &P.ops[i + 1] : nullptr;
-				/* sphere, sphere, smooth min of a proven k, and something after it (a pair never finishes an object: its word 1
-				 * holds the second radius, not an id): one PAIR record with this sphere's SET / PUSH */
-				const lol_op* sm = i + 2 < R.top ? &P.ops[i + 2] : nullptr;
-				if (fuse_pairs && o.op == LOL_OP_SPHERE && nx && nx->op == LOL_OP_SPHERE && sm && (sm->op == LOL_OP_SMIN || sm->op == LOL_OP_SMIN_R) &&
-				    i + 3 < R.top && fast && fast->has(sm->f[0])) {
-					m[0] = lol::mop_header(lol::MOP_SPHERE, depth == 0 ? lol::MOP_SET : lol::MOP_PUSH);
-					if (depth > 0) m[0] |= (uint32_t)(depth - 1) << lol::MOP_SLOT_SHIFT;
-					for (int j = 0; j < 3; j++) m[6 + j] = fbits32(nx->f[j]);
-					m[1] = fbits32(nx->f[3]);
-					m[9] = fbits32(sm->f[0]);
-					m[10] = fbits32(2.0f * sm->f[0]);
-					m[11] = fbits32(0.5f * (1.0f / sm->f[0]));
-					/* SMIN: sminf(this sphere, the next one); SMIN_R: the operands arrive swapped (lol_scene.h) */
-					pairs.emplace_back(out.size(), sm->op == LOL_OP_SMIN_R);
-					depth++;
-					i += 2;
-				} else
 				if (nx && (nx->op == LOL_OP_SMIN || nx->op == LOL_OP_SMIN_R) && depth >= 1) {
 					m[0] = lol::mop_header(kind, nx->op == LOL_OP_SMIN ? lol::MOP_SMIN : lol::MOP_SMIN_X);
 					smin_fields(m, *nx);
@@ -977,7 +956,6 @@ std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast, co
 			}
 			last = out.size();
 			emitted = true;
-			mop_at.push_back(last);
 			out.insert(out.end(), m, m + lol::MOP_DWORDS);
 		}
 		out[last] |= lol::MOP_TOP | lol::MOPB_TAIL | (R.id < max_id_seen ? lol::MOP_TIE : 0u);
@@ -991,9 +969,6 @@ std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast, co
 		for (size_t k : ends_at[oi + 1])                                   /* every run that ends here: how far its test jumps */
 			out[at[k] + 1] = (uint32_t)((out.size() - at[k]) / lol::MOP_DWORDS - 1);
 	}
-	/* the builder's own notes leave the finished list, and their bit positions mark the pairs (lol_kernel.h, MOPB_PAIR) */
-	for (size_t at_rec : mop_at) out[at_rec] &= ~(lol::MOP_FASTDIV | lol::MOP_NOFIXUP);
-	for (const auto& pr : pairs) out[pr.first] |= lol::MOPB_PAIR | (pr.second ? lol::MOPB_PAIR_BA : 0u);
 	return out;
 }
 

@@ -582,16 +582,6 @@ constexpr u32 MOPB_POST = 1u << 29, MOPB_POST_YA = 1u << 30;      /* YA: the pop
 constexpr u32 MOP_POST_SLOT_SHIFT = 25u;
 constexpr u32 MOPB_STACK = 1u << 31;                              /* = POST | PUSH */
 constexpr u32 MOP_NOFIXUP = 1u << 24;   /* with MOP_FASTDIV: the blend factor is also proven without v_div_fixup_f32 (smin_h_fast<false>) */
-/* (MOP_FASTDIV and MOP_NOFIXUP are notes build_mops makes for itself while it builds a list — the kernel tests the SMIN_* bits
- * derived from them — and are cleared from the finished list: their positions then say something else.)
- * A PAIR record (round 5): `smooth_union(sphere, sphere)` whose value is then SET or PUSHed — two records of the first four rounds,
- * "sphere A: SET / PUSH" and "sphere B: smooth-minned into the accumulator" — as ONE: x = sminf(sphere A, sphere B) (operand order:
- * MOPB_PAIR_BA), then the record's own SET / PUSH.  Sphere A in words 2-5 as ever, sphere B's centre in words 6-8 (a sphere
- * leaves them unused) and its radius in word 1 (a pair never finishes an object: no id there), k, 2k, .5/k in words 9-11;
- * only for a k whose blend factor is proven (the form with v_div_fixup: valid in both lists).  This kernel is bound by its
- * scalar side — fetch, header tests and loop of a record are ~25 scalar instructions around ~25 vector ones — so what pays is
- * fewer RECORDS: scene4's blob U(U(s1, s2), U(s3, U(s4, s5))) is four records instead of six. */
-constexpr u32 MOPB_PAIR = 16u, MOPB_PAIR_BA = 1u << 24;
 /* Exact object culling (lol_gpu.hip, "exact culling") in the interpreter: a record that finishes a top-level object
  * (MOP_TOP) may carry MOPB_CULL_NEXT / MOPB_CULL_CHAIN — the NEXT record is then not a macro-op but a test's constants
  * {word 0 = CULLC_* flags, word 1 = how many records after it belong to the objects the test guards, f[2..4] = C,
@@ -690,13 +680,6 @@ struct Interp {
 			float x = 0.f;
 			if (LOL_OFTEN(hdr & MOPB_SPHERE))
 				x = KIND ? sd_sphere_fast<KIND ? KIND : 1>(p, F(2), F(3), F(4), F(5), r) : sd_sphere(p, F(2), F(3), F(4), F(5));
-			if (hdr & MOPB_PAIR) {                                   /* (never with NOT_SPHERE or SMIN: build_mops) */
-				LOL_KEEP_BRANCH();
-				const float y = KIND ? sd_sphere_fast<KIND ? KIND : 1>(p, F(6), F(7), F(8), F(1), r) : sd_sphere(p, F(6), F(7), F(8), F(1));
-				const bool ba = (hdr & MOPB_PAIR_BA) != 0u;
-				const float a = ba ? y : x, b = ba ? x : y;
-				x = sminf_fastdiv<true>(a, b, F(9), F(10), F(11));
-			}
 			if (LOL_RARE(hdr & MOPB_NOT_SPHERE)) {                   /* grouped: a sphere macro-op pays one test for these */
 				LOL_KEEP_BRANCH();
 				if (hdr & MOPB_RBOX)
