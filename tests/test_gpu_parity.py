@@ -38,7 +38,8 @@ def torch_cuda():
 
 @pytest.fixture(scope="module", params=[1, 3, 0, 4], ids=["spec", "spec-plain", "interp-plain", "interp"])
 def renderer(torch_cuda, request):
-    """All kernels: hipRTC scene-specialised and the AOT LDS interpreter, each with and without the proven fast paths."""
+    """All kernels: the hipRTC scene-specialised one and the ahead-of-time interpreter (macro-op list fetched with scalar loads), each
+    with and without the proven fast paths."""
     r = gpu.Renderer(0, specialize=request.param)
     r.want_kernel = "lol_render_spec" if request.param in (1, 3) else "render_interp"
     yield r
@@ -112,7 +113,7 @@ def check_against_oracle(g, sc, w, h, max_steps=256, y0=0, y1=None, camera=None)
 
 @pytest.mark.parametrize("name,w,h", [
     ("scene", 256, 256), ("scene4", 256, 256), ("scene2", 160, 120), ("scene3", 160, 120),
-    ("scene4", 97, 61),          # ragged: neither dimension a multiple of the 32x8 tile
+    ("scene4", 97, 61),          # ragged: neither dimension a multiple of the 16x4 wave patch (nor of the 64x16 regions)
     ("scene", 33, 9), ("scene4", 1, 1), ("scene4", 5, 300),
 ])
 def test_frame_matches_oracle(torch_cuda, renderer, scenes, name, w, h):
