@@ -1,7 +1,11 @@
 """Soak: many random scenes, GPU (spec + interp) vs the CPU oracle.  python tests/tools/soak.py [n] [seed] [stress] [onek] [still]
 still: every scene is rendered five times under one camera — the first frames in a fixed order and through rectangles, the
 later ones with their pixels dealt to waves by cost and the waves handed out longest first (lol_gpu.hip) — and the LAST frame is
-what is held against the oracle (pixels, colours, ids, distances, step counts)."""
+what is held against the oracle (pixels, colours, ids, distances, step counts).
+flight (round 5): every scene is rendered seven times with TWO FRAMES IN FLIGHT on the library's own streams
+(lol_gpu_set_frames_in_flight) — scene camera, scene camera, another camera, then the scene camera four more times, so that
+new views (fixed order) and repeated views (one set of scheduling tables per stream) overlap — and the last frame of EACH stream is
+held against the oracle."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -16,7 +20,35 @@ modes = sys.argv[3:]                                    # any of: stress onek st
 stress = "stress" in modes
 onek = "onek" in modes                                  # every smooth union of a scene shares one k: the interpreter folds its pops (MOPB_POST)
 still = "still" in modes
+flight = "flight" in modes
 rng = np.random.default_rng(seed)
+
+
+def flight_render(r, sc, w, h):
+    """seven frames, two in flight; returns the last frame of each of the two streams, as gpu_render() does for one frame"""
+    dev = torch.device("cuda:0")
+    sets = []
+    for _ in range(2):
+        frame = torch.full((h, w), 0x55AA55, dtype=torch.int32, device=dev)
+        rgb = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
+        dist = torch.zeros((h, w), dtype=torch.float32, device=dev)
+        hid = torch.zeros((h, w), dtype=torch.int32, device=dev)
+        steps = torch.zeros((h, w), dtype=torch.int32, device=dev)
+        sets.append((frame, rgb, dist, hid, steps, gpu.Debug(rgb.data_ptr(), dist.data_ptr(), hid.data_ptr(), steps.data_ptr())))
+    torch.cuda.synchronize()                              # (the fills run on torch's stream, the frames on the library's own)
+    r.prepare(sc)
+    other = S.Camera()
+    other.point = S.V3(sc.c.camera.point.x + 0.37, sc.c.camera.point.y + 0.11, sc.c.camera.point.z - 0.23)
+    other.direction = sc.c.camera.direction
+    other.fov = sc.c.camera.fov
+    r.set_frames_in_flight(2)
+    for k, cam in enumerate([None, None, other, None, None, None, None]):
+        f = sets[k % 2]
+        r.render_into(f[0].data_ptr(), w, h, 256, camera=cam, debug=f[5])
+    r.sync()
+    r.set_frames_in_flight(1)
+    return [dict(xrgb=f[0].cpu().numpy().view(np.uint32), rgb=f[1].cpu().numpy(), dist=f[2].cpu().numpy(),
+                 id=f[3].cpu().numpy().view(np.uint32), steps=f[4].cpu().numpy().view(np.uint32), miss_skip=r.miss_skip_active()) for f in sets]
 
 
 def stress_scene(rng):
@@ -62,6 +94,10 @@ for i in range(n):
     w, h = int(rng.integers(17, 90)), int(rng.integers(9, 60))
     for m, r in rs.items():
         try:
+            if flight:
+                for g in flight_render(r, sc, w, h):
+                    check_against_oracle(g, sc, w, h)
+                continue
             g = gpu_render(torch, r, sc, w, h, repeat=5 if still else 1)
             check_against_oracle(g, sc, w, h)
             if still:
