@@ -232,3 +232,55 @@ def test_c_host_pipeline_depths_show_the_same_last_frame(tmp_path):
         assert p.returncode == 0 and "hip_renderer" not in p.stderr, p.stderr
         outs.append(open(out, "rb").read())
     assert all(o == outs[0] for o in outs[1:])
+
+
+def test_random_sequences_through_the_host_pipeline(torch_cuda, scenes):
+    """A host that does everything at once: frames of three sizes and five cameras (a camera often repeats: still views follow
+    their predecessor's stream, new ones move on), begun and ended in random interleavings up to the depth allowed, frames
+    discarded with their kernels still running, the number of frames in flight changed whenever nothing is pending — every
+    frame that is delivered must be the frame a sequential context renders for its size and camera, in order."""
+    sc = scenes["scene4"]
+    rng = np.random.default_rng(20261005)
+    sizes = [(200, 120), (97, 61), (320, 180)]
+    cams = [None] + [orbit(i) for i in (10, 50, 90, 130)]
+    r = gpu.Renderer(0)
+    r.prepare(sc)
+    want = {}
+    for si, (w, h) in enumerate(sizes):
+        for ci, cam in enumerate(cams):
+            surf = np.zeros((h, w), dtype=np.uint32)
+            r.render_host(surf.ctypes.data, w, h, camera=cam)
+            want[si, ci] = surf
+    depth = 2
+    queue = []                                            # (size index, camera index) of the frames begun and not yet ended
+    delivered = 0
+    ci = 0
+    for step in range(400):
+        op = rng.random()
+        if not queue and op < 0.08:
+            depth = int(rng.integers(1, 5))
+            r.set_frames_in_flight(depth)
+            depth = max(depth, 2)                         # (render_host_begin never accepts fewer than two)
+        elif queue and op < 0.12:
+            r.render_host_discard()
+            queue.clear()
+        elif len(queue) < depth and (op < 0.6 or not queue):
+            si = int(rng.integers(0, len(sizes)))
+            if rng.random() < 0.5:
+                ci = int(rng.integers(0, len(cams)))      # else: the camera of the frame before (a repeated view, if the size repeats too)
+            w, h = sizes[si]
+            r.render_host_begin(w, h, camera=cams[ci])
+            queue.append((si, ci))
+        elif queue:
+            si, cj = queue.pop(0)
+            w, h = sizes[si]
+            assert r.render_host_pending_size() == (w, h)
+            pitch = (w + int(rng.integers(0, 9))) * 4
+            surf = np.full((h, pitch // 4), 0xDEADBEEF, dtype=np.uint32)
+            r.render_host_end(surf.ctypes.data, pitch, w, h)
+            assert np.array_equal(surf[:, :w], want[si, cj]), f"step {step}: frame of size {sizes[si]}, camera {cj}"
+            assert np.all(surf[:, w:] == 0xDEADBEEF)
+            delivered += 1
+        assert r.render_host_pending() == len(queue)
+    assert delivered > 100
+    r.close()
