@@ -481,7 +481,7 @@ def launch_ranks(n: int, argv: list) -> int:
         return proc.wait()
 
 
-def host_surface_rates(r, sc, cfg, cams, frames: int = 12):
+def host_surface_rates(r, sc, cfg, cams, frames: int = 40):
     """Through the boundary the reference's host uses (naive_renderer.c:233-235: surf->pixels is HOST memory): whole
     frames into a pitched host surface, synchronously per frame (what render_thread does) in each host mode, and
     with two frames in flight (lol_gpu_render_host_begin / _end).  Wall-clock, never part of `value`."""

@@ -2166,7 +2166,8 @@ static bool lpt_table_for_frame(lol_gpu* ctx, const lol_frame_camera* cam, int w
 	if (!Tp) {
 		if (++ctx->lpt_homeless < 2) return false;
 		for (lol_gpu::TileLpt& P : ctx->lpt) if (!Tp || P.stamp < Tp->stamp) Tp = &P;
-		if (!ok(hipStreamSynchronize(Tp->home))) return false;
+		/* (a caller's stream may have been destroyed since: then whatever it still had queued is waited for with the device) */
+		if (!ok(hipStreamSynchronize(Tp->home)) && !ok(hipDeviceSynchronize())) return false;
 		Tp->launched = false;
 		Tp->key[0] = 0;                                  /* whatever it knew was another stream's schedule */
 	}

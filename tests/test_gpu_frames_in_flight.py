@@ -284,3 +284,45 @@ def test_random_sequences_through_the_host_pipeline(torch_cuda, scenes):
         assert r.render_host_pending() == len(queue)
     assert delivered > 100
     r.close()
+
+
+def test_table_sets_outlive_the_streams_they_lived_on(torch_cuda, scenes):
+    """A host may destroy a stream it rendered a repeated view on.  The scheduling tables that lived on it are taken over by the
+    next stream that needs a set — after whatever the dead stream still had queued has finished (the device is drained when
+    the stream itself can no longer be waited for) — and the frames stay the same frames."""
+    import ctypes as C
+    torch = torch_cuda
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+
+    def new_stream():
+        s = C.c_void_p()
+        assert hip.hipStreamCreate(C.byref(s)) == 0
+        return s
+
+    sc = scenes["scene4"]
+    w, h = 384, 216
+    want = sequential_frames(torch, sc, w, h, [None])[0]
+    r = gpu.Renderer(0)
+    r.prepare(sc)
+    first = [new_stream() for _ in range(4)]
+    frames = [torch.zeros((h, w), dtype=torch.int32, device="cuda:0") for _ in range(6)]
+    torch.cuda.synchronize()
+    for _ in range(5):                                    # the view repeats on four streams: all four table sets are taken
+        for s, f in zip(first, frames):
+            r.render_into(f.data_ptr(), w, h, stream=s.value)
+    for s in first:                                       # ... and the streams go away with frames still queued on them
+        assert hip.hipStreamDestroy(s) == 0
+    later = [new_stream() for _ in range(2)]
+    for _ in range(6):                                    # two new streams: homeless twice, then each takes a dead stream's set over
+        for s, f in zip(later, frames[4:]):
+            r.render_into(f.data_ptr(), w, h, stream=s.value)
+    torch.cuda.synchronize()
+    assert r.tile_order()["order"] == "lpt"               # the last frame went through a table again
+    for k, f in enumerate(frames):
+        assert np.array_equal(f.cpu().numpy().view(np.uint32), want), f"frame buffer {k}"
+    r.close()
+    for s in later:
+        hip.hipStreamDestroy(s)
