@@ -977,7 +977,8 @@ def main():
             "assembly": None if pipe is None else ("lol_gpu_assemble_parts_at (library kernel, own stream)" if assembler else "torch index_select"),
             "host_issue_us_per_frame": round(host_s / max(steps, 1) * 1e6, 1),
             "prewarm_frames": prewarm,            # untimed set-up frames before the W warm-up steps (clock ramp)
-            "parity_checker": "oracle/lol_oracle.c — the CPU restatement of naive_renderer.c (DESIGN.md §5)",
+            "parity_checker": "oracle/lol_oracle.c — the CPU restatement of naive_renderer.c, pinned to values composed from the reference's "
+                              "own compiled primitives; its loop structure is restated (naive_renderer.c needs SDL2 to build): DESIGN.md §5",
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 6),
                          "traffic": traffic, "traffic_source": traffic_source,
