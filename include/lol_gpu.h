@@ -216,7 +216,8 @@ const char* lol_gpu_kernel_key(const lol_gpu* ctx);
  * them.  They are honoured ONLY in a process that also sets LOL_GPU_TUNING=1; one that is set without it is ignored and
  * reported once on stderr; every one that took effect is listed here, in lol_gpu_specialize_log() and in bench.py's
  * record, so that a number can never silently come from a shell's leftovers.  (Not fenced: LOL_GPU_CACHE_DIR, LOL_GPU_ROCTX —
- * where code objects are kept, whether frames are marked: neither changes what is computed.) */
+ * where code objects are kept, whether frames are marked: neither changes what is computed.)  The string belongs to the library
+ * and is valid until the next call of this function. */
 const char* lol_gpu_tuning_switches(void);
 /* Frame ranges pushed to roctx so far by this process (LOL_GPU_ROCTX=1 marks every frame launch for
  * `rocprofv3 --marker-trace`, the counterpart of the reference's -j/--jitdump aid); 0 when not asked for, -1 when asked
