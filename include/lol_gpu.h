@@ -234,6 +234,12 @@ long lol_gpu_roctx_ranges(void);
 /* enable: 0 = interpreter, plain arithmetic; 1 = specialise, with the proven-exact shortcuts (default);
  * 3 = specialise without them; 4 = interpreter with them.  Takes effect at the next lol_gpu_upload_program. */
 int         lol_gpu_set_specialize(lol_gpu* ctx, int enable);
+/* The largest program (ops) the scene compiler takes on; larger scenes render on the interpreter, which reads them as data.
+ * hipRTC cannot be interrupted once it runs — lol_gpu_destroy and the next upload's compile wait for it — and takes about
+ * n^1.5: 5 s at 1300 ops, 41 s at 5000, minutes beyond 10,000 (fields of objects on the GPU box).  Default (and 0): 6144 ops,
+ * about a minute.  A host that would rather wait for the 2x faster kernel of a huge scene raises it.  Takes effect at the next
+ * lol_gpu_upload_program. */
+int         lol_gpu_set_specialize_max_ops(lol_gpu* ctx, unsigned max_ops);
 const char* lol_gpu_specialize_log(const lol_gpu* ctx);
 /* Tiered start-up (lol_gpu_upload_program): wait for the scene compiler and switch to its kernel now (returns at once when
  * nothing is being compiled).  For tests and benchmarks that want to time or inspect one particular kernel. */

@@ -153,6 +153,7 @@ struct lol_gpu {
 	lol_frame_camera pipe_last_cam{};
 	int          pipe_last_geom[3] = { 0, 0, 0 };
 	int          want_spec = 1;
+	uint32_t     spec_max_ops = 0;       /* lol_gpu_set_specialize_max_ops: 0 = LOL_SPEC_MAX_OPS */
 	hipModule_t  spec_module = nullptr;
 	hipFunction_t spec_fn = nullptr;
 	hipFunction_t spec_sdf_fn = nullptr; /* lol_sdf_spec of the same module (lol_gpu_sdf_batch) */
@@ -1718,11 +1719,11 @@ void start_specialise(lol_gpu* ctx, const FastPaths& fast) {
 	 * straight-line source (two SDF bodies of ~150 bytes per op) takes hipRTC minutes, and programs no longer have a
 	 * capacity (lol_scene.h): such a scene renders on the interpreter, which reads it as data.  Not a failure: no complaint. */
 	{
-		uint32_t limit = LOL_SPEC_MAX_OPS;
+		uint32_t limit = ctx->spec_max_ops ? ctx->spec_max_ops : LOL_SPEC_MAX_OPS;
 		if (const char* e = tuning_env("LOL_GPU_SPEC_MAX_OPS")) limit = (uint32_t)strtoul(e, nullptr, 10);
 		if (ctx->h_prog.n_ops > limit) {
 			char b[160];
-			snprintf(b, sizeof b, "%u ops: above the %u the scene compiler takes on (LOL_GPU_SPEC_MAX_OPS); rendered by the interpreter", ctx->h_prog.n_ops, limit);
+			snprintf(b, sizeof b, "%u ops: above the %u the scene compiler takes on (lol_gpu_set_specialize_max_ops / LOL_GPU_SPEC_MAX_OPS); rendered by the interpreter", ctx->h_prog.n_ops, limit);
 			ctx->spec_log = b;
 			return;
 		}
@@ -1899,6 +1900,12 @@ int lol_gpu_set_specialize(lol_gpu* ctx, int enable) {
 	/* 0 interpreter, plain | 1 specialised + proven fast paths (default) | 3 specialised, plain | 4 interpreter + fast paths */
 	ctx->want_spec = (enable == 1 || enable == 3) ? 1 : 0;
 	ctx->want_fast = (enable == 1 || enable == 4) ? 1 : 0;
+	return LOL_GPU_OK;
+}
+
+int lol_gpu_set_specialize_max_ops(lol_gpu* ctx, unsigned max_ops) {
+	if (!ctx || max_ops > LOL_MAX_OPS) return LOL_GPU_ERR_ARG;
+	ctx->spec_max_ops = max_ops;             /* takes effect at the next lol_gpu_upload_program */
 	return LOL_GPU_OK;
 }
 

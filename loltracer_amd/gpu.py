@@ -160,6 +160,8 @@ def gpu_lib() -> C.CDLL:
         lib.lol_gpu_kernel_name.restype = C.c_char_p
         lib.lol_gpu_set_specialize.argtypes = [vp, C.c_int]
         lib.lol_gpu_set_specialize.restype = C.c_int
+        lib.lol_gpu_set_specialize_max_ops.argtypes = [vp, C.c_uint]
+        lib.lol_gpu_set_specialize_max_ops.restype = C.c_int
         lib.lol_gpu_specialize_log.argtypes = [vp]
         lib.lol_gpu_specialize_log.restype = C.c_char_p
         lib.lol_gpu_specialize_wait.argtypes = [vp]
@@ -280,6 +282,7 @@ EXPORTED_SYMBOLS = [
     "lol_gpu_assemble_parts_at", "lol_gpu_split_rows", "lol_gpu_multi_set_root_band_rows",
     "lol_gpu_multi_set_pixel_format", "lol_gpu_multi_set_tile_order",
     "lol_gpu_set_frames_in_flight", "lol_gpu_frames_in_flight", "lol_gpu_next_stream", "lol_gpu_tuning_switches",
+    "lol_gpu_set_specialize_max_ops",
 ]
 
 
@@ -355,6 +358,10 @@ class Renderer:
         self._check(self._lib.lol_gpu_upload_program(self._ctx, C.byref(program)))
         if wait:
             self.specialize_wait()
+
+    def set_specialize_max_ops(self, max_ops: int):
+        """The largest program the scene compiler takes on (0 = the default, 6144 ops); takes effect at the next prepare()."""
+        self._check(self._lib.lol_gpu_set_specialize_max_ops(self._ctx, max_ops))
 
     def specialize_wait(self):
         self._check(self._lib.lol_gpu_specialize_wait(self._ctx))

@@ -320,7 +320,7 @@ def test_scene_beyond_the_old_capacity(torch_cuda, mode, name):
     r.close()
 
 
-def test_operand_stack_deeper_than_the_slot_fields(torch_cuda, monkeypatch):
+def test_operand_stack_deeper_than_the_slot_fields(torch_cuda):
     """A balanced smooth-union tree of 4096 spheres in ONE object: operand stack 13 — one more than the interpreter's register
     stacks hold; the deep instantiation (slots in words of their own, lol_kernel.h MOP_DEEP_FROM) renders it like the oracle, and
     so does the specialised kernel, whose straight-line SDF needs no stack at all."""
@@ -338,14 +338,18 @@ def test_operand_stack_deeper_than_the_slot_fields(torch_cuda, monkeypatch):
     sc = S.Scene.parse_string(text)
     prog = sc.flatten()
     assert prog.n_ops == 8192 and prog.max_stack == 13
-    monkeypatch.setenv("LOL_GPU_SPEC_MAX_OPS", "16384")          # (above the default cap of 6144 ops: the scene compiler takes it on when told to)
     for mode, name in ((4, "render_interp"), (0, "render_interp"), (1, "lol_render_spec")):
         r = gpu.Renderer(0, specialize=mode)
+        r.set_specialize_max_ops(16384)                   # (above the default cap of 6144 ops: the scene compiler takes it on when the host says so)
         r.prepare(sc)
         assert r.kernel_name() == name, r.specialize_log()
         g = gpu_render(torch_cuda, r, sc, 16, 8)
         check_against_oracle(g, sc, 16, 8)
         r.close()
+    r = gpu.Renderer(0)                                   # without: quietly on the interpreter, the reason in the log
+    r.prepare(sc)
+    assert r.kernel_name() == "render_interp" and "6144" in r.specialize_log()
+    r.close()
 
 
 def test_very_large_scenes_stay_on_the_interpreter(torch_cuda, monkeypatch):
