@@ -138,8 +138,9 @@ struct lol_gpu {
 	uint32_t*    d_frame = nullptr;      /* framebuffer for lol_gpu_render_host */
 	size_t       frame_bytes = 0;
 	/* lol_gpu_render_host_begin / _end: frames in flight, one device framebuffer each (sized per slot, so frames of
-	 * different sizes can be in flight while the host's window is being resized); slot = frame number % PIPE_SLOTS, and
-	 * the kernel of slot k runs on frame_streams[k % pipe_streams]: consecutive frames overlap */
+	 * different sizes can be in flight while the host's window is being resized); slot = frame number % PIPE_SLOTS.  The kernel
+	 * of a frame with a NEW view goes to the next of the context's frame streams, one under the view of the frame before it
+	 * follows that frame (lol_gpu_render_host_begin): consecutive frames of a moving camera overlap */
 	static constexpr int PIPE_SLOTS = 4;
 	uint32_t*    d_pipe[PIPE_SLOTS] = { nullptr, nullptr, nullptr, nullptr };
 	size_t       pipe_bytes[PIPE_SLOTS] = { 0, 0, 0, 0 };
@@ -225,7 +226,8 @@ struct lol_gpu {
 		unsigned frames = 0, sorts = 0;      /* frames launched with this key; sorts done */
 		hipStream_t home = nullptr;          /* the stream these tables live on; nullptr = the set is free */
 		bool     launched = false;           /* a frame (or a table kernel) has been queued on `home` through these tables since the
-		                                      * stream last ran dry: they may be in use whatever `key` says (lpt_retire clears it) */
+		                                      * stream last ran dry: they may be in use whatever `key` says (cleared where that stream is
+		                                      * waited for: before the tables are freed, or change hands) */
 		unsigned long long stamp = 0;        /* when the set was last used (the least recently used one makes room for a fifth stream) */
 		lol_frame_camera cam_epoch{};        /* the view the tables' costs belong to */
 	};
@@ -266,25 +268,31 @@ __attribute__((visibility("hidden"))) const char* lol_gpu_internal_tuning_env(co
 	const char* v = getenv(name);
 	if (!v) return nullptr;
 	const char* on = getenv("LOL_GPU_TUNING");
-	std::lock_guard<std::mutex> lock(g_tuning_mutex);
-	if (!(on && on[0] == '1' && !on[1])) {
-		if (std::find(g_tuning_ignored.begin(), g_tuning_ignored.end(), name) == g_tuning_ignored.end()) {
-			g_tuning_ignored.push_back(name);
-			fprintf(stderr, "lol_gpu: %s is set but LOL_GPU_TUNING=1 is not: ignored (tuning switches are for A/B runs)\n", name);
+	/* (called from entry points of the C ABI, some of which hold no try block of their own: a switch that cannot be RECORDED —
+	 * no memory for its name — is not honoured, and nothing is thrown) */
+	try {
+		std::lock_guard<std::mutex> lock(g_tuning_mutex);
+		if (!(on && on[0] == '1' && !on[1])) {
+			if (std::find(g_tuning_ignored.begin(), g_tuning_ignored.end(), name) == g_tuning_ignored.end()) {
+				g_tuning_ignored.push_back(name);
+				fprintf(stderr, "lol_gpu: %s is set but LOL_GPU_TUNING=1 is not: ignored (tuning switches are for A/B runs)\n", name);
+			}
+			return nullptr;
 		}
-		return nullptr;
-	}
-	for (auto& e : g_tuning_seen) if (e.first == name) { e.second = v; return v; }
-	g_tuning_seen.emplace_back(name, v);
-	return v;
+		for (auto& e : g_tuning_seen) if (e.first == name) { e.second = v; return v; }
+		g_tuning_seen.emplace_back(name, v);
+		return v;
+	} catch (...) { return nullptr; }
 }
 static inline const char* tuning_env(const char* name) { return lol_gpu_internal_tuning_env(name); }
 
 extern "C" const char* lol_gpu_tuning_switches(void) {
-	std::lock_guard<std::mutex> lock(g_tuning_mutex);
-	g_tuning_text.clear();
-	for (const auto& e : g_tuning_seen) { if (!g_tuning_text.empty()) g_tuning_text += ' '; g_tuning_text += e.first + "=" + e.second; }
-	return g_tuning_text.c_str();
+	try {
+		std::lock_guard<std::mutex> lock(g_tuning_mutex);
+		g_tuning_text.clear();
+		for (const auto& e : g_tuning_seen) { if (!g_tuning_text.empty()) g_tuning_text += ' '; g_tuning_text += e.first + "=" + e.second; }
+		return g_tuning_text.c_str();
+	} catch (...) { return "(out of memory)"; }
 }
 
 namespace {
@@ -2165,8 +2173,10 @@ static bool lpt_table_for_frame(lol_gpu* ctx, const lol_frame_camera* cam, int w
 	ctx->lpt_have_last = true;
 	if (!still) return false;
 	auto ok = [](hipError_t e) { if (e != hipSuccess) (void)hipGetLastError(); return e == hipSuccess; };
-	/* the set that lives on this stream; else a free one; else — once the host has stayed on the new stream for two such
-	 * frames in a row — the least recently used one, after ITS stream has run dry (a fixed order meanwhile) */
+	/* the set that lives on this stream; else a free one; else — once two such frames in a row have found no set, i.e. the host
+	 * has moved to streams without one and is not merely rotating over more streams than there are sets (then the first
+	 * LPT_SETS streams keep theirs and the others run in the fixed order: taking turns at a set would cost a stream
+	 * synchronisation per frame) — the least recently used one, after ITS stream has run dry */
 	lol_gpu::TileLpt* Tp = nullptr;
 	for (lol_gpu::TileLpt& P : ctx->lpt) if (P.home == s) Tp = &P;
 	if (!Tp) for (lol_gpu::TileLpt& P : ctx->lpt) if (!P.home && !Tp) Tp = &P;
