@@ -215,7 +215,8 @@ def read_frames(prefix, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("flags", [[], ["--pipeline"], ["--devices", "0", "--parts-per-device", "3"], ["--pipeline", "--tile-columns"]])
+@pytest.mark.parametrize("flags", [[], ["--pipeline"], ["--devices", "0", "--parts-per-device", "3"], ["--pipeline", "--tile-columns"],
+                                   ["--pipeline-depth", "3"], ["--pipeline-depth", "4"]])
 def test_c_host_resizes_between_frames(tmp_path, scenes, flags):
     """main.c:182-187 through render_thread: grow, shrink, grow again on ONE context; every surface the host sees equals
     the oracle's frame of that size (static camera, so the pipelined mode's one-frame lag shows the same picture)."""
@@ -225,7 +226,7 @@ def test_c_host_resizes_between_frames(tmp_path, scenes, flags):
     p = subprocess.run([HOST, "3", SCENE4, "--resize-script", script, "--dump-frames", prefix] + flags,
                        capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "hip_renderer" not in p.stderr, p.stderr
-    n = len(sizes) + (1 if "--pipeline" in flags else 0)
+    n = len(sizes) + (1 if "--pipeline" in flags else 0) + (int(flags[1]) - 1 if flags[:1] == ["--pipeline-depth"] else 0)
     frames = read_frames(prefix, n)
     want = {s: O.render(scenes["scene4"], s[0], s[1], threads=4)[0] for s in set(sizes)}
     for i, f in enumerate(frames):
