@@ -1030,7 +1030,14 @@ def main():
                                               "of the two fixed tile orders (`scheduling`); `value` is the repeated view")
             leg("scheduling", sched_leg)
         if world == 1 and not orbit and local is not None and os.environ.get("LOL_BENCH_FRAMES_IN_FLIGHT_LEG", "1") != "0":
-            leg("frames_in_flight", lambda: out.__setitem__("frames_in_flight", frames_in_flight_rates(r, sc, cfg)))
+            def fif_leg():
+                out["frames_in_flight"] = frames_in_flight_rates(r, sc, cfg)
+                mv = out["frames_in_flight"].get("moving_camera")
+                if mv:
+                    # the round-5 figure beside `value` (still camera, sequential) and `value_new_view` (one new frame, sequential):
+                    # a camera that moves EVERY frame, two frames in flight on the library's own streams
+                    out["value_moving_camera_2_in_flight"] = mv["2_in_flight_mpixels_per_s"]
+            leg("frames_in_flight", fif_leg)
         if world == 1 and not args.no_cpu_baseline and not orbit and local is not None:
             def cpu_leg():
                 base, ctr = cpu_baseline(sc, cfg, gpu_frame=local.cpu().numpy().view(np.uint32))

@@ -85,6 +85,7 @@ def test_default_line_carries_roofline_cpu_baseline_and_both_kernels():
     for cam in ("still_camera", "moving_camera"):
         assert fl[cam]["2_in_flight_last_frame_equal"] is True and fl[cam]["3_in_flight_last_frame_equal"] is True
         assert fl[cam]["1_in_flight_mpixels_per_s"] > 0
+    assert out["value_moving_camera_2_in_flight"] == fl["moving_camera"]["2_in_flight_mpixels_per_s"] > 0
     assert out["host_surface"]["host_surface_mpixels_per_s"]["pipelined_3"] > 0
     # `valu` describes the machine; nothing in it called a fraction exceeds 1
     v = out["valu"]
