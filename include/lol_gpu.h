@@ -244,8 +244,12 @@ const char* lol_gpu_specialize_log(const lol_gpu* ctx);
 /* Tiered start-up (lol_gpu_upload_program): wait for the scene compiler and switch to its kernel now (returns at once when
  * nothing is being compiled).  For tests and benchmarks that want to time or inspect one particular kernel. */
 int         lol_gpu_specialize_wait(lol_gpu* ctx);
-/* 0 = no scene kernel (switched off, or the scene is above LOL_GPU_SPEC_MAX_OPS), 1 = being compiled, 3 = compiled, takes over
- * at the next frame, 2 = in use, -1 = the compiler failed (the interpreter renders; reason in lol_gpu_specialize_log).
+/* 0 = no scene kernel (switched off, or the scene is above the cap of lol_gpu_set_specialize_max_ops), 1 = being compiled, 3 =
+ * compiled, takes over at the next frame, 2 = in use, -1 = the compiler failed (the interpreter renders; reason in
+ * lol_gpu_specialize_log).  Scenes of 257 ... 1024 ops get TWO kernels, one after the other (round 5): the form with the SDF as
+ * one out-of-line function, which hipRTC delivers in 0.4 - 3 s, and then the form with the SDF inlined into the three loops, 14 -
+ * 88 % faster, in 3 - 18 s: 5 = the first is in use and the second being compiled, 6 = the second is compiled and takes over
+ * at the next frame.  Same pixels from all of them; lol_gpu_specialize_wait waits for the last.
  * *compile_ms (may be NULL) = what the scene compiler's last finished run took. */
 int         lol_gpu_specialize_state(lol_gpu* ctx, double* compile_ms);
 /*

@@ -82,6 +82,8 @@ struct BigStackThread {
 	void join() { if (started) { pthread_join(t, nullptr); started = false; } }
 };
 
+namespace { struct FastPaths; }      /* (defined below, among the proofs) */
+struct OwnedProgram;
 /* One run of the scene compiler on a host thread (tiered start-up: start_specialise / finish_specialise below). */
 struct SpecJob {
 	std::mutex mu;
@@ -92,6 +94,12 @@ struct SpecJob {
 	int shape[3] = { LOL_WAVE_W, LOL_WAVE_H, LOL_WAVES_X };
 	std::chrono::steady_clock::time_point started;
 	double compile_ms = 0;
+	/* what the run compiles — its own copies: the context may take another scene meanwhile */
+	std::shared_ptr<OwnedProgram> prog;
+	std::shared_ptr<FastPaths> fast;
+	std::string arch;
+	bool cull = true;
+	int form = 0;                        /* SpecForm: by size, or the form a tier asks for */
 	BigStackThread th;
 };
 
@@ -159,6 +167,10 @@ struct lol_gpu {
 	hipFunction_t spec_fn = nullptr;
 	hipFunction_t spec_sdf_fn = nullptr; /* lol_sdf_spec of the same module (lol_gpu_sdf_batch) */
 	std::string  spec_log;
+	hipModule_t  spec_module_old = nullptr;   /* the first tier's module once the second has taken over: frames in flight may still run it, so it
+	                                           * stays loaded until the next upload (which drains the device) or the end of the context */
+	bool         second_tier_pending = false; /* when the running job's kernel is in use, the INLINED form is compiled next (start_specialise) */
+	bool         second_tier_running = false; /* `job` is that second run */
 	SpecJob*     job = nullptr;       /* the scene compiler's run for the CURRENT program, until its module is swapped in */
 	std::vector<SpecJob*> old_jobs;   /* runs for programs since replaced: joined when they have finished */
 	int          spec_state = 0;         /* 0 no specialised kernel wanted / possible, 1 compiling, 2 in use, -1 failed */
@@ -207,12 +219,14 @@ struct lol_gpu {
 		float mon_ratio[MONITOR_WINDOW] = {};
 	} tiles;
 	int          generation = 0;         /* uploads so far */
+	int          kernel_epoch = 0;       /* changes whenever the frames' kernel does: an upload (the interpreter takes over), each swap of
+	                                      * finish_specialise — what a kernel's tiles cost says nothing about another kernel's */
 	/* LOL_GPU_TILES_LPT: longest tiles first ("longest tiles first" below).  One SET of tables per stream that launches frames
 	 * of a repeated view (lpt_table_for_frame): everything about a set happens on its home stream, so frames, the costs they
 	 * write and the sorts that read them are ordered by that stream itself — and frames in flight on several streams
 	 * (lol_gpu_set_frames_in_flight, lol_gpu_render_host_begin) each keep their schedule. */
 	struct TileLpt {
-		int      key[7] = { 0, 0, 0, 0, 0, 0, 0 };   /* w, h, max_steps, band_rows, cycle_rows, offset_rows, generation * 2 + spec */
+		int      key[7] = { 0, 0, 0, 0, 0, 0, 0 };   /* w, h, max_steps, band_rows, cycle_rows, offset_rows, kernel_epoch */
 		uint32_t n_tiles = 0;
 		uint32_t* d_order[2] = { nullptr, nullptr };   /* tile_order tables: frames read [cur], a sort writes [cur ^ 1] */
 		uint32_t* d_cost = nullptr;          /* what the blocks of the last frame cost, by launch position */
@@ -1220,26 +1234,39 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
  * [SQRT_FAST_MIN, inf) (a sample within 2^-48 of a sphere centre, or an overflow) shades its pixels
  * again with the plain SDF, so the shortcut never decides a result.
  */
-/* Scenes above this many ops get their SDF as an out-of-line function (emit_sdf).  Measured on MI355X
- * (tools/large_scene_ab.py, profiles/): inlined code is 10-20 % faster up to 256 ops (1.1 s to compile); beyond
- * that compile time and code size (six copies of the SDF) grow linearly while the call overhead stays fixed.
- * LOL_GPU_SPEC_INLINE_MAX overrides. */
-constexpr uint32_t LOL_SPEC_INLINE_MAX_OPS = 256;
+/* Scenes above this many ops get their SDF as an out-of-line function (emit_sdf).  Rounds 2 - 4: 256 — the inlined form took
+ * 1.3 s (256 ops) to 15 s (1024) to compile against 0.35 - 2.2 s out of line, and render_prepare WAITED for the compiler.  It
+ * no longer does (tiered start-up: the compiler runs on its own thread, frames render on the interpreter meanwhile), so what
+ * decides now is the kernel that comes out.  Measured on MI355X in round 5 (tools/large_scene_ab.py, chains of smooth unions at
+ * 1080p, profiles/r5_large_scene_ab.jsonl; inlined / out of line / interpreter, Mpixels/s): 284 ops 311 / 165 / 185 (the
+ * out-of-line kernel was SLOWER than the interpreter it replaced), 504 ops 174 / 126 / 105, 1024 ops 80.6 / 60.1 / 43.2 — the
+ * inlined form +88 % / +38 % / +34 % for 1.4 / 2.6 / 6.6 s of background compile (0.4 / 0.6 / 1.4 out of line) — and at 2048 ops
+ * the other way round: 13.7 / 15.6 (960x540; 19 s against 3.8 s: six copies of a 300 KB function no longer pay).
+ * LOL_GPU_SPEC_INLINE_MAX (a tuning switch) overrides. */
+constexpr uint32_t LOL_SPEC_INLINE_MAX_OPS = 1024;
+/* ... and above THIS many ops the inlined form is the scene's SECOND kernel: the out-of-line form, which hipRTC delivers 3 - 6
+ * times sooner, renders until it is there (start_specialise) */
+constexpr uint32_t LOL_SPEC_FIRST_TIER_INLINE_MAX_OPS = 256;
 /* specialise(): larger scenes stay on the interpreter.  The scene compiler cannot be interrupted, lol_gpu_destroy has to wait
  * for it, and a second upload's run queues behind it — so what it takes on is bounded by what was MEASURED as tolerable
  * (profiles/r4_big_scene_probe.jsonl, fields of N objects on the GPU box: 5.3 s at 1320 ops, 14.6 s at 2640, 40.7 s at 5060,
  * about n^1.5: a minute at 6500, four at 16,384 — round 4's cap).  LOL_GPU_SPEC_MAX_OPS (a tuning switch) moves it. */
 constexpr uint32_t LOL_SPEC_MAX_OPS = 6144;
 
-bool spec_out_of_line(const lol_program& P) {
+/* which form of the scene's SDF a run of the compiler produces: by the program's size, or the one the tiers ask for */
+enum SpecForm { SPEC_BY_SIZE = 0, SPEC_OUT_OF_LINE = 1, SPEC_INLINE = 2 };
+
+bool spec_out_of_line(const lol_program& P, int form = SPEC_BY_SIZE) {
+	if (form == SPEC_OUT_OF_LINE) return true;
+	if (form == SPEC_INLINE) return false;
 	uint32_t limit = LOL_SPEC_INLINE_MAX_OPS;
 	if (const char* e = tuning_env("LOL_GPU_SPEC_INLINE_MAX")) limit = (uint32_t)strtoul(e, nullptr, 10);
 	return P.n_ops > limit;
 }
 
-std::string generate_source(const lol_program& P, const FastPaths* fast, bool cull) {
+std::string generate_source(const lol_program& P, const FastPaths* fast, bool cull, int form = SPEC_BY_SIZE) {
 	std::string s;
-	const bool ool = spec_out_of_line(P);
+	const bool ool = spec_out_of_line(P, form);
 	const std::vector<RootBound> roots = analyse_roots(P);
 	const CullPlan plan = plan_culling(roots, cull);
 	s += "#include \"lol_kernel.h\"\n";
@@ -1434,8 +1461,8 @@ bool has_return_clobbering_branch(const void* data, size_t n_bytes) {
 bool has_return_clobbering_branch(const std::vector<char>& code) { return has_return_clobbering_branch(code.data(), code.size()); }
 
 bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string& arch, std::vector<char>& code,
-                  std::string& log, std::string* src_out = nullptr, const int* shape = nullptr, bool cull = true) {
-	std::string src = generate_source(P, fast, cull);
+                  std::string& log, std::string* src_out = nullptr, const int* shape = nullptr, bool cull = true, int form = SPEC_BY_SIZE) {
+	std::string src = generate_source(P, fast, cull, form);
 	if (src_out) *src_out = src;
 	if (const char* dump = tuning_env("LOL_GPU_DUMP_SPEC_SOURCE"))       /* debugging aid: the source as really generated on this device */
 		if (FILE* f = fopen(dump, "w")) { fputs(src.c_str(), f); fclose(f); }
@@ -1575,7 +1602,7 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
 		code.clear();
 		return false;
 	}
-	if (options_dropped && spec_out_of_line(P)) {
+	if (options_dropped && spec_out_of_line(P, form)) {
 		/* The retry above also dropped -amdgpu-long-branch-factor=0, the option that KEEPS the compiler from that bug, and an
 		 * out-of-line SDF is where it bites (a function beyond s_cbranch's reach).  The pattern check would be all that is left
 		 * between this code object and a launch that never ends: not enough — the interpreter renders this scene. */
@@ -1710,10 +1737,15 @@ void reap(lol_gpu* ctx, bool all) {
 	}
 }
 
+void launch_job(SpecJob* job);
+
 /* Start compiling the specialised kernel of ctx's (just committed) program.  The previous scene's module is gone already
  * (the caller has drained the device); until finish_specialise() swaps the new one in, the interpreter renders. */
 void start_specialise(lol_gpu* ctx, const FastPaths& fast) {
 	if (ctx->spec_module) { (void)hipModuleUnload(ctx->spec_module); ctx->spec_module = nullptr; }
+	if (ctx->spec_module_old) { (void)hipModuleUnload(ctx->spec_module_old); ctx->spec_module_old = nullptr; }
+	ctx->second_tier_pending = ctx->second_tier_running = false;
+	ctx->kernel_epoch++;                                /* the interpreter renders the new scene until its kernel is there */
 	ctx->spec_fn = nullptr;
 	ctx->spec_sdf_fn = nullptr;
 	snprintf(ctx->kernel_name, sizeof ctx->kernel_name, "render_interp");
@@ -1743,11 +1775,12 @@ void start_specialise(lol_gpu* ctx, const FastPaths& fast) {
 		arch = name.substr(0, name.find(':'));
 	}
 	SpecJob* job = nullptr;
-	std::shared_ptr<OwnedProgram> prog;
 	try {
 		job = new SpecJob;
-		prog = std::make_shared<OwnedProgram>();         /* the thread's own copy: the context may take another scene meanwhile */
-		prog->assign(ctx->h_prog);
+		job->prog = std::make_shared<OwnedProgram>();    /* the thread's own copy: the context may take another scene meanwhile */
+		job->prog->assign(ctx->h_prog);
+		job->fast = std::make_shared<FastPaths>(fast);
+		job->arch = arch;
 	} catch (...) { delete job; ctx->spec_log = "out of host memory"; return; }
 	{
 		char b[160];
@@ -1764,15 +1797,32 @@ void start_specialise(lol_gpu* ctx, const FastPaths& fast) {
 			job->shape[0] = a; job->shape[1] = b; job->shape[2] = c;
 		}
 	}
-	const bool cull = culling_enabled(ctx->want_cull);
+	job->cull = culling_enabled(ctx->want_cull);
+	/* Two tiers for mid-size scenes (round 5).  With its SDF inlined into the three loops a scene of 257 ... 1024 ops renders
+	 * 14 - 88 % faster than with the one out-of-line function (profiles/r5_large_scene_ab.jsonl, r5_field_inline_ab.jsonl) —
+	 * and takes hipRTC 3 - 18 s instead of 0.4 - 3 s.  So such a scene gets the out-of-line kernel first and the inlined one
+	 * when that is ready: interpreter -> out-of-line kernel -> inlined kernel, each swap at a frame boundary, same pixels on
+	 * all three.  (LOL_GPU_SPEC_INLINE_MAX, a tuning switch, pins ONE form by size as before.) */
+	ctx->second_tier_pending = !tuning_env("LOL_GPU_SPEC_INLINE_MAX") && ctx->h_prog.n_ops > LOL_SPEC_FIRST_TIER_INLINE_MAX_OPS &&
+	                           ctx->h_prog.n_ops <= LOL_SPEC_INLINE_MAX_OPS;
+	ctx->second_tier_running = false;
+	job->form = ctx->second_tier_pending ? SPEC_OUT_OF_LINE : SPEC_BY_SIZE;
+	ctx->job = job;
+	ctx->spec_state = 1;
+	launch_job(job);
+}
+
+/* start the run on its own (large-stack) thread; without a thread to be had, or with LOL_GPU_ASYNC_COMPILE=0, it runs / is waited
+ * for here */
+void launch_job(SpecJob* job) {
 	job->started = std::chrono::steady_clock::now();
-	auto work = [job, prog, fast, arch, cull]() {
+	auto work = [job]() {
 		bool ok = false;
 		std::vector<char> code;
 		std::string log;
 		try {
 			std::lock_guard<std::mutex> rtc(g_rtc_mutex);
-			ok = compile_spec(prog->p, &fast, arch, code, log, nullptr, job->shape, cull);
+			ok = compile_spec(job->prog->p, job->fast.get(), job->arch, code, log, nullptr, job->shape, job->cull, job->form);
 		} catch (...) { ok = false; log = "the scene compiler ran out of memory"; }
 		std::lock_guard<std::mutex> lock(job->mu);
 		job->compile_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - job->started).count();
@@ -1782,8 +1832,6 @@ void start_specialise(lol_gpu* ctx, const FastPaths& fast) {
 		job->done = true;
 		job->cv.notify_all();
 	};
-	ctx->job = job;
-	ctx->spec_state = 1;
 	const char* async = tuning_env("LOL_GPU_ASYNC_COMPILE");
 	bool threaded = !(async && async[0] == '0');
 	/* LOL_GPU_ASYNC_COMPILE=0: the upload itself waits for the compiler (still on the large-stack thread) */
@@ -1793,48 +1841,86 @@ void start_specialise(lol_gpu* ctx, const FastPaths& fast) {
 	else if (!threaded) job->th.join();
 }
 
-/* The frame boundary: when the compiler has finished (or `wait`), load the module and switch the context over to it.
- * Returns true when the state changed.  The device of the context is current. */
+/* The frame boundary: when the compiler has finished (or `wait`), load the module and switch the context over to it; a
+ * scene of the middle sizes then has its second run started (the inlined form), which takes over the same way when IT is
+ * done — `wait` waits for both.  Returns true when the state changed.  The device of the context is current. */
 bool finish_specialise(lol_gpu* ctx, bool wait) {
-	SpecJob* job = ctx->job;
-	if (!job) return false;
-	{
-		std::unique_lock<std::mutex> lock(job->mu);
-		if (!job->done) {
-			if (!wait) return false;
-			job->cv.wait(lock, [job] { return job->done; });
+	bool changed = false;
+	for (;;) {
+		SpecJob* job = ctx->job;
+		if (!job) return changed;
+		{
+			std::unique_lock<std::mutex> lock(job->mu);
+			if (!job->done) {
+				if (!wait) return changed;
+				job->cv.wait(lock, [job] { return job->done; });
+			}
 		}
-	}
-	if (job->th.joinable()) job->th.join();
-	ctx->job = nullptr;
-	ctx->spec_compile_ms = job->compile_ms;
-	/* an unexpected failure is reported once on stderr: frames still render, through the (slower) interpreter */
-	auto complain = [&](const std::string& why) {
-		ctx->spec_log = why;
-		ctx->spec_state = -1;
-		fprintf(stderr, "lol_gpu: scene specialisation failed, using the interpreter kernel: %s\n", ctx->spec_log.c_str());
+		if (job->th.joinable()) job->th.join();
+		ctx->job = nullptr;
+		ctx->spec_compile_ms = job->compile_ms;
+		const bool second = ctx->second_tier_running;
+		ctx->second_tier_running = false;
+		changed = true;
+		/* an unexpected failure is reported once on stderr: frames still render, through the (slower) interpreter — or, when it
+		 * is the second run that failed, through the first run's kernel, which stays */
+		auto complain = [&](const std::string& why) {
+			if (second) {
+				ctx->spec_log += "(the inlined form of the kernel was not to be had: " + why + "; the out-of-line form stays)\n";
+				ctx->spec_state = 2;
+			} else {
+				ctx->spec_log = why;
+				ctx->spec_state = -1;
+				ctx->second_tier_pending = false;
+				fprintf(stderr, "lol_gpu: scene specialisation failed, using the interpreter kernel: %s\n", ctx->spec_log.c_str());
+			}
+			delete job;
+		};
+		if (!job->ok) { complain(job->log); return true; }
+		hipModule_t mod = nullptr;
+		hipFunction_t fn = nullptr, sdf_fn = nullptr;
+		if (hipModuleLoadData(&mod, job->code.data()) != hipSuccess) { complain("hipModuleLoadData failed"); return true; }
+		if (hipModuleGetFunction(&fn, mod, "lol_render_spec") != hipSuccess) {
+			(void)hipModuleUnload(mod);
+			complain("lol_render_spec not found in the compiled module");
+			return true;
+		}
+		if (hipModuleGetFunction(&sdf_fn, mod, "lol_sdf_spec") != hipSuccess) sdf_fn = nullptr;
+		if (ctx->spec_module) {
+			/* the first tier's module: frames launched through it may still be in flight, so it is only unloaded by the next
+			 * upload (which drains the device first) or with the context */
+			if (ctx->spec_module_old) (void)hipModuleUnload(ctx->spec_module_old);      /* (cannot happen: one second tier per upload) */
+			ctx->spec_module_old = ctx->spec_module;
+		}
+		ctx->spec_module = mod;
+		ctx->spec_fn = fn;
+		ctx->spec_sdf_fn = sdf_fn;
+		ctx->wave_w = job->shape[0]; ctx->wave_h = job->shape[1]; ctx->waves_x = job->shape[2];
+		ctx->spec_log = (second ? ctx->spec_log + "second tier (SDF inlined): " : job->note) + job->log + (job->log.empty() || job->log.back() == '\n' ? "" : "\n");
+		snprintf(ctx->kernel_name, sizeof ctx->kernel_name, "lol_render_spec");
+		ctx->spec_key = fnv_hex(job->code.data(), job->code.size());
+		ctx->spec_state = 2;
+		ctx->kernel_epoch++;
+		if (ctx->second_tier_pending) {
+			/* the out-of-line kernel renders from now on; the inlined form is compiled behind it */
+			ctx->second_tier_pending = false;
+			SpecJob* next = nullptr;
+			try {
+				next = new SpecJob;
+				next->prog = job->prog; next->fast = job->fast; next->arch = job->arch; next->cull = job->cull;
+				memcpy(next->shape, job->shape, sizeof next->shape);
+				next->form = SPEC_INLINE;
+			} catch (...) { delete next; next = nullptr; }
+			if (next) {
+				ctx->job = next;
+				ctx->second_tier_running = true;
+				ctx->spec_state = 5;
+				try { launch_job(next); } catch (...) { ctx->job = nullptr; ctx->second_tier_running = false; ctx->spec_state = 2; delete next; }
+			}
+		}
 		delete job;
-		return true;
-	};
-	if (!job->ok) return complain(job->log);
-	hipModule_t mod = nullptr;
-	hipFunction_t fn = nullptr, sdf_fn = nullptr;
-	if (hipModuleLoadData(&mod, job->code.data()) != hipSuccess) return complain("hipModuleLoadData failed");
-	if (hipModuleGetFunction(&fn, mod, "lol_render_spec") != hipSuccess) {
-		(void)hipModuleUnload(mod);
-		return complain("lol_render_spec not found in the compiled module");
+		if (!wait) return true;
 	}
-	if (hipModuleGetFunction(&sdf_fn, mod, "lol_sdf_spec") != hipSuccess) sdf_fn = nullptr;
-	ctx->spec_module = mod;
-	ctx->spec_fn = fn;
-	ctx->spec_sdf_fn = sdf_fn;
-	ctx->wave_w = job->shape[0]; ctx->wave_h = job->shape[1]; ctx->waves_x = job->shape[2];
-	ctx->spec_log = job->note + job->log;
-	snprintf(ctx->kernel_name, sizeof ctx->kernel_name, "lol_render_spec");
-	ctx->spec_key = fnv_hex(job->code.data(), job->code.size());
-	ctx->spec_state = 2;
-	delete job;
-	return true;
 }
 
 }  // namespace
@@ -1880,6 +1966,7 @@ void lol_gpu_destroy(lol_gpu* ctx) {
 	if (ctx->job) { ctx->old_jobs.push_back(ctx->job); ctx->job = nullptr; }
 	reap(ctx, true);                         /* a compiler thread still running is waited for: it must not outlive the library */
 	if (ctx->spec_module) (void)hipModuleUnload(ctx->spec_module);
+	if (ctx->spec_module_old) (void)hipModuleUnload(ctx->spec_module_old);
 	for (int i = 0; i < 2; i++) {
 		if (ctx->d_tables[i]) (void)hipFree(ctx->d_tables[i]);
 		if (ctx->d_mops[i]) (void)hipFree(ctx->d_mops[i]);
@@ -2165,7 +2252,7 @@ static bool lpt_table_for_frame(lol_gpu* ctx, const lol_frame_camera* cam, int w
 	const size_t n_lanes = (size_t)n * 64, n_pixels = (size_t)w * (size_t)n_rows;
 	ctx->lpt_last_set = -1;
 	if (block != 64 || w > 0xFFFF || n_rows > 0x7FFF || n_lanes > 0xFFFFFFFFull) return false;      /* (an entry is column | row << 16 | flag; one-wave blocks) */
-	const int key[7] = { w, h, max_steps, R->band_rows, R->cycle_rows, R->offset_rows, ctx->generation * 2 + (ctx->spec_fn ? 1 : 0) };
+	const int key[7] = { w, h, max_steps, R->band_rows, R->cycle_rows, R->offset_rows, ctx->kernel_epoch };
 	/* what the frame before this one was (on whatever stream): the same view of the same frame? */
 	const bool still = ctx->lpt_have_last && memcmp(key, ctx->lpt_last_key, sizeof key) == 0 && memcmp(cam, &ctx->lpt_last_cam, sizeof *cam) == 0;
 	memcpy(ctx->lpt_last_key, key, sizeof key);
@@ -2297,7 +2384,7 @@ static int tile_order_for_frame(lol_gpu* ctx, int w, int h, int max_steps, const
 	lol_gpu::TileAuto& T = ctx->tiles;
 	*trial = -1;
 	if (T.mode != LOL_GPU_TILES_AUTO && T.mode != LOL_GPU_TILES_LPT) return T.chosen;
-	const int key[6] = { w, h, max_steps, R->band_rows, R->cycle_rows, ctx->generation * 2 + (ctx->spec_fn ? 1 : 0) };      /* (the kernel too: interpreter or the scene's own) */
+	const int key[6] = { w, h, max_steps, R->band_rows, R->cycle_rows, ctx->kernel_epoch };      /* (the kernel too: interpreter, or which form of the scene's own) */
 	if (memcmp(key, T.key, sizeof key) != 0) {          /* another scene, size or partition: measure again */
 		memcpy(T.key, key, sizeof key);
 		if (!T.have_events) {
@@ -2434,7 +2521,9 @@ int lol_gpu_specialize_state(lol_gpu* ctx, double* compile_ms) {
 	if (!ctx) return LOL_GPU_ERR_ARG;
 	if (ctx->job) {                                    /* has the compiler finished?  (the swap itself happens at a frame or a wait) */
 		std::lock_guard<std::mutex> lock(ctx->job->mu);
-		if (compile_ms) *compile_ms = ctx->job->done ? ctx->job->compile_ms : 0.0;
+		/* (while the second run is at work: what the first one took) */
+		if (compile_ms) *compile_ms = ctx->job->done ? ctx->job->compile_ms : ctx->second_tier_running ? ctx->spec_compile_ms : 0.0;
+		if (ctx->second_tier_running) return ctx->job->done ? 6 : 5;
 		return ctx->job->done ? 3 : 1;
 	}
 	if (compile_ms) *compile_ms = ctx->spec_compile_ms;

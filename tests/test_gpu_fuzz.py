@@ -184,7 +184,7 @@ def chain_scene(n_unions, seed=3):
                          ids=["142ops-inline", "142ops-out-of-line", "264ops-default", "264ops-out-of-line"])
 def test_large_scenes_are_specialised_too(torch_cuda, monkeypatch, n_unions, inline_max):
     """Round 1 left scenes above 128 ops to the interpreter.  Every program the library accepts is now specialised:
-    the SDF inlined up to 256 ops, as one out-of-line function beyond (LOL_GPU_SPEC_INLINE_MAX) — same pixels."""
+    the SDF inlined up to 1024 ops (256 before round 5), as one out-of-line function beyond (LOL_GPU_SPEC_INLINE_MAX) — same pixels."""
     if inline_max is not None:
         monkeypatch.setenv("LOL_GPU_SPEC_INLINE_MAX", str(inline_max))
     sc = chain_scene(n_unions)
