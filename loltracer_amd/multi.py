@@ -180,7 +180,7 @@ class GatherPipeline:
 
     def __init__(self, w: int, h: int, band_rows: int, device, group=None, dst: int = 0, depth: int = 2,
                  dtype=torch.int32, force_collective: bool = False, partition: Optional[Partition] = None,
-                 assembler: Optional[Callable] = None):
+                 assembler: Optional[Callable] = None, kernel_streams: Optional[list] = None):
         self.group, self.dst, self.h, self.w = group, dst, h, w
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -213,6 +213,17 @@ class GatherPipeline:
         self.cuda = torch.device(device).type == "cuda"
         self.asm_stream = torch.cuda.Stream(device=device) if self.cuda and self.is_dst and not self.single else None
         self.assembled = [None] * self.depth
+        # kernel_streams (GPU, optional): one torch stream per slot.  Slot k's rendering and its gather are issued on stream k, so
+        # the KERNELS of consecutive frames run on different streams and overlap (a rank's launch of its bands is a small launch:
+        # its ramp and tail are a larger share of it than of a whole frame's; bench.py: LOL_BENCH_KERNEL_STREAMS).  Everything about
+        # one slot is still ordered on one stream; slots only share the root's frame, which the one assembly stream orders.
+        self.kernel_streams = list(kernel_streams) if (kernel_streams and self.cuda and not self.single) else None
+        if self.kernel_streams is not None and len(self.kernel_streams) < self.depth:
+            raise ValueError("one kernel stream per slot, please")
+
+    def _slot_stream(self, slot: int):
+        import contextlib
+        return torch.cuda.stream(self.kernel_streams[slot]) if self.kernel_streams is not None else contextlib.nullcontext()
 
     def _assemble(self, slot: int, stream_handle):
         if self.assembler is not None:
@@ -226,7 +237,8 @@ class GatherPipeline:
             return
         self.work[slot] = None
         if self.asm_stream is not None:
-            w.wait()                                   # the render stream may overwrite local[slot] only after the
+            with self._slot_stream(slot):
+                w.wait()                               # the render stream may overwrite local[slot] only after the
                                                        # collective that reads it (two frames of slack at depth 2)
             with torch.cuda.stream(self.asm_stream):
                 w.wait()                               # orders the assembly stream after the collective
@@ -235,9 +247,10 @@ class GatherPipeline:
                 ev.record()
             self.assembled[slot] = ev
         else:
-            w.wait()                                   # orders the current stream after the collective
-            if self.is_dst:
-                self._assemble(slot, torch.cuda.current_stream().cuda_stream if self.cuda else None)
+            with self._slot_stream(slot):
+                w.wait()                               # orders the (slot's) stream after the collective
+                if self.is_dst:
+                    self._assemble(slot, torch.cuda.current_stream().cuda_stream if self.cuda else None)
         self.frames_done += 1
 
     def submit(self, render):
@@ -251,8 +264,9 @@ class GatherPipeline:
             self.frames_done += 1
             return
         self._finish(slot)
-        render(self.local[slot])
-        self._gather(slot)
+        with self._slot_stream(slot):
+            render(self.local[slot])
+            self._gather(slot)
 
     def _gather(self, slot: int):
         if self.assembled[slot] is not None:           # staging[slot] is still being read by the assembly stream
@@ -270,7 +284,8 @@ class GatherPipeline:
         if self.single:
             return
         self._finish(slot)
-        self._gather(slot)
+        with self._slot_stream(slot):
+            self._gather(slot)
         self._finish(slot)
         self._join()
 

@@ -127,7 +127,12 @@ def test_multi_rank_record_schema():
         assert set(r) >= {"rank", "rows", "frames", "kernel_ms_avg", "kernel_ms_min", "kernel_ms_max", "wall_ms_per_frame",
                           "exposed_ms_per_frame", "host_issue_us_per_frame", "tile_order", "tile_trial_ms"}
     assert f["per_rank"][0]["rows"] == 512 and f["per_rank"][3]["tile_order"] == "lpt" and f["per_rank"][2]["tile_order"] == "rows"
-    assert f["kernel_ms"] == {"min": 0.55, "max": 0.62, "rank0": 0.55, "slowest_rank": 7}
+    assert f["kernel_ms"] == {"min": 0.55, "max": 0.62, "rank0": 0.55, "slowest_rank": 7, "kernels_sharing_the_device": 1, "note": None}
+    # two kernel streams per rank: a kernel's elapsed time is shared with its neighbour's, the derived figures say so
+    g = bench.per_rank_fields([dict(row, kernel_ms_avg=2 * row["kernel_ms_avg"]) for row in stats], 0.68, 2)
+    assert g["kernel_ms"]["kernels_sharing_the_device"] == 2 and "elapsed / 2" in g["kernel_ms"]["note"]
+    assert abs(g["gather_exposed_ms"] - f["gather_exposed_ms"]) < 1e-9
+    assert abs(g["ms_per_step_over_slowest_kernel"] - f["ms_per_step_over_slowest_kernel"]) < 1e-3
     assert abs(f["gather_exposed_ms"] - 0.13) < 1e-9 and abs(f["per_rank"][0]["exposed_ms_per_frame"] - 0.13) < 1e-9
     # the names the record uses for the checks (bench.py main / run_cabi)
     src = open(os.path.join(ROOT, "bench.py")).read()
