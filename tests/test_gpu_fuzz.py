@@ -363,3 +363,45 @@ def test_very_large_scenes_stay_on_the_interpreter(torch_cuda, monkeypatch):
     g = gpu_render(torch_cuda, r, sc, 32, 16)
     check_against_oracle(g, sc, 32, 16)
     r.close()
+
+
+def test_both_tiers_of_mid_size_scenes_match_the_oracle(torch_cuda, monkeypatch):
+    """Scenes of 257 ... 1024 ops get two kernels (lol_gpu.hip, start_specialise): the SDF as one out-of-line function first, the
+    SDF inlined into the three loops behind it.  Chains, fields (the culling plan's nested tests in both forms) and a union tree:
+    every pixel, id, distance and step count of a frame rendered on EACH tier equals the oracle's."""
+    import time
+    monkeypatch.setenv("LOL_GPU_CACHE_DIR", "")                      # both kernels are really compiled, one after the other
+    scenes = [chain_scene(140, seed=int(time.time()) % 9973),        # (scenes no other test of this process has compiled)
+              S.Scene.parse_string(big_field_scene(150, 7, 2, seed=int(time.time()) % 9967)),
+              S.Scene.parse_string(big_field_scene(330, 9, 3, seed=int(time.time()) % 9949))]
+    for sc in scenes:
+        n_ops = sc.flatten().n_ops
+        assert 256 < n_ops <= 1024, n_ops
+        w, h = 48, 28
+        r = gpu.Renderer(0)
+        r.prepare(sc, wait=False)
+        deadline = time.perf_counter() + 240
+        while r.specialize_state()[0] == 1 and time.perf_counter() < deadline:
+            time.sleep(0.01)
+        dev = torch_cuda.device("cuda:0")
+        bufs = [torch_cuda.zeros((h, w), dtype=dt, device=dev) for dt in (torch_cuda.int32, torch_cuda.float32, torch_cuda.int32, torch_cuda.int32)]
+        rgb = torch_cuda.zeros((h, w, 3), dtype=torch_cuda.float32, device=dev)
+        torch_cuda.cuda.synchronize()
+
+        def frame():
+            dbg = gpu.Debug(rgb.data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), bufs[3].data_ptr())
+            r.render_into(bufs[0].data_ptr(), w, h, debug=dbg)
+            r.sync()
+            return dict(xrgb=bufs[0].cpu().numpy().view(np.uint32), rgb=rgb.cpu().numpy(), dist=bufs[1].cpu().numpy(),
+                        id=bufs[2].cpu().numpy().view(np.uint32), steps=bufs[3].cpu().numpy().view(np.uint32), miss_skip=r.miss_skip_active())
+        g1 = frame()                                                 # the frame boundary at which the first kernel takes over
+        assert r.kernel_name() == "lol_render_spec" and r.specialize_state()[0] in (5, 6), (n_ops, r.specialize_state(), r.specialize_log())
+        key1 = r.kernel_key()
+        g1 = frame()
+        if r.kernel_key() == key1:                                   # (still the first tier: this frame ran on it)
+            check_against_oracle(g1, sc, w, h)
+        r.specialize_wait()
+        g2 = frame()
+        assert r.specialize_state()[0] == 2 and r.kernel_key() != key1 and "second tier" in r.specialize_log()
+        check_against_oracle(g2, sc, w, h)
+        r.close()
