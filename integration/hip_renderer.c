@@ -28,8 +28,9 @@
  *                   --report (one line on stdout at render_destroy: kernel, its key,
  *                   tile order mode / order in use / sorts so far),
  *                   --wait-kernel (render_prepare returns only when the scene's own
- *                   kernel is in place, as the tracing JIT's does; without it the
- *                   first frames render on the interpreter kernel: benchmarks), and
+ *                   kernel is in place, as the tracing JIT's does — the LAST one, for a
+ *                   scene of 257 ... 1024 ops, which gets two; without it the first
+ *                   frames render on the interpreter kernel: benchmarks), and
  *                   --dump-kernel BASE, the counterpart of the JIT renderer's
  *                   -j/--jitdump (tracing_jit_renderer.dasc:424-433): writes the
  *                   scene-specialised kernel as BASE.hip (generated source) and
