@@ -264,11 +264,6 @@ int         lol_gpu_verify_fast_paths(lol_gpu* ctx, float k, unsigned long long 
 /* The same exhaustive run for the blend factor WITHOUT its v_div_fixup_f32 (lol_kernel.h, smin_h_fast<false>): inputs on
  * which it differs from the exact factor, or — for dlt = +-inf — fails to make the smooth minimum NaN.  0 = proven. */
 int         lol_gpu_verify_smin_no_fixup(lol_gpu* ctx, float k, unsigned long long* mismatches);
-/* The shadow march's 50 s / t (naive_renderer.c:83) without v_div_scale / v_div_fmas / v_div_fixup (lol_kernel.h, fdiv_fast):
- * the same arithmetic as the full division inside the box of operands the march establishes for itself, by the definition of
- * those instructions; this sweeps 2^32 quotients of that box on the device against '/' (seed 0: the fixed exponent corners a
- * context checks before it uses the shortcut; other seeds: pseudo-random exponents and divisor mantissas).  0 = equal. */
-int         lol_gpu_verify_shadow_division(lol_gpu* ctx, uint32_t seed, unsigned long long* mismatches);
 /* Gamma and quantisation of a colour channel — Uint8 v = powf(c, 1 / 2.2f) * 255 (naive_renderer.c:231-232, renderer.h:17-22) —
  * through a table of 256 thresholds instead of the powf (lol_kernel.h, gamma_u8_table): used by frames only after this sweep of
  * every float in [0, 1] found no difference on the context's device (it runs at the first upload; LOL_GPU_GAMMA_TABLE=0 keeps the

@@ -17,6 +17,10 @@ extern "C" {
  * every check has passed: exercises the all-or-nothing upload. */
 int lol_gpu_testing_fail_uploads(lol_gpu* ctx, int n);
 
+/* The next `n` FIRST runs of the scene compiler for a scene of the middle sizes (257 ... 1024 ops: out-of-line form first, inlined
+ * form behind it) count as failed: exercises "the inlined form is compiled all the same" (lol_gpu.hip, finish_specialise). */
+int lol_gpu_testing_fail_first_tier(lol_gpu* ctx, int n);
+
 /* Every `stride`-th PART gets the root's band height (lol_gpu_multi_set_root_band_rows) even on ONE device, so that a
  * one-GPU box runs bands of unequal height through split, launches, exchange, assembly and host copies.  0 = off. */
 int lol_gpu_multi_testing_root_stride(lol_gpu_multi* m, int stride);

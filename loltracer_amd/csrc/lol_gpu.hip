@@ -165,6 +165,8 @@ struct lol_gpu {
 	uint32_t     spec_max_ops = 0;       /* lol_gpu_set_specialize_max_ops: 0 = LOL_SPEC_MAX_OPS */
 	hipModule_t  spec_module = nullptr;
 	hipFunction_t spec_fn = nullptr;
+	hipFunction_t spec_steps_fn = nullptr;   /* lol_render_spec_steps, the same pipeline with the per-lane step counters (generate_source);
+	                                          * nullptr where the module holds one kernel only: spec_fn counts then */
 	hipFunction_t spec_sdf_fn = nullptr; /* lol_sdf_spec of the same module (lol_gpu_sdf_batch) */
 	std::string  spec_log;
 	hipModule_t  spec_module_old = nullptr;   /* the first tier's module once the second has taken over: frames in flight may still run it, so it
@@ -178,6 +180,7 @@ struct lol_gpu {
 	std::string  spec_key;               /* FNV-1a of the code object the frames run (lol_gpu_kernel_key) */
 	std::string  interp_key;             /* ... and of {this build, the uploaded macro-op lists} for the interpreter */
 	int          fail_uploads = 0;       /* lol_gpu_testing_fail_uploads: that many uploads still fail at the copy */
+	int          fail_first_tier = 0;    /* lol_gpu_testing_fail_first_tier: that many out-of-line first runs of the scene compiler "fail" */
 	int          want_fast = 1;          /* allow the proven-exact shortcuts in the specialised kernel */
 	unsigned     want_skips = 7;         /* exact skips allowed when the program qualifies: bit 0 escaped waves, 1 zero incidence, 2 settled shadows */
 	int          want_cull = 1;          /* allow the exact culling of top-level objects (plan_culling) */
@@ -188,8 +191,6 @@ struct lol_gpu {
 	int          interp_sqrt_kind = 0;   /* fast sqrt of the interpreter: 3 (sqrt_r2) when proven and allowed, else 0 */
 	int          sqrt_verified = -1;     /* -1 not run, 0 none proven, else the lol::sqrt_fast KIND proven on this device */
 	bool         sqrt_tiny_ok = false;   /* the second counter of that run was 0 too (sd_sphere_fast_nr) */
-	int          fdiv_verified = -1;     /* -1 not run, 1 fdiv_fast == '/' over verify_fdiv_kernel's sweep on this device, 0 not */
-	bool         shadow_fdiv = false;    /* the kernels in use were built with it (FastPaths::fdiv_ok at the last upload) */
 	struct DivProof { uint32_t k_bits; bool ok, no_fixup_ok; };
 	std::vector<DivProof> div_verified;  /* per smoothness constant: smin_h_fast proven / proven without v_div_fixup too */
 	unsigned long long* d_bad = nullptr; /* mismatch counter of the verification kernels */
@@ -219,6 +220,12 @@ struct lol_gpu {
 		float mon_ratio[MONITOR_WINDOW] = {};
 	} tiles;
 	int          generation = 0;         /* uploads so far */
+	/* the primary march's first step (first_step): sdf(camera origin) of program `first_gen`, kept while the camera stays where it is */
+	float        first_origin[3] = { 0, 0, 0 };
+	int          first_gen = -1;
+	float        first_dist = 0;
+	uint32_t     first_id = 0;
+	std::vector<float> first_stack;
 	int          kernel_epoch = 0;       /* changes whenever the frames' kernel does: an upload (the interpreter takes over), each swap of
 	                                      * finish_specialise — what a kernel's tiles cost says nothing about another kernel's */
 	/* LOL_GPU_TILES_LPT: longest tiles first ("longest tiles first" below).  One SET of tables per stream that launches frames
@@ -411,6 +418,84 @@ bool camera_sane(const lol_frame_camera& c) {
 	return true;
 }
 
+/* ---------------------------------------------------------------- the primary march's first step, once per camera position
+ * Step 0 of get_intersection (naive_renderer.c:56-57) evaluates sdf(ro + rd * 0): the camera's position, the same point for
+ * every pixel of the frame.  Like the camera basis of get_camera_ray (naive_renderer.c:183-186, computed once per frame in
+ * lol_frame_camera_init) it is a per-frame constant, hoisted: the value is computed HERE, once per camera position, in the
+ * reference's own arithmetic — sdf() / get_obj_dist() / sdSphere / sdRoundBox / sminf (naive_renderer.c:11-44, sdf.h:8-22,
+ * float.h:6-33) over the post-order program of lol_scene.h, objects in file order, first strict minimum — and handed to the
+ * kernels as two launch arguments (lol_kernel.h, FLAG_FIRST_STEP / march).  Every operation is an IEEE binary32 +, -, *, /,
+ * sqrt or comparison, correctly rounded here as on the device (this file is compiled with -ffp-contract=off; no libm call), so
+ * the value IS what every lane's first step would have computed.  Not used (the kernels take the step themselves) unless:
+ * the camera is sane (camera_sane: then every ray direction that is finite makes ro + rd * 0 = ro, see march), no component of
+ * the origin is a negative zero, max_steps >= 1, and the value lies in [0.001, 100] — a march that ends on its first step, or
+ * goes on with a NaN, is left to the loop.  tests/test_gpu_parity.py compares every pixel's distance, id and step count
+ * (this step included) with the oracle's either way. */
+inline float h_minf(float a, float b) { return a < b ? a : b; }      /* MINSS: b on NaN / equal (float.h:6) */
+inline float h_maxf(float a, float b) { return a > b ? a : b; }
+inline float h_len3(float x, float y, float z) { return __builtin_sqrtf((x * x + y * y) + z * z); }      /* DPPS 0x71 (vec.h:52-56): (x² + y²) + (z² + 0) */
+bool host_sdf(const lol_program& P, const float p[3], std::vector<float>& st, float* dist_out, uint32_t* id_out) {
+	if (st.size() < (size_t)P.max_stack + 1) st.resize((size_t)P.max_stack + 1);
+	size_t sp = 0;
+	float best = __builtin_inff();
+	uint32_t best_id = 0;
+	for (uint32_t i = 0; i < P.n_ops; i++) {
+		const lol_op& o = P.ops[i];
+		switch (o.op) {
+		case LOL_OP_SPHERE:
+			if (sp >= st.size()) return false;
+			st[sp++] = h_len3(p[0] - o.f[0], p[1] - o.f[1], p[2] - o.f[2]) - o.f[3];
+			break;
+		case LOL_OP_RBOX: {
+			if (sp >= st.size()) return false;
+			const float qx = __builtin_fabsf(p[0] - o.f[0]) - o.f[3], qy = __builtin_fabsf(p[1] - o.f[1]) - o.f[4], qz = __builtin_fabsf(p[2] - o.f[2]) - o.f[5];
+			st[sp++] = h_len3(h_maxf(qx, 0.f), h_maxf(qy, 0.f), h_maxf(qz, 0.f)) + h_minf(h_maxf(qx, h_maxf(qy, qz)), 0.f) - o.f[6];
+			break;
+		}
+		case LOL_OP_PLANE:
+			if (sp >= st.size()) return false;
+			st[sp++] = p[1] - o.f[0];
+			break;
+		case LOL_OP_SMIN: case LOL_OP_SMIN_R: {
+			if (sp < 2) return false;
+			const float top = st[--sp], under = st[--sp];
+			const float a = o.op == LOL_OP_SMIN ? under : top, b = o.op == LOL_OP_SMIN ? top : under, k = o.f[0];
+			const float h = h_minf(h_maxf(.5f + .5f * (b - a) / k, 0.f), 1.f);
+			st[sp++] = (b + (a - b) * h) - k * h * (1.f - h);
+			break;
+		}
+		case LOL_OP_TOP: {
+			if (sp < 1) return false;
+			const float d = st[--sp];
+			if (d < best) { best = d; best_id = o.id; }
+			break;
+		}
+		default: return false;
+		}
+	}
+	*dist_out = best;
+	*id_out = best_id;
+	return true;
+}
+/* FLAG_FIRST_STEP for a frame of `cam`?  Fills ctx->first_dist / first_id (kept while the camera stays where it is). */
+bool first_step(lol_gpu* ctx, const lol_frame_camera& cam, int max_steps) {
+	if (max_steps < 1 || !camera_sane(cam)) return false;
+	float origin[3] = { cam.origin.x, cam.origin.y, cam.origin.z };
+	uint32_t bits[3];
+	memcpy(bits, origin, sizeof bits);
+	for (uint32_t b : bits) if (b == 0x80000000u) return false;
+	if (ctx->first_gen != ctx->generation || memcmp(ctx->first_origin, origin, sizeof origin) != 0) {
+		float d = 0.f; uint32_t id = 0;
+		bool ok = false;
+		try { ok = host_sdf(ctx->h_prog, origin, ctx->first_stack, &d, &id); } catch (...) { ok = false; }
+		ctx->first_dist = ok ? d : __builtin_nanf("");
+		ctx->first_id = id;
+		ctx->first_gen = ctx->generation;
+		memcpy(ctx->first_origin, origin, sizeof origin);
+	}
+	return ctx->first_dist >= 0.001f && ctx->first_dist <= 100.f;
+}
+
 /* --------------------------------------------- exhaustive proofs of the fast paths
  * Each kernel feeds all 2^32 float bit patterns through the shortcut and through the plain
  * expression it replaces and counts the inputs on which they differ (same bits, or both NaN,
@@ -474,34 +559,6 @@ __global__ __launch_bounds__(VERIFY_THREADS) void verify_div_kernel(float k, flo
 	if (m) atomicAdd(bad + 1, (unsigned long long)m);
 }
 
-/* fdiv_fast(n, t) against n / t (lol_kernel.h): all 2^23 mantissas of n x 512 combinations of {exponent of n, exponent of t,
- * mantissa of t} spread over the box soft_shadow keeps its operands in — n in [2^-60, 2^64], t in [2^-28, 2^58], corners and
- * a margin beyond them included.  `seed` != 0 replaces the fixed divisor mantissas and moves the exponents (tests sweep a
- * few seeds; the context runs seed 0 once).  2^32 quotients, a few ms. */
-__global__ __launch_bounds__(VERIFY_THREADS) void verify_fdiv_kernel(uint32_t seed, unsigned long long* bad) {
-	const int en_tab[8] = { -60, -37, -9, -1, 0, 7, 33, 64 }, et_tab[8] = { -28, -13, -1, 0, 1, 11, 35, 58 };
-	const uint32_t mt_tab[8] = { 0u, 1u, 0x7fffffu, 0x400000u, 0x2aaaaau, 0x555555u, 0x123456u, 0x7ffffeu };
-	uint32_t base = blockIdx.x * VERIFY_THREADS + threadIdx.x;
-	unsigned n_bad = 0;
-	for (uint32_t it = 0; it < VERIFY_ITERS; it++) {
-		const uint32_t idx = base + it * (VERIFY_BLOCKS * VERIFY_THREADS);
-		const uint32_t mn = idx & 0x7fffffu, sel = idx >> 23;
-		int en = en_tab[sel & 7u], et = et_tab[sel >> 3 & 7u];
-		uint32_t mt = mt_tab[sel >> 6 & 7u];
-		if (seed) {
-			uint32_t h = (sel + 1u) * 0x9E3779B1u ^ seed * 0x85EBCA77u;
-			h ^= h >> 15; h *= 0xC2B2AE3Du; h ^= h >> 13;
-			mt = h & 0x7fffffu;
-			en = -60 + (int)((h >> 23) % 125u);          /* [-60, 64] */
-			et = -28 + (int)((h >> 9 ^ h >> 27) % 87u);  /* [-28, 58] */
-		}
-		const float n = __builtin_bit_cast(float, (uint32_t)(en + 127) << 23 | mn);
-		const float t = __builtin_bit_cast(float, (uint32_t)(et + 127) << 23 | mt);
-		if (!same_float(lol::fdiv_fast(n, t), n / t)) n_bad++;
-	}
-	if (n_bad) atomicAdd(bad, (unsigned long long)n_bad);
-}
-
 /* The gamma staircase (lol_kernel.h, "gamma + quantisation").  Thread k finds T[k], the smallest float in [0, 1] whose channel
  * value (Uint8)(powf(c, 1 / 2.2f) * 255) is >= k, by bisection over the bit patterns (for floats >= +0 the order of the bits is
  * the order of the values) — which presumes the staircase monotone; verify_gamma_kernel then proves table route == powf route
@@ -545,8 +602,7 @@ unsigned long long run_verify(lol_gpu* ctx, int sqrt_kind, float k, unsigned lon
 		return ~0ull;
 	unsigned long long bad[2] = { 0, 0 };
 	if (hipMemcpy(ctx->d_bad, bad, sizeof bad, hipMemcpyHostToDevice) != hipSuccess) return ~0ull;
-	if (sqrt_kind == -1) hipLaunchKernelGGL(verify_fdiv_kernel, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, __builtin_bit_cast(uint32_t, k), ctx->d_bad);
-	else if (sqrt_kind == 3) hipLaunchKernelGGL(verify_sqrt_kernel<3>, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, ctx->d_bad);
+	if (sqrt_kind == 3) hipLaunchKernelGGL(verify_sqrt_kernel<3>, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, ctx->d_bad);
 	else if (sqrt_kind == 2) hipLaunchKernelGGL(verify_sqrt_kernel<2>, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, ctx->d_bad);
 	else if (sqrt_kind == 1) hipLaunchKernelGGL(verify_sqrt_kernel<1>, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, ctx->d_bad);
 	else hipLaunchKernelGGL(verify_div_kernel, dim3(VERIFY_BLOCKS), dim3(VERIFY_THREADS), 0, ctx->stream, k, 2.0f * k, 0.5f * (1.0f / k),
@@ -595,7 +651,6 @@ struct FastPaths {
 	bool sqrt_tiny_ok = false;            /* ... and NaN-or-tiny below its domain: spheres may drop the range tracker (sd_sphere_fast_nr) */
 	std::vector<float> div_ok;            /* smoothness constants k whose smin_h_fast verified */
 	std::vector<float> div_nf_ok;         /* ... and verified without v_div_fixup as well (smin_h_fast<false>) */
-	bool fdiv_ok = false;                 /* fdiv_fast == '/' over the sweep of verify_fdiv_kernel: the shadow march may use it */
 	bool gamma_ok = false;                /* the gamma table route == the powf route for every float in [0, 1] (verify_gamma_kernel) */
 	bool has(float k) const {
 		for (float v : div_ok) if (memcmp(&v, &k, 4) == 0) return true;
@@ -1013,15 +1068,18 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 		/* out of line the cool-down state is per call (always 0: every evaluation tests) */
 		/* (amdgpu_waves_per_eu applies to kernels only: the function is scheduled with the default register budget) */
 		(void)occupancy;
-		snprintf(line, sizeof line, "__device__ __noinline__ SdfOut %s_fn(float px, float py, float pz, u32 rg_lo, u32 rg_hi, u64 care) {\n"
-		         "\t\tconst V3 p = { px, py, pz };\n\t\tRange rg; rg.lo = rg_lo; rg.hi = rg_hi;\n\t\tu64 nan = 0;\n\t\tfloat best; u32 best_id;\n\t%s",
+		snprintf(line, sizeof line, "__device__ __noinline__ SdfOut %s_fn(float px, float py, float pz, u32 rg_lo, u32 rg_hi) {\n"
+		         "\t\tconst V3 p = { px, py, pz };\n\t\tRange rg; rg.lo = rg_lo; rg.hi = rg_hi;\n\t\tfloat nanacc = 0.f;\n\t\tfloat best; u32 best_id;\n\t%s",
 		         name, cool_decl);
 		s += line;
 	} else {
-		snprintf(line, sizeof line, "struct %s {\n\tstatic constexpr bool MASKS = true;\n\tstatic constexpr bool FAST_DIV = %s;\n\tRange rg;\n\tu64 nan = 0;\n%s", name,
-		         fast && fast->fdiv_ok ? "true" : "false", cool_decl);
+		/* ASSUME_SETTLED: the fast pipeline only runs under FLAG_SHADOW_SETTLED (generate_source; lol_kernel.h, soft_shadow).
+		 * loop_done(): what the wave-uniform cool-down counter is after a loop that lanes leave one by one (lol_kernel.h, Interp) */
+		snprintf(line, sizeof line, "struct %s {\n\tstatic constexpr bool ASSUME_SETTLED = %s;\n\tRange rg;\n\tfloat nanacc = 0.f;\n%s"
+		         "\t__device__ __forceinline__ void loop_done() { %s }\n", name, fast ? "true" : "false", cool_decl,
+		         plan.intervals.empty() ? "" : "cool[0] = 0u;");
 		s += line;
-		s += "\t__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id, u64 care = ~0ull) {\n";
+		s += "\t__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id) {\n";
 	}
 	s += "\t\tbest = __builtin_inff(); best_id = 0u;\n";
 	int t = 0, n_tests = 0;
@@ -1068,14 +1126,14 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 			snprintf(line, sizeof line, "\t\t  need%d = ((", k0);
 			s += line;
 			s += votes;
-			snprintf(line, sizeof line, ") & care) != 0;\n\t\t  if (need%d) cool[0] = %du;\n\t\t  } else cool[0]--;\n\t\t  if (need%d) {\n", k0, cooldown, k0);
+			snprintf(line, sizeof line, ")) != 0;\n\t\t  if (need%d) cool[0] = %du;\n\t\t  } else cool[0]--;\n\t\t  if (need%d) {\n", k0, cooldown, k0);
 			s += line;
 		} else {
 			s += "\t\t{\n";
 			s += decl;
 			s += "\t\t  if (((";
 			s += votes;
-			s += ") & care) != 0) {\n";
+			s += ")) != 0) {\n";
 		}
 	};
 	uint32_t max_id_seen = 0;
@@ -1089,7 +1147,7 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 			next_iv++;
 		}
 		/* the object's expression tree from its post-order ops (child `a` / `b` = the operands of sminf(a, b, k)) */
-		struct Node { uint32_t op; int a, b; Sphere bound; uint32_t prims; };
+		struct Node { uint32_t op; int a, b; Sphere bound; uint32_t prims; bool fon = false; };      /* fon: the fast SDF's value of this node is finite or NaN */
 		std::vector<Node> nodes;
 		{
 			std::vector<int> st;
@@ -1098,6 +1156,7 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 				const lol_op& o = P.ops[i];
 				Node n{ i, -1, -1, { false, { 0, 0, 0 }, 0, 1 }, 1 };
 				if (o.op == LOL_OP_SPHERE) {
+					n.fon = fsqrt && nan_flag && o.f[3] >= 0x1p-20f && std::isfinite(o.f[3]);      /* sd_sphere_fast_nr (emit_node) */
 					n.bound = { sane(o.f[0]) && sane(o.f[1]) && sane(o.f[2]) && sane(o.f[3]), { o.f[0], o.f[1], o.f[2] }, o.f[3] > 0 ? (double)o.f[3] : 0.0, 1 };
 				} else if (o.op == LOL_OP_RBOX) {
 					bool ok = true;
@@ -1116,6 +1175,7 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 					n.bound.levels++;
 					if (!sane(n.bound.r)) n.bound.ok = false;
 					n.prims = nodes[n.a].prims + nodes[n.b].prims;
+					n.fon = nodes[n.a].fon && nodes[n.b].fon && fast && fast->has(o.f[0]);
 				}
 				st.push_back((int)nodes.size());
 				nodes.push_back(n);
@@ -1174,7 +1234,7 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 				         "\t\t  const float sx%d = p.x - %s, sy%d = p.y - %s, sz%d = p.z - %s;\n"
 				         "\t\t  const float sl%d = (sx%d * sx%d + sy%d * sy%d) + sz%d * sz%d;\n"
 				         "\t\t  const float su%d = (sb%d + %s) * %s;\n"
-				         "\t\t  if (((vote(!(sl%d > su%d * su%d)) | vote(!(su%d > 0.f)) | vote(!(sw%d <= -%s)) | vote(!(sl%d < 0x1p120f))) & care) != 0) {\n",
+				         "\t\t  if ((vote(!(sl%d > su%d * su%d)) | vote(!(su%d > 0.f)) | vote(!(sw%d <= -%s)) | vote(!(sl%d < 0x1p120f))) != 0) {\n",
 				         r, q, b, kss.c_str(), q, b, q,
 				         q, fbits(ct.c[0]).c_str(), q, fbits(ct.c[1]).c_str(), q, fbits(ct.c[2]).c_str(),
 				         q, q, q, q, q, q, q,
@@ -1183,7 +1243,7 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 				s += line;
 				const int a = emit_node(n.a);
 				if (sat_arith)
-					snprintf(line, sizeof line, "\t\t  t%d = sminf_fastdiv_sat%s(t%d, t%d, %s, %s, %s, %s, care);\n\t\t  } else t%d = t%d + 0.f;\n\t\t}\n",
+					snprintf(line, sizeof line, "\t\t  t%d = sminf_fastdiv_sat%s(t%d, t%d, %s, %s, %s, %s);\n\t\t  } else t%d = t%d + 0.f;\n\t\t}\n",
 					         r, fx, a, b, kk.c_str(), k2.c_str(), hrk.c_str(), kss.c_str(), r, b);
 				else
 					snprintf(line, sizeof line, "\t\t  t%d = sminf_fastdiv%s(t%d, t%d, %s, %s, %s);\n\t\t  } else t%d = t%d + 0.f;\n\t\t}\n",
@@ -1196,8 +1256,8 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 			const int first = emit_node(a_first ? n.a : n.b), second = emit_node(a_first ? n.b : n.a);
 			const int a = a_first ? first : second, b = a_first ? second : first;
 			if (proven && sat_arith)
-				snprintf(line, sizeof line, "\t\tconst float t%d = sminf_fastdiv_sat%s(t%d, t%d, %s, %s, %s, %s, care);\n", t, fx, a, b,
-				         kk.c_str(), k2.c_str(), hrk.c_str(), kss.c_str());
+				snprintf(line, sizeof line, "\t\tconst float t%d = sminf_fastdiv_sat%s%s(t%d, t%d, %s, %s, %s, %s);\n", t,
+				         nodes[n.a].fon && nodes[n.b].fon ? "2" : "", fx, a, b, kk.c_str(), k2.c_str(), hrk.c_str(), kss.c_str());
 			else if (proven)
 				snprintf(line, sizeof line, "\t\tconst float t%d = sminf_fastdiv%s(t%d, t%d, %s, %s, %s);\n", t, fx, a, b, kk.c_str(), k2.c_str(), hrk.c_str());
 			else
@@ -1206,8 +1266,8 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 		};
 		object_has_nr = false;
 		const int d = emit_node((int)nodes.size() - 1);
-		if (object_has_nr) {                 /* a NaN from a sphere without range tracker reaches the object's value */
-			snprintf(line, sizeof line, "\t\tnan |= vote(t%d != t%d);\n", d, d);
+		if (object_has_nr) {                 /* a NaN from a sphere without range tracker reaches the object's value: 0 * NaN (or inf) = NaN */
+			snprintf(line, sizeof line, "\t\tnanacc = __builtin_fmaf(t%d, 0.f, nanacc);\n", d);
 			s += line;
 		}
 		if (R.id < max_id_seen)      /* evaluated after an object that follows it in the file: ties go to the lower id */
@@ -1219,10 +1279,12 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 		for (uint32_t k = 0; k < runs_ending[oi + 1]; k++) s += "\t\t} }\n";               /* every run that ends here */
 	}
 	if (out_of_line) {
-		s += "\t\treturn { best, best_id, rg.lo, rg.hi, nan };\n}\n";
-		snprintf(line, sizeof line, "struct %s {\n\tstatic constexpr bool MASKS = true;\n\tstatic constexpr bool FAST_DIV = %s;\n\tRange rg;\n\tu64 nan = 0;\n\t__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id, u64 care = ~0ull) {\n"
-		         "\t\tconst SdfOut o = %s_fn(p.x, p.y, p.z, rg.lo, rg.hi, care);\n"
-		         "\t\tbest = o.best; best_id = o.id; rg.lo = o.lo; rg.hi = o.hi; nan |= o.nan;\n\t}\n};\n", name, fast && fast->fdiv_ok ? "true" : "false", name);
+		s += "\t\treturn { best, best_id, rg.lo, rg.hi, nanacc };\n}\n";
+		snprintf(line, sizeof line, "struct %s {\n\tstatic constexpr bool ASSUME_SETTLED = %s;\n\tRange rg;\n\tfloat nanacc = 0.f;\n"
+		         "\t__device__ __forceinline__ void loop_done() {}\n"
+		         "\t__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id) {\n"
+		         "\t\tconst SdfOut o = %s_fn(p.x, p.y, p.z, rg.lo, rg.hi);\n"
+		         "\t\tbest = o.best; best_id = o.id; rg.lo = o.lo; rg.hi = o.hi; nanacc += o.nanacc;\n\t}\n};\n", name, fast ? "true" : "false", name);
 		s += line;
 	} else {
 		s += "\t}\n};\n";
@@ -1247,6 +1309,8 @@ constexpr uint32_t LOL_SPEC_INLINE_MAX_OPS = 1024;
 /* ... and above THIS many ops the inlined form is the scene's SECOND kernel: the out-of-line form, which hipRTC delivers 3 - 6
  * times sooner, renders until it is there (start_specialise) */
 constexpr uint32_t LOL_SPEC_FIRST_TIER_INLINE_MAX_OPS = 256;
+/* ... and up to THIS many ops the module holds the pipeline twice: with and without the per-lane step counters (generate_source) */
+constexpr uint32_t LOL_SPEC_TWO_KERNELS_MAX_OPS = 256;
 /* specialise(): larger scenes stay on the interpreter.  The scene compiler cannot be interrupted, lol_gpu_destroy has to wait
  * for it, and a second upload's run queues behind it — so what it takes on is bounded by what was MEASURED as tolerable
  * (profiles/r4_big_scene_probe.jsonl, fields of N objects on the GPU box: 5.3 s at 1320 ops, 14.6 s at 2640, 40.7 s at 5060,
@@ -1283,7 +1347,7 @@ std::string generate_source(const lol_program& P, const FastPaths* fast, bool cu
 		if (sscanf(e, "%d,%d", &lo, &hi) == 2 && lo >= 1 && hi >= lo && hi <= 8) { waves_lo = lo; waves_hi = hi; }
 	}
 	const std::string occupancy = " __attribute__((amdgpu_waves_per_eu(" + std::to_string(waves_lo) + ", " + std::to_string(waves_hi) + ")))";
-	if (ool) s += "struct SdfOut { float best; u32 id; u32 lo, hi; u64 nan; };\n";
+	if (ool) s += "struct SdfOut { float best; u32 id; u32 lo, hi; float nanacc; };\n";
 	emit_sdf(s, P, "SpecSdfExact", nullptr, ool, roots, plan, occupancy);
 	const bool any_fast = fast && (fast->sqrt_kind || !fast->div_ok.empty());
 	if (any_fast) emit_sdf(s, P, "SpecSdfFast", fast, ool, roots, plan, occupancy);
@@ -1291,26 +1355,42 @@ std::string generate_source(const lol_program& P, const FastPaths* fast, bool cu
 	/* where lights / materials are read from is a property of the scene too (lol_kernel.h, TABLES_LDS_MAX_DWORDS) */
 	const bool tables_global = !lol::tables_in_lds(P.n_lights, P.n_materials, P.n_roots);
 	const std::string tg = tables_global ? "true" : "false";
-	s += "extern \"C\" __global__ __launch_bounds__(lol::BLOCK)" + occupancy + " void lol_render_spec(const lol::Launch L) {\n";
-	s += "\textern __shared__ lol::u32 lds[];\n";
+	/* The pipeline once as a template on COUNT (lol_kernel.h, march: the per-lane step counters), and as one or two kernels:
+	 *   lol_render_spec_steps  counts steps: frames with diagnostics (lol_gpu_debug::steps) and the one frame of a view that records
+	 *                          what its pixels cost (lol_gpu.hip, "pixels dealt by cost");
+	 *   lol_render_spec        does not (+1.3 % on C3): every other frame.
+	 * A scene above LOL_SPEC_TWO_KERNELS_MAX_OPS gets the counting kernel alone, under the name lol_render_spec: a second copy of
+	 * its pipeline would nearly double what the compiler takes for it. */
+	const bool two = P.n_ops <= LOL_SPEC_TWO_KERNELS_MAX_OPS;
+	s += "template <bool COUNT> __device__ __forceinline__ void lol_spec_body(const lol::Launch& L, lol::u32* lds) {\n";
 	if (!tables_global) {
 		s += "\tlol::stage_common(L, lds);\n";
 		s += "\t__syncthreads();\n";
 	}
 	s += "\tif (!lol::start_tile_clock<" + tg + ">(L, lds)) return;\n";
 	if (any_fast) {
-		s += "\tlol::SpecSdfFast fast;\n";
-		s += "\tlol::Pixel P = lol::shade_pixel<lol::SpecSdfFast, " + tg + ">(L, fast, lds);\n";
-		s += "\tif (lol::unproven(fast)) {\n";
+		/* the fast pipeline takes FLAG_SHADOW_SETTLED for granted (lol_kernel.h, soft_shadow): a launch without it is the plain pipeline's */
+		s += "\tlol::Pixel P;\n";
+		s += "\tbool plain = !(L.flags & lol::FLAG_SHADOW_SETTLED);\n";
+		s += "\tif (!plain) {\n";
+		s += "\t\tlol::SpecSdfFast fast;\n";
+		s += "\t\tP = lol::shade_pixel<lol::SpecSdfFast, " + tg + ", COUNT>(L, fast, lds);\n";
+		s += "\t\tplain = lol::unproven(fast);\n";
+		s += "\t}\n";
+		s += "\tif (plain) {\n";
 		s += "\t\tlol::SpecSdfExact exact;\n";
-		s += "\t\tP = lol::shade_pixel<lol::SpecSdfExact, " + tg + ">(L, exact, lds);\n";
+		s += "\t\tP = lol::shade_pixel<lol::SpecSdfExact, " + tg + ", COUNT>(L, exact, lds);\n";
 		s += "\t}\n";
 	} else {
 		s += "\tlol::SpecSdfExact exact;\n";
-		s += "\tlol::Pixel P = lol::shade_pixel<lol::SpecSdfExact, " + tg + ">(L, exact, lds);\n";
+		s += "\tlol::Pixel P = lol::shade_pixel<lol::SpecSdfExact, " + tg + ", COUNT>(L, exact, lds);\n";
 	}
 	s += "\tlol::store_pixel<" + tg + ">(L, P, lds);\n";
 	s += "}\n";
+	const std::string head = "extern \"C\" __global__ __launch_bounds__(lol::BLOCK)" + occupancy + " void ";
+	const std::string tail = "(const lol::Launch L) {\n\textern __shared__ lol::u32 lds[];\n\tlol_spec_body<";
+	if (two) s += head + "lol_render_spec_steps" + tail + "true>(L, lds);\n}\n";
+	s += head + "lol_render_spec" + tail + (two ? "false" : "true") + ">(L, lds);\n}\n";
 	/* the SDF alone at arbitrary points (lol_gpu_sdf_batch) */
 	s += "extern \"C\" __global__ __launch_bounds__(64) void lol_sdf_spec(const float* pts, float* dist, lol::u32* id, lol::u32 n) {\n";
 	s += "\tlol::SpecSdfExact exact;\n";
@@ -1508,9 +1588,7 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
 		 * ever (found in round 4 when scenes lost their 1024-op capacity: the kernel never finished; ROCm 7.0 and 7.2 alike).
 		 * With the factor 0 no register is reserved and the branch relaxation scavenges a dead one at the branch, correctly.
 		 * has_return_clobbering_branch() below refuses any code object that still shows the pattern. */
-		/* (LOL_GPU_LONG_BRANCH_REG=1 leaves LLVM's default in place: for the test that sees the tripwire refuse the result) */
-		const char* lbr = tuning_env("LOL_GPU_LONG_BRANCH_REG");
-		if (!(lbr && lbr[0] == '1')) { opts.push_back("-mllvm"); opts.push_back("-amdgpu-long-branch-factor=0"); }
+		opts.push_back("-mllvm"); opts.push_back("-amdgpu-long-branch-factor=0");
 	}
 	char d0[32], d1[32], d2[32];
 	if (shape) {
@@ -1624,7 +1702,7 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
  * code.  (A second context of a host — a second window, the ranks of a test — then spends its render_prepare on the scene.) */
 struct DeviceProofs {
 	int  sqrt_verified = -1; bool sqrt_tiny_ok = false;
-	int  fdiv_verified = -1, gamma_verified = -1;
+	int  gamma_verified = -1;
 	std::vector<lol_gpu::DivProof> div;
 };
 std::mutex g_proofs_mutex;
@@ -1636,7 +1714,6 @@ void proofs_from_process(lol_gpu* ctx) {
 	if (it == g_proofs.end()) return;
 	const DeviceProofs& P = it->second;
 	if (ctx->sqrt_verified < 0 && P.sqrt_verified >= 0) { ctx->sqrt_verified = P.sqrt_verified; ctx->sqrt_tiny_ok = P.sqrt_tiny_ok; }
-	if (ctx->fdiv_verified < 0) ctx->fdiv_verified = P.fdiv_verified;
 	if (ctx->gamma_verified < 0) ctx->gamma_verified = P.gamma_verified;
 	for (const auto& e : P.div) {
 		bool known = false;
@@ -1648,7 +1725,6 @@ void proofs_to_process(const lol_gpu* ctx) {
 	std::lock_guard<std::mutex> lock(g_proofs_mutex);
 	DeviceProofs& P = g_proofs[ctx->device];
 	if (ctx->sqrt_verified >= 0) { P.sqrt_verified = ctx->sqrt_verified; P.sqrt_tiny_ok = ctx->sqrt_tiny_ok; }
-	if (ctx->fdiv_verified >= 0) P.fdiv_verified = ctx->fdiv_verified;
 	if (ctx->gamma_verified >= 0) P.gamma_verified = ctx->gamma_verified;
 	for (const auto& e : ctx->div_verified) {
 		bool known = false;
@@ -1679,13 +1755,6 @@ FastPaths prove_fast_paths(lol_gpu* ctx, const lol_program& prog) {
 			else if (ctx->gamma_verified == 1 && !ctx->d_gamma && !build_gamma_table(ctx)) ctx->gamma_verified = 0;      /* proven by another context of this device: only the table */
 			fast.gamma_ok = ctx->gamma_verified == 1;
 		}
-	}
-	/* The shadow march's division shortcut (lol_kernel.h, fdiv_fast) is OFF unless LOL_GPU_SHADOW_FDIV=1: exact, but it bought
-	 * C3 0.95 % in a same-call A/B (7854 vs 7779 Mpixels/s, profiles/r4_ab_fdiv.txt), below the 1.5 % the review set as the bar
-	 * for keeping it in the default kernel.  Asked for, it is still only used after this device's own sweep agrees. */
-	if (tuning_env("LOL_GPU_SHADOW_FDIV") && tuning_env("LOL_GPU_SHADOW_FDIV")[0] == '1') {
-		if (ctx->fdiv_verified < 0) ctx->fdiv_verified = run_verify(ctx, -1, 0.f) == 0 ? 1 : 0;      /* (seed 0 travels as the bits of k = 0) */
-		fast.fdiv_ok = ctx->fdiv_verified == 1;
 	}
 	for (uint32_t i = 0; i < prog.n_ops; i++) {
 		const lol_op& o = prog.ops[i];
@@ -1746,7 +1815,7 @@ void start_specialise(lol_gpu* ctx, const FastPaths& fast) {
 	if (ctx->spec_module_old) { (void)hipModuleUnload(ctx->spec_module_old); ctx->spec_module_old = nullptr; }
 	ctx->second_tier_pending = ctx->second_tier_running = false;
 	ctx->kernel_epoch++;                                /* the interpreter renders the new scene until its kernel is there */
-	ctx->spec_fn = nullptr;
+	ctx->spec_fn = ctx->spec_steps_fn = nullptr;
 	ctx->spec_sdf_fn = nullptr;
 	snprintf(ctx->kernel_name, sizeof ctx->kernel_name, "render_interp");
 	ctx->spec_log.clear();
@@ -1862,12 +1931,40 @@ bool finish_specialise(lol_gpu* ctx, bool wait) {
 		const bool second = ctx->second_tier_running;
 		ctx->second_tier_running = false;
 		changed = true;
+		/* the scene's second run (the form with the SDF inlined) behind the first: same program, proofs, shape */
+		auto start_second_tier = [&]() {
+			ctx->second_tier_pending = false;
+			SpecJob* next = nullptr;
+			try {
+				next = new SpecJob;
+				next->prog = job->prog; next->fast = job->fast; next->arch = job->arch; next->cull = job->cull;
+				memcpy(next->shape, job->shape, sizeof next->shape);
+				next->form = SPEC_INLINE;
+			} catch (...) { delete next; next = nullptr; }
+			if (!next) return false;
+			ctx->job = next;
+			ctx->second_tier_running = true;
+			try { launch_job(next); } catch (...) { ctx->job = nullptr; ctx->second_tier_running = false; delete next; return false; }
+			return true;
+		};
 		/* an unexpected failure is reported once on stderr: frames still render, through the (slower) interpreter — or, when it
-		 * is the second run that failed, through the first run's kernel, which stays */
+		 * is the second run that failed, through the first run's kernel, which stays.  A FIRST run that fails where a second was
+		 * to follow (257 ... 1024 ops: the out-of-line form, the one the long-branch trip-wire and the dropped-options refusal of
+		 * compile_spec are about) does not cost the scene its kernel: the inlined form, which has no out-of-line function to
+		 * trip them, is compiled all the same while the interpreter renders (round-5 advisor). */
 		auto complain = [&](const std::string& why) {
 			if (second) {
-				ctx->spec_log += "(the inlined form of the kernel was not to be had: " + why + "; the out-of-line form stays)\n";
-				ctx->spec_state = 2;
+				if (ctx->spec_fn) {
+					ctx->spec_log += "(the inlined form of the kernel was not to be had: " + why + "; the out-of-line form stays)\n";
+					ctx->spec_state = 2;
+				} else {
+					ctx->spec_log += "(nor was the inlined form: " + why + ")\n";
+					ctx->spec_state = -1;
+					fprintf(stderr, "lol_gpu: scene specialisation failed, using the interpreter kernel: %s\n", ctx->spec_log.c_str());
+				}
+			} else if (ctx->second_tier_pending && start_second_tier()) {
+				ctx->spec_log = "(the out-of-line form of the kernel was not to be had: " + why + "; compiling the inlined form)\n";
+				ctx->spec_state = 1;
 			} else {
 				ctx->spec_log = why;
 				ctx->spec_state = -1;
@@ -1876,15 +1973,22 @@ bool finish_specialise(lol_gpu* ctx, bool wait) {
 			}
 			delete job;
 		};
-		if (!job->ok) { complain(job->log); return true; }
+		if (!second && ctx->second_tier_pending && ctx->fail_first_tier > 0) {      /* lol_gpu_testing_fail_first_tier */
+			ctx->fail_first_tier--;
+			job->ok = false;
+			job->log = "injected failure of the first run (lol_gpu_testing_fail_first_tier)";
+		}
+		if (!job->ok) { complain(job->log); if (!wait || !ctx->job) return true; continue; }
 		hipModule_t mod = nullptr;
-		hipFunction_t fn = nullptr, sdf_fn = nullptr;
-		if (hipModuleLoadData(&mod, job->code.data()) != hipSuccess) { complain("hipModuleLoadData failed"); return true; }
+		hipFunction_t fn = nullptr, steps_fn = nullptr, sdf_fn = nullptr;
+		if (hipModuleLoadData(&mod, job->code.data()) != hipSuccess) { complain("hipModuleLoadData failed"); if (!wait || !ctx->job) return true; continue; }
 		if (hipModuleGetFunction(&fn, mod, "lol_render_spec") != hipSuccess) {
 			(void)hipModuleUnload(mod);
 			complain("lol_render_spec not found in the compiled module");
-			return true;
+			if (!wait || !ctx->job) return true;
+			continue;
 		}
+		if (hipModuleGetFunction(&steps_fn, mod, "lol_render_spec_steps") != hipSuccess) steps_fn = nullptr;      /* (one kernel: it counts) */
 		if (hipModuleGetFunction(&sdf_fn, mod, "lol_sdf_spec") != hipSuccess) sdf_fn = nullptr;
 		if (ctx->spec_module) {
 			/* the first tier's module: frames launched through it may still be in flight, so it is only unloaded by the next
@@ -1894,6 +1998,7 @@ bool finish_specialise(lol_gpu* ctx, bool wait) {
 		}
 		ctx->spec_module = mod;
 		ctx->spec_fn = fn;
+		ctx->spec_steps_fn = steps_fn;
 		ctx->spec_sdf_fn = sdf_fn;
 		ctx->wave_w = job->shape[0]; ctx->wave_h = job->shape[1]; ctx->waves_x = job->shape[2];
 		ctx->spec_log = (second ? ctx->spec_log + "second tier (SDF inlined): " : job->note) + job->log + (job->log.empty() || job->log.back() == '\n' ? "" : "\n");
@@ -1901,23 +2006,8 @@ bool finish_specialise(lol_gpu* ctx, bool wait) {
 		ctx->spec_key = fnv_hex(job->code.data(), job->code.size());
 		ctx->spec_state = 2;
 		ctx->kernel_epoch++;
-		if (ctx->second_tier_pending) {
-			/* the out-of-line kernel renders from now on; the inlined form is compiled behind it */
-			ctx->second_tier_pending = false;
-			SpecJob* next = nullptr;
-			try {
-				next = new SpecJob;
-				next->prog = job->prog; next->fast = job->fast; next->arch = job->arch; next->cull = job->cull;
-				memcpy(next->shape, job->shape, sizeof next->shape);
-				next->form = SPEC_INLINE;
-			} catch (...) { delete next; next = nullptr; }
-			if (next) {
-				ctx->job = next;
-				ctx->second_tier_running = true;
-				ctx->spec_state = 5;
-				try { launch_job(next); } catch (...) { ctx->job = nullptr; ctx->second_tier_running = false; ctx->spec_state = 2; delete next; }
-			}
-		}
+		/* the out-of-line kernel renders from now on; the inlined form is compiled behind it */
+		if (ctx->second_tier_pending && start_second_tier()) ctx->spec_state = 5;
 		delete job;
 		if (!wait) return true;
 	}
@@ -2478,16 +2568,6 @@ int lol_gpu_verify_fast_paths(lol_gpu* ctx, float k, unsigned long long sqrt_mis
 	return LOL_GPU_OK;
 }
 
-/* ... and for the shadow march's division (fdiv_fast against '/', verify_fdiv_kernel): mismatches over the 2^32 quotients of
- * the sweep `seed` selects (0 = the fixed corners the context itself checks; anything else = pseudo-random exponents and
- * divisor mantissas inside the box) */
-int lol_gpu_verify_shadow_division(lol_gpu* ctx, uint32_t seed, unsigned long long* mismatches) {
-	if (!ctx || !mismatches) return LOL_GPU_ERR_ARG;
-	LOL_HIP(ctx, hipSetDevice(ctx->device));
-	*mismatches = run_verify(ctx, -1, __builtin_bit_cast(float, seed));
-	return LOL_GPU_OK;
-}
-
 /* ... and for the blend factor without v_div_fixup (smin_h_fast<false>): inputs on which it differs from the exact
  * factor (finite and NaN dlt) or fails to turn the smooth minimum NaN (dlt = +-inf); 0 = proven, ~0 = could not run */
 int lol_gpu_verify_smin_no_fixup(lol_gpu* ctx, float k, unsigned long long* mismatches) {
@@ -2627,7 +2707,7 @@ static int upload_program(lol_gpu* ctx, const lol_program* prog) {
 	{
 		/* what render_interp executes = this build's code (lol_kernel.h AND this file: record layout, flags) + the lists */
 		std::string id = std::string(LOL_BUILD_ID) + "|" + fnv_hex(mops.data(), mops.size() * 4) + "|" + std::to_string(interp_sqrt_kind) +
-		                 (fast.fdiv_ok ? "|fdiv" : "") + (fast.gamma_ok ? "|gamma" : "");
+		                 (fast.gamma_ok ? "|gamma" : "");
 		interp_key = fnv_hex(id.data(), id.size());
 	}
 	ctx->h_own.assign(*prog);                         /* the last fallible step (host memory; all or nothing itself): the old scene is intact until here */
@@ -2638,7 +2718,6 @@ static int upload_program(lol_gpu* ctx, const lol_program* prog) {
 	ctx->n_mops = n_mops;
 	ctx->finite_scene = shadow_settle_ok(*prog);
 	ctx->interp_sqrt_kind = interp_sqrt_kind;
-	ctx->shadow_fdiv = fast.fdiv_ok;
 	ctx->gamma_table = fast.gamma_ok;
 	ctx->interp_key.swap(interp_key);
 	resolve_skips(ctx);
@@ -2694,8 +2773,9 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	L.root_material = L.materials + (size_t)P.n_materials * lol::MATERIAL_DWORDS;
 	L.ambient[0] = P.ambient_color.x; L.ambient[1] = P.ambient_color.y; L.ambient[2] = P.ambient_color.z;
 	L.flags = (ctx->miss_skip ? lol::FLAG_MISS_SKIP : 0u) | (ctx->dark_skip ? lol::FLAG_DARK_SKIP : 0u) |
-	          (ctx->shadow_settle && camera_sane(*cam) ? lol::FLAG_SHADOW_SETTLED | (ctx->shadow_fdiv ? lol::FLAG_SHADOW_FDIV : 0u) : 0u);
+	          (ctx->shadow_settle && camera_sane(*cam) ? lol::FLAG_SHADOW_SETTLED : 0u);
 	if (ctx->gamma_table) { L.flags |= lol::FLAG_GAMMA_TABLE; L.gamma_table = ctx->d_gamma; }
+	if (first_step(ctx, *cam, max_steps)) { L.flags |= lol::FLAG_FIRST_STEP; L.first_dist = ctx->first_dist; L.first_id = ctx->first_id; }
 	L.dst = static_cast<uint32_t*>(dst);
 	L.pitch_px = (uint32_t)(pitch_bytes / 4);
 	L.fmt_shift = ctx->fmt_shift; L.fmt_loss = ctx->fmt_loss; L.fmt_amask = ctx->fmt_amask;
@@ -2744,7 +2824,9 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	}
 	if (ctx->spec_fn) {
 		void* args[] = { &L };
-		e = hipModuleLaunchKernel(ctx->spec_fn, grid.x, grid.y, 1, block, 1, 1, (unsigned)common, s, args, nullptr);
+		/* the step counters are compiled into lol_render_spec_steps alone (generate_source): who reads them gets that kernel */
+		const bool counts = (dbg && dbg->steps) || L.pixel_cost;
+		e = hipModuleLaunchKernel(counts && ctx->spec_steps_fn ? ctx->spec_steps_fn : ctx->spec_fn, grid.x, grid.y, 1, block, 1, 1, (unsigned)common, s, args, nullptr);
 	} else {
 		const int kind = ctx->interp_sqrt_kind;
 		const int cls = interp_stack_class(P.max_stack);
@@ -3016,6 +3098,12 @@ int lol_gpu_testing_has_return_clobbering_branch(const void* code, size_t n_byte
 	return has_return_clobbering_branch(code, n_bytes) ? 1 : 0;
 }
 
+int lol_gpu_testing_fail_first_tier(lol_gpu* ctx, int n) {
+	if (!ctx || n < 0) return LOL_GPU_ERR_ARG;
+	ctx->fail_first_tier = n;
+	return LOL_GPU_OK;
+}
+
 int lol_gpu_testing_fail_uploads(lol_gpu* ctx, int n) {
 	if (!ctx || n < 0) return LOL_GPU_ERR_ARG;
 	ctx->fail_uploads = n;
@@ -3068,7 +3156,6 @@ int lol_gpu_compile_offline(const lol_program* prog, const char* arch, const cha
 	if (assume_fast) {                 /* ISA inspection only: pretend every shortcut was proven */
 		fast.sqrt_kind = assume_fast >= 1 && assume_fast <= 3 ? 4 - assume_fast : 3;   /* 1 → sqrt_r2, 2 → sqrt_gs, 3 → sqrt_pm */
 		fast.sqrt_tiny_ok = true;
-		fast.fdiv_ok = true;
 		for (uint32_t i = 0; i < prog->n_ops; i++)
 			if ((prog->ops[i].op == LOL_OP_SMIN || prog->ops[i].op == LOL_OP_SMIN_R) && !fast.has(prog->ops[i].f[0]))
 				{ fast.div_ok.push_back(prog->ops[i].f[0]); fast.div_nf_ok.push_back(prog->ops[i].f[0]); }

@@ -21,9 +21,10 @@
  * Both use the same pipeline below, so they produce the same bits.
  *
  * Shape of the code on a 64-wide wavefront:
- *  - control flow is wave-uniform: the march / shadow loops run while
- *    vote(alive) != 0 and lanes that have hit or escaped keep their state
- *    by predication;
+ *  - the march / shadow loops are per-lane loops: a lane that has hit, escaped or settled leaves
+ *    EXEC (s_andn2 exec + s_cbranch_execnz — the wave goes on while any lane is left) and its
+ *    state stays in its registers untouched; everything INSIDE an SDF evaluation is wave-uniform
+ *    (skips are taken when the ballot of the lanes still in EXEC allows them);
  *  - lights and materials are staged once per block into LDS and read back
  *    with wave-uniform (lights) or per-lane (material of the hit) addresses;
  *  - pixels are written through an LDS tile so each wave stores whole row
@@ -70,7 +71,8 @@ constexpr u32 FLAG_TILE_COLS = 8u;   /* the launch grid is transposed: tiles are
 constexpr u32 FLAG_SHADOW_SETTLED = 4u;   /* a shadow march ends as soon as its factor can only be 0 (soft_shadow) */
 constexpr u32 FLAG_TILE_TABLE = 32u;      /* a one-dimensional grid of one-wave blocks: block b shades the 64 pixels of wave slot Launch::tile_order[b] of the
                                            * pixel table Launch::lane_pixels (pixels dealt to waves by cost, waves handed out longest first: lol_gpu.hip) */
-constexpr u32 FLAG_SHADOW_FDIV = 16u;     /* with FLAG_SHADOW_SETTLED: 50 s / t by fdiv_fast where the Sdf policy allows it (soft_shadow) */
+constexpr u32 FLAG_FIRST_STEP = 128u;     /* Launch::first_dist / first_id hold sdf(camera origin): the primary march's first step, the same for every
+                                           * pixel (naive_renderer.c:56-57 with dist = 0), is not taken again per pixel (march) */
 constexpr u32 FLAG_GAMMA_TABLE = 64u;     /* gamma + quantisation of a channel through Launch::gamma_table (gamma_u8_table), proven equal to the
                                            * powf route on this device for every float in [0, 1] (lol_gpu.hip, verify_gamma_kernel) */
 
@@ -113,6 +115,8 @@ struct Launch {
 	const u32* lane_pixels;
 	unsigned short* pixel_cost;
 	const float* gamma_table;    /* FLAG_GAMMA_TABLE: GAMMA_LEVELS + 1 thresholds (gamma_u8_table) */
+	float  first_dist;           /* FLAG_FIRST_STEP: sdf(cam.origin) ... */
+	u32    first_id;             /* ... and the object it belongs to (lol_gpu.hip, first_step) */
 };
 constexpr u32 LANE_PADDING = 1u << 31;
 
@@ -172,13 +176,33 @@ struct V3 { float x, y, z; };
 /* Wave vote.  The compiler turns a vote on a COMPARISON into that comparison writing its lane mask to an SGPR pair,
  * but a vote on anything else — `a && b`, a bool carried around a loop — is first materialised as 0 / 1 in a VGPR
  * (v_cndmask) and compared again (v_cmp_ne): two half-rate instructions and a hazard nop per vote, and this pipeline
- * votes six times per SDF evaluation.  So votes are only ever taken on single comparisons and combined as masks on
- * the scalar side: "which lanes still care" travels as a mask (`care`), not as a per-lane bool. */
+ * votes several times per SDF evaluation.  So votes are only ever taken on single comparisons and combined as masks on
+ * the scalar side.  Inside the march / shadow loops a ballot covers the lanes still in EXEC — the ones still marching. */
 typedef unsigned long long u64;
 __device__ __forceinline__ u64 vote(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 __device__ __forceinline__ float minf_(float a, float b) { return a < b ? a : b; }   /* MINSS: b on NaN/equal */
 __device__ __forceinline__ float maxf_(float a, float b) { return a > b ? a : b; }   /* MAXSS */
+/* v_min_f32 itself (fminf would first canonicalise an operand the compiler cannot prove quiet: one more instruction) */
+__device__ __forceinline__ float vmin_(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	float r;
+	asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+#else
+	return __builtin_fminf(a, b);
+#endif
+}
+/* max(x, -0.f) as one v_max_f32 */
+__device__ __forceinline__ float vmax_neg0_(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	float r;
+	asm("v_max_f32 %0, 0x80000000, %1" : "=v"(r) : "v"(x));
+	return r;
+#else
+	return __builtin_fmaxf(x, -0.f);
+#endif
+}
 __device__ __forceinline__ float clampf_(float v, float lo, float hi) { return minf_(maxf_(v, lo), hi); }
 
 __device__ __forceinline__ V3 add(V3 a, V3 b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }
@@ -457,17 +481,34 @@ __device__ __forceinline__ float sminf_fastdiv(float a, float b, float k, float 
  *   dlt <= -ks  =>  .5f + q < 0 and h == +0:                                   result = (b - dlt*0) - k*0*1  = b - dlt*0.f
  * (dlt*0.f is kept: it is -0, or NaN for dlt = -inf, exactly as in the full expression).  verify_div_kernel checks
  * both implications for every float dlt on the device next to the proof of smin_h_fast.  The shortcut is taken per
- * WAVE — when every lane that still cares is saturated — so it costs one compare and a scalar branch where it does
+ * WAVE — when every lane (in EXEC) is saturated — so it costs one compare and a scalar branch where it does
  * not apply: two spheres more than k apart in distance is the common case away from the seams of a blob
- * (scene4 C3: +8.7 %).  NaN dlt is never saturated. */
+ * (scene4 C3: +8.7 %).  NaN dlt is never saturated.  "Every lane" = every lane in EXEC: inside the march and shadow loops the
+ * lanes still marching. */
 template <bool FIXUP = true>
-__device__ __forceinline__ float sminf_fastdiv_sat(float a, float b, float k, float k2, float hrk, float ks, u64 care) {
+__device__ __forceinline__ float sminf_fastdiv_sat(float a, float b, float k, float k2, float hrk, float ks) {
 	const float dlt = b - a;
-	if ((vote(!(__builtin_fabsf(dlt) >= ks)) & care) == 0) {
+	if (vote(!(__builtin_fabsf(dlt) >= ks)) == 0) {
 		asm volatile("");                         /* keep the branch: if-converted, every evaluation would pay for both sides */
 		const float r1 = b - dlt;
 		const float r0 = b - dlt * 0.f;
 		return dlt > 0.f ? r1 : r0;
+	}
+	const float h = smin_h_fast<FIXUP>(dlt, k2, hrk);
+	return (b - dlt * h) - k * h * (1.f - h);
+}
+/* ... and where both operands are known to be finite or NaN — spheres on the proven root without range tracker (a squared
+ * length that overflows gives NaN there, never inf: sd_sphere_fast_nr) and smooth minima of such — so that a saturated dlt
+ * (|dlt| >= ks > 0; NaN is never saturated) is finite and not 0:
+ *   dlt > 0:  b - dlt;      dlt < 0:  b - dlt*0.f = b - (-0.f)      i.e.  b - max(dlt, -0.f)
+ * two full-rate instructions for the multiply, compare, select and subtract above (round 6: +0.9 % on C3, +1.7 % for a new
+ * view; profiles/r6_ab2.txt).  lol_gpu.hip (emit_sdf: Node::fon) decides per smooth union which form is generated. */
+template <bool FIXUP = true>
+__device__ __forceinline__ float sminf_fastdiv_sat2(float a, float b, float k, float k2, float hrk, float ks) {
+	const float dlt = b - a;
+	if (vote(!(__builtin_fabsf(dlt) >= ks)) == 0) {
+		asm volatile("");
+		return b - vmax_neg0_(dlt);
 	}
 	const float h = smin_h_fast<FIXUP>(dlt, k2, hrk);
 	return (b - dlt * h) - k * h * (1.f - h);
@@ -507,31 +548,6 @@ __device__ __forceinline__ float sd_round_box_fast(V3 p, float cx, float cy, flo
 	float root = sqrt_fast<KIND>(l2s);
 	root = l2 == 0.f ? 0.f : root;
 	return root + minf_(maxf_(q.x, maxf_(q.y, q.z)), 0.f) - r;
-}
-
-/* 50 s / t of the shadow march (naive_renderer.c:83) without v_div_scale x 2, v_div_fmas and v_div_fixup: exactly the
- * sequence hipcc emits for a correctly rounded `/` — reciprocal, one Newton step on it, quotient, two residual corrections,
- * the last one fused — minus the scaling and the special-case fix-up around it.  By the ISA's definition of those three
- * instructions the sequences are THE SAME arithmetic whenever v_div_scale returns its operand unscaled (vcc = 0, so
- * v_div_fmas is a plain fma) and v_div_fixup hands its first operand through, i.e. for finite non-zero normal n, t with
- *   t not a denormal, 1/t not a denormal, n/t not a denormal, exponent(n) - exponent(t) < 96, biased exponent(n) > 23.
- * soft_shadow uses it for t in [2^-28, 2^58] and n = 50 s with n <= 0 (only the sign of the quotient is used then) or
- * n in [2^-60, 2^64], and establishes those ranges from what it marches (FDIV_* below); verify_fdiv_kernel (lol_gpu.hip)
- * holds the two sequences against each other on the device over all 2^23 mantissas of n for 512 combinations of exponents
- * and divisor mantissas spread over that box, corners included.  Saves 4 half-rate instructions of 13 per shadow step. */
-#ifndef LOL_FDIV_T_MIN
-#define LOL_FDIV_T_MIN 0x1p-28f      /* (tests compile the scene kernel with a huge value here to see the fallback take over) */
-#endif
-constexpr float FDIV_T_MIN = LOL_FDIV_T_MIN, FDIV_T_MAX = 0x1p58f, FDIV_RES_MIN = 0x1p-30f;
-__device__ __forceinline__ float fdiv_fast(float n, float t) {
-	float y = __builtin_amdgcn_rcpf(t);
-	const float e = __builtin_fmaf(-t, y, 1.0f);
-	y = __builtin_fmaf(e, y, y);
-	float q = n * y;
-	float r = __builtin_fmaf(-t, q, n);
-	q = __builtin_fmaf(r, y, q);
-	r = __builtin_fmaf(-t, q, n);
-	return __builtin_fmaf(r, y, q);
 }
 
 /* ------------------------------------------------------------ SDF interpreter
@@ -585,7 +601,7 @@ constexpr u32 MOP_NOFIXUP = 1u << 24;   /* with MOP_FASTDIV: the blend factor is
 /* Exact object culling (lol_gpu.hip, "exact culling") in the interpreter: a record that finishes a top-level object
  * (MOP_TOP) may carry MOPB_CULL_NEXT / MOPB_CULL_CHAIN — the NEXT record is then not a macro-op but a test's constants
  * {word 0 = CULLC_* flags, word 1 = how many records after it belong to the objects the test guards, f[2..4] = C,
- * f[5] = R', f[6] = K}; if every lane that cares may skip them, they are jumped over.  Runs nest (lol_gpu.hip, plan_culling):
+ * f[5] = R', f[6] = K}; if every lane in EXEC may skip them, they are jumped over.  Runs nest (lol_gpu.hip, plan_culling):
  * CULLC_NEXT says the record after this one is the test of a run nested in this one, CULLC_AFTER that the record
  * after the guarded ones is the test of the run that follows.  Lives in the rare TAIL branch, so ordinary records
  * pay nothing. */
@@ -627,21 +643,17 @@ struct Interp {
 	u32        n_mops;
 	Range      rg;       /* KIND != 0: range of the squared lengths given to the proven fast sqrt (see above) */
 	u32        cool;     /* evaluations left before a CULL_NEXT record tests again (wave-uniform) */
-	u64        nan = 0;  /* (the specialised SDF's "an untracked sphere went NaN" mask; never set here) */
+	float      nanacc = 0.f;  /* (the specialised SDF's "an object's value went NaN" accumulator; never set here) */
+	/* the fast pipeline of the SPECIALISED kernel takes FLAG_SHADOW_SETTLED for granted (soft_shadow); this one reads the flag */
+	static constexpr bool ASSUME_SETTLED = false;
+	/* `cool` is wave-uniform state that the march / shadow loops change while lanes leave them one by one: what comes out of
+	 * such a loop counts as per-lane for the compiler (it would travel in a VGPR and every later test of it would be a
+	 * per-lane branch).  The loops end by calling this: never testing — and testing at once — are both always allowed. */
+	__device__ __forceinline__ void loop_done() { cool = 0u; }
 
 	/* Inlined into the march / normal / shadow loops: as a real (noinline) function it was 8 % slower — arguments
 	 * travel in VGPRs and need v_readfirstlane, plus call / return and the callee's register shuffling. */
-	/* `care` stays a per-lane bool here and the loops around it vote on `alive` itself (MASKS = false): this kernel is
-	 * bound by its scalar side, where the mask bookkeeping of the other form costs more than the two vector
-	 * instructions per vote it saves (measured: -1.8 % with masks in round 2, -2 % in round 3; the specialised kernel +4.1 %).
-	 * (Handing the loop's own vote down as the mask: +0.5 % here, but the changed loop text cost the SPECIALISED kernel 2.4 %
-	 * on C2 — same instructions, another schedule.) */
-	static constexpr bool MASKS = false;
-	/* the shadow march keeps the plain division here (soft_shadow, fdiv_fast): this kernel is bound by its scalar side, and the
-	 * second division variant with its branch and votes in the loop cost it 9 % on C3 (4330 -> 3950 Mpixels/s, measured), the
-	 * four half-rate instructions it saves nothing */
-	static constexpr bool FAST_DIV = false;
-	__device__ __forceinline__ void eval(V3 p, float& best_out, u32& id_out, bool care = true) {
+	__device__ __forceinline__ void eval(V3 p, float& best_out, u32& id_out) {
 		/* everything the loop carries is a local: the trip count and the list pointer must stay provably
 		 * wave-uniform (scalar loop, scalar loads, scalar branches), which they do not when they live behind
 		 * `this` next to per-lane results written through references */
@@ -756,9 +768,9 @@ struct Interp {
 							const float cx = p.x - C(2), cy = p.y - C(3), cz = p.z - C(4);
 							const float l2 = (cx * cx + cy * cy) + cz * cz;
 							const float u = (best + C(5)) * C(6);
-							/* any lane that cares and may not skip (skip = l2 > u*u && u > 0).  One ballot per comparison, combined
+							/* any lane (in EXEC: still marching) that may not skip (skip = l2 > u*u && u > 0).  One ballot per comparison, combined
 							 * on the scalar side: the ballot of the compound condition went through a VGPR (v_cndmask + v_cmp_ne) */
-							const u64 needed = vote(care) & (vote(!(l2 > u * u)) | vote(!(u > 0.f)));
+							const u64 needed = vote(!(l2 > u * u)) | vote(!(u > 0.f));
 							cl = CULL_COOLDOWN + 1u;                        /* (one branch: `if (needed != 0)` after it cost a flag register) */
 							if (needed == 0) {
 								LOL_KEEP_BRANCH();
@@ -780,7 +792,7 @@ struct Interp {
 							const float cx = p.x - C(2), cy = p.y - C(3), cz = p.z - C(4);
 							const float l2 = (cx * cx + cy * cy) + cz * cz;
 							const float u = (best + C(5)) * C(6);
-							if ((vote(care) & (vote(!(l2 > u * u)) | vote(!(u > 0.f)))) == 0) {
+							if ((vote(!(l2 > u * u)) | vote(!(u > 0.f))) == 0) {
 								LOL_KEEP_BRANCH();
 								const u32 k = rec[1];
 								rec += k * MOP_DWORDS;
@@ -802,37 +814,51 @@ struct Interp {
 	}
 };
 
-/* did this wave's fast SDF leave what was proven for it (a squared length outside the fast root's domain, or a NaN
- * from a sphere that carries no range tracker)?  Then its results are not used. */
+/* did this wave's fast SDF leave what was proven for it (a squared length outside the fast root's domain, or a NaN / inf
+ * value of an object whose spheres carry no range tracker: nanacc = fma(value, 0, nanacc) stays 0 for finite values)?
+ * Then its results are not used. */
 template <class Sdf>
-__device__ __forceinline__ bool unproven(const Sdf& sdf) { return (vote(sdf.rg.outside()) | sdf.nan) != 0; }
+__device__ __forceinline__ bool unproven(const Sdf& sdf) { return (vote(sdf.rg.outside()) | vote(sdf.nanacc != sdf.nanacc)) != 0; }
 
 /* --------------------------------------------------------------- the pipeline */
 
 struct Hit { float dist; u32 id; u32 steps; };
 
-/* get_intersection, naive_renderer.c:48-69 */
-template <class Sdf>
-__device__ __forceinline__ Hit march(Sdf& sdf, V3 ro, V3 rd, int max_steps) {
+/* get_intersection, naive_renderer.c:48-69.
+ *
+ * A per-lane loop: a lane that has hit or escaped takes the `break`, i.e. leaves EXEC — its dist / id / steps stay where they
+ * are, no select keeps them — and the wave goes round while any lane is left (s_andn2 exec; s_cbranch_execnz).  Rounds 1 - 5
+ * kept the control flow wave-uniform instead (`while (vote(alive))`, every update a v_cndmask under `alive`): three selects and
+ * two extra compares per step at half rate; round 6 measured the plain loop +4.7 % on C3, +7 % on C2, +3 ... 4.7 % on the
+ * interpreter (profiles/r6_ab1.txt, r6_ab_interp.txt).  Inside sdf.eval every ballot now covers the marching lanes only, which
+ * is exactly what the "care" masks of those rounds were handed down for.
+ *
+ * FLAG_FIRST_STEP: step 0 evaluates the SDF at ro + rd * 0 = ro — the camera, the same point for every pixel of the frame — so the
+ * host passes that one value (lol_gpu.hip, first_step: computed once per camera position) and the loop starts at step 1.  What
+ * makes ro + rd * 0 equal ro bit for bit: rd finite (rd * 0 = +-0; checked here, per wave: a wave with a lane whose direction
+ * is not finite marches from step 0) and no component of ro a negative zero (-0 + +0 = +0; the host checks, with first_dist in
+ * [EPSILON, MAX_DIST] — a march that would end on its first step is left to the loop — and max_steps >= 1).
+ * Round 6: +1.9 % on C3, +1.2 % for a new view, +4 % with two frames in flight (profiles/r6_ab4.txt).
+ *
+ * COUNT = false compiles the step counters out (Hit::steps stays 0): only the diagnostics and the one frame of a view that
+ * records what its pixels cost read them (+1.3 %, profiles/r6_ab1.txt). */
+template <bool COUNT, class Sdf>
+__device__ __forceinline__ Hit march(Sdf& sdf, V3 ro, V3 rd, int max_steps, bool first_given, float first_dist, u32 first_id) {
 	const float EPSILON = 0.001f, MAX_DIST = 100.f;
-	float dist = 0.f;
-	u32 id = 0, steps = 0;
-	bool alive = true;
-	u64 marching = vote(true);                    /* `alive` as a mask (see vote()); kept up only where Sdf::MASKS */
-	for (int i = 0; i < max_steps; i++) {
-		if ((Sdf::MASKS ? marching : vote(alive)) == 0) break;       /* every lane has hit or escaped */
+	/* (a NaN or infinite component makes the squared length NaN or inf) */
+	const bool skip_first = first_given && vote(!(len2(rd) < 4.f)) == 0;
+	float dist = skip_first ? first_dist : 0.f;
+	u32 id = skip_first ? first_id : 0u, steps = skip_first ? 1u : 0u;
+	for (int i = skip_first ? 1 : 0; i < max_steps; i++) {
 		V3 p = add(ro, scale(rd, dist));
 		float d; u32 did;
-		/* lanes that are done do not care: they do not keep an object from being culled */
-		if constexpr (Sdf::MASKS) sdf.eval(p, d, did, marching); else sdf.eval(p, d, did, alive);
-		if (alive) {
-			dist += d;
-			id = did;
-			steps++;
-			if (d < EPSILON || dist > MAX_DIST) alive = false;
-		}
-		if constexpr (Sdf::MASKS) marching &= ~(vote(d < EPSILON) | vote(dist > MAX_DIST));     /* (finished lanes: bits already clear) */
+		sdf.eval(p, d, did);
+		dist += d;
+		id = did;
+		if (COUNT) steps++;
+		if (d < EPSILON || dist > MAX_DIST) break;
 	}
+	sdf.loop_done();
 	if (dist >= MAX_DIST) id = 0;
 	return { dist, id, steps };
 }
@@ -840,6 +866,8 @@ __device__ __forceinline__ Hit march(Sdf& sdf, V3 ro, V3 rd, int max_steps) {
 /* in_shadow + softshadow, naive_renderer.c:73-100.  dir/light_dist come from the caller,
  * which needs the same normalize(light - p) for the Phong term. */
 /*
+ * A per-lane loop like march(): lanes that do not need the factor never enter it, a lane whose march is over leaves EXEC.
+ *
  * `settled` (FLAG_SHADOW_SETTLED, wave-uniform): the march of a lane also ends once res <= 0.  The factor returned is
  * maxf(res, 0), and from res <= 0 on every further step can only keep it there: res' = minf(res, v) = (res < v ? res : v)
  * is <= 0 again for every v that is not NaN, and v = 50 s / t is NaN only for a non-finite s or t, or for 0 / 0 — which
@@ -849,47 +877,35 @@ __device__ __forceinline__ Hit march(Sdf& sdf, V3 ro, V3 rd, int max_steps) {
  * never <= 0).  The reference goes on until res < -1 or t > L; a ray that grazes along just inside a surface does so for
  * all 128 steps while its 63 neighbours wait.  Same pixels; the shadow step counts of lol_gpu_debug shrink.
  *
- * `fdiv` (FLAG_SHADOW_FDIV with `settled`, wave-uniform, Sdf::FAST_DIV): from the second step on the quotient is fdiv_fast's.
- * What makes its operands lie in the proven box, for every lane that is still marching at step i >= 1:
- *   - t.  Step 0 divides by t = 0 (the reference's +-inf / NaN semantics: always the plain division) and leaves t = s0.  A lane
- *     still marching afterwards has s0 >= 0, and every later step of a marching lane had s > 0 (with s <= 0 the quotient is
- *     <= 0, or NaN only for t = 0, and the lane is settled): t only grows.  So t >= s0, checked ONCE, at step 1: t >= 2^-28
- *     (a NaN res from s0 = 0 fails this check too); and t <= 2^58 is checked at the end.
- *   - n = 50 s <= 0: only `quotient <= 0` is used (the lane settles, the factor comes out 0) and fdiv_fast keeps the sign.
- *   - n > 0: n <= 50 (t + s) <= 2^64 by the bound on t; and every such quotient is >= the final res, so res >= 2^-30 at the
- *     end gives n >= 2^-30 t >= 2^-58 (below 2^-60 fdiv_fast could not have come out above 2^-31 either).
- * A wave with a lane outside these checks marks sdf.nan — like a sphere without range tracker that went NaN — and shades
- * its pixels again through the plain Sdf, whose FAST_DIV is false.
+ * Sdf::ASSUME_SETTLED (the specialised kernel's fast pipeline, which the kernel only enters under FLAG_SHADOW_SETTLED): the
+ * running minimum is ONE v_min_f32 instead of the compare + select of minf_ (float.h:6: the SECOND operand on NaN or
+ * equal).  The two differ in the sign of a zero result — which ends the march and comes out as maxf_(+-0, 0) = +0 — and for
+ * a NaN quotient, which under the flag's conditions is 0 / 0 of a first step with s == +-0 alone: t stays 0, the point never
+ * moves, the reference's factor is NaN for all 128 steps and comes out 0; here res stays 1 for the same 128 steps and
+ * `t == 0` names the case afterwards (a t that RETURNED to 0 did so on a step with 50 s / t = -50: the factor is 0 as well).
+ * Round 6: +0.5 % (profiles/r6_ab1.txt).
  */
-template <class Sdf>
-__device__ __forceinline__ float soft_shadow(Sdf& sdf, V3 p, V3 dir, float max_dist, u32& steps, bool needed, bool settled, bool fdiv_flag = false) {
+template <bool COUNT, class Sdf>
+__device__ __forceinline__ float soft_shadow(Sdf& sdf, V3 p, V3 dir, float max_dist, u32& steps, bool needed, bool settled) {
+	constexpr bool VMIN = Sdf::ASSUME_SETTLED;
 	V3 ro = add(p, dir);
 	float res = 1.f, t = 0.f;
-	const float stop_at = settled ? 0.f : -1.f;          /* res < -1 (naive_renderer.c:85), or res <= 0 */
-	const bool fdiv = Sdf::FAST_DIV && settled && fdiv_flag;
-	u64 out_of_box = 0;
-	bool alive = needed;          /* a lane that does not need the factor never marches (returns 1) */
-	u64 marching = Sdf::MASKS ? vote(needed) : 0;
-	for (int i = 0; i < 128; i++) {
-		const u64 live = Sdf::MASKS ? marching : vote(alive);
-		if (live == 0) break;
-		if constexpr (Sdf::FAST_DIV) if (fdiv && i == 1) out_of_box |= vote(!(t >= FDIV_T_MIN)) & live;
-		V3 q = add(ro, scale(dir, t));
-		float s; u32 sid;
-		if constexpr (Sdf::MASKS) sdf.eval(q, s, sid, marching); else sdf.eval(q, s, sid, alive);
-		if (alive) {
-			float v;
-			if (Sdf::FAST_DIV && fdiv && i != 0) v = fdiv_fast(50.f * s, t);
-			else v = 50.f * s / t;
-			res = minf_(res, v);
+	/* res < -1 (naive_renderer.c:85) is res <= the float below -1 for every res that is not NaN (and NaN fails both) */
+	const float stop = (VMIN || settled) ? 0.f : -0x1.000002p+0f;
+	if (needed) {
+		for (int i = 0; i < 128; i++) {
+			V3 q = add(ro, scale(dir, t));
+			float s; u32 sid;
+			sdf.eval(q, s, sid);
+			const float v = 50.f * s / t;
+			res = VMIN ? vmin_(res, v) : minf_(res, v);
 			t += s;
-			steps++;
-			if (res < -1.f || t > max_dist || (settled && res <= 0.f)) alive = false;
+			if (COUNT) steps++;
+			if (res <= stop || t > max_dist) break;
 		}
-		if constexpr (Sdf::MASKS) marching &= ~((settled ? vote(res <= stop_at) : vote(res < stop_at)) | vote(t > max_dist));
+		if (VMIN && t == 0.f) res = 0.f;
 	}
-	if constexpr (Sdf::FAST_DIV)
-		if (fdiv) sdf.nan |= out_of_box | (vote(res < FDIV_RES_MIN) & vote(res > 0.f)) | vote(!(t <= FDIV_T_MAX));
+	sdf.loop_done();
 	return maxf_(res, 0.f);
 }
 
@@ -951,7 +967,7 @@ __device__ __forceinline__ int frame_row(const Launch& L, int r) {
  * `lds` = lights | materials | root_material | out tile (already staged and synchronised); with TABLES_GLOBAL the
  * three tables are read from global memory instead (L.lights, L.materials, L.root_material) and `lds` is the tile alone.
  */
-template <class Sdf, bool TABLES_GLOBAL = false>
+template <class Sdf, bool TABLES_GLOBAL = false, bool COUNT = true>
 __device__ __forceinline__ Pixel shade_pixel(const Launch& L, Sdf& sdf, const u32* lds) {
 	const u32* l_light = TABLES_GLOBAL ? L.lights : lds;
 	const u32* l_mat   = TABLES_GLOBAL ? L.materials : l_light + L.n_lights * LIGHT_DWORDS;
@@ -986,7 +1002,7 @@ __device__ __forceinline__ Pixel shade_pixel(const Launch& L, Sdf& sdf, const u3
 	V3 rd = add(scale(v3(L.cam.right), vx * L.cam.width), scale(v3(L.cam.up), vy * L.cam.height));
 	rd = normalize(add(rd, cdir));
 
-	Hit hit = march(sdf, ro, rd, L.max_steps);
+	Hit hit = march<COUNT>(sdf, ro, rd, L.max_steps, (L.flags & FLAG_FIRST_STEP) != 0u, L.first_dist, L.first_id);
 
 	/* get_material, naive_renderer.c:103-112 (per-lane table lookups) */
 	u32 mid = hit.id ? l_rootm[hit.id - 1] : 0u;
@@ -1029,8 +1045,7 @@ __device__ __forceinline__ Pixel shade_pixel(const Launch& L, Sdf& sdf, const u3
 			bool needed = true;
 			if (L.flags & FLAG_DARK_SKIP) needed = di > 0.f;
 			if ((L.flags & FLAG_MISS_SKIP) && hit.id == 0u) needed = false;
-			float shadow = soft_shadow(sdf, p, light_dir, light_dist, shadow_steps, needed, (L.flags & FLAG_SHADOW_SETTLED) != 0u,
-			                           (L.flags & FLAG_SHADOW_FDIV) != 0u);
+			float shadow = soft_shadow<COUNT>(sdf, p, light_dir, light_dist, shadow_steps, needed, (L.flags & FLAG_SHADOW_SETTLED) != 0u);
 
 			V3 refl = sub(scale(n, 2.f * dot(light_dir, n)), light_dir);
 			V3 Id = mul(scale(lds_v3(lp + 3), shadow * di), m_diff);

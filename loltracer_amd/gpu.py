@@ -176,8 +176,6 @@ def gpu_lib() -> C.CDLL:
         lib.lol_gpu_verify_fast_paths.restype = C.c_int
         lib.lol_gpu_verify_smin_no_fixup.argtypes = [vp, C.c_float, P(C.c_ulonglong)]
         lib.lol_gpu_verify_smin_no_fixup.restype = C.c_int
-        lib.lol_gpu_verify_shadow_division.argtypes = [vp, C.c_uint32, P(C.c_ulonglong)]
-        lib.lol_gpu_verify_shadow_division.restype = C.c_int
         lib.lol_gpu_verify_gamma_table.argtypes = [vp, P(C.c_ulonglong), P(C.c_float)]
         lib.lol_gpu_verify_gamma_table.restype = C.c_int
         lib.lol_gpu_powf_batch.argtypes = [vp, vp, vp, vp, C.c_size_t, vp]
@@ -252,6 +250,8 @@ def gpu_lib() -> C.CDLL:
         # include/lol_gpu_testing.h
         lib.lol_gpu_testing_fail_uploads.argtypes = [vp, C.c_int]
         lib.lol_gpu_testing_fail_uploads.restype = C.c_int
+        lib.lol_gpu_testing_fail_first_tier.argtypes = [vp, C.c_int]
+        lib.lol_gpu_testing_fail_first_tier.restype = C.c_int
         lib.lol_gpu_testing_has_return_clobbering_branch.argtypes = [C.c_char_p, C.c_size_t]
         lib.lol_gpu_testing_has_return_clobbering_branch.restype = C.c_int
         lib.lol_gpu_multi_testing_root_stride.argtypes = [vp, C.c_int]
@@ -262,14 +262,14 @@ def gpu_lib() -> C.CDLL:
     return _lib
 
 
-TESTING_SYMBOLS = ["lol_gpu_testing_fail_uploads", "lol_gpu_testing_has_return_clobbering_branch", "lol_gpu_multi_testing_root_stride",
+TESTING_SYMBOLS = ["lol_gpu_testing_fail_uploads", "lol_gpu_testing_fail_first_tier", "lol_gpu_testing_has_return_clobbering_branch", "lol_gpu_multi_testing_root_stride",
                    "lol_gpu_multi_testing_force_copier_threads"]          # include/lol_gpu_testing.h
 
 EXPORTED_SYMBOLS = [
     "lol_gpu_abi_version", "lol_gpu_device_count", "lol_gpu_create", "lol_gpu_destroy", "lol_gpu_error", "lol_gpu_upload_program",
     "lol_gpu_part_rows", "lol_gpu_render_device", "lol_gpu_render_host", "lol_gpu_sync", "lol_gpu_malloc",
     "lol_gpu_free", "lol_gpu_memcpy_d2h", "lol_gpu_kernel_name", "lol_gpu_set_specialize",
-    "lol_gpu_specialize_log", "lol_gpu_specialize_wait", "lol_gpu_specialize_state", "lol_gpu_multi_specialize_wait", "lol_gpu_compile_offline", "lol_gpu_verify_fast_paths", "lol_gpu_verify_smin_no_fixup", "lol_gpu_verify_shadow_division", "lol_gpu_verify_gamma_table", "lol_gpu_set_miss_skip",
+    "lol_gpu_specialize_log", "lol_gpu_specialize_wait", "lol_gpu_specialize_state", "lol_gpu_multi_specialize_wait", "lol_gpu_compile_offline", "lol_gpu_verify_fast_paths", "lol_gpu_verify_smin_no_fixup", "lol_gpu_verify_gamma_table", "lol_gpu_set_miss_skip",
     "lol_gpu_miss_skip_active", "lol_gpu_set_exact_skips", "lol_gpu_powf_batch", "lol_gpu_device", "lol_gpu_sdf_batch", "lol_gpu_set_cull", "lol_gpu_set_tile_order", "lol_gpu_tile_order", "lol_gpu_cull_bounds", "lol_gpu_cull_bounds_clusters",
     "lol_gpu_render_host_begin", "lol_gpu_render_host_end", "lol_gpu_render_host_pending",
     "lol_gpu_multi_create", "lol_gpu_multi_destroy", "lol_gpu_multi_error", "lol_gpu_multi_device_count",
@@ -423,6 +423,10 @@ class Renderer:
     def kernel_key(self) -> str:
         return self._lib.lol_gpu_kernel_key(self._ctx).decode()
 
+    def testing_fail_first_tier(self, n: int):
+        """lol_gpu_testing_fail_first_tier: the next n out-of-line first runs of the scene compiler count as failed."""
+        self._check(self._lib.lol_gpu_testing_fail_first_tier(self._ctx, n))
+
     def testing_fail_uploads(self, n: int):
         """include/lol_gpu_testing.h: the next n uploads fail at their copy step."""
         self._check(self._lib.lol_gpu_testing_fail_uploads(self._ctx, n))
@@ -455,12 +459,6 @@ class Renderer:
         """Mismatch count of the blend factor without v_div_fixup over all 2^32 inputs; 0 means proven."""
         n = C.c_ulonglong()
         self._check(self._lib.lol_gpu_verify_smin_no_fixup(self._ctx, k, C.byref(n)))
-        return n.value
-
-    def verify_shadow_division(self, seed: int = 0) -> int:
-        """Mismatches of fdiv_fast against '/' over the 2^32 quotients of sweep `seed`; 0 means equal."""
-        n = C.c_ulonglong()
-        self._check(self._lib.lol_gpu_verify_shadow_division(self._ctx, seed, C.byref(n)))
         return n.value
 
     def verify_gamma_table(self):

@@ -177,9 +177,9 @@ def test_tuning_switches_are_fenced_and_recorded(tmp_path):
 
     plain, sw, err = run("plain")
     assert sw == "" and "LOL_GPU_TUNING" not in err
-    fenced, sw, err = run("fenced", LOL_GPU_RTC_FLAGS="-ffp-contract=fast", LOL_GPU_SCHED="default", LOL_GPU_LONG_BRANCH_REG="1")
+    fenced, sw, err = run("fenced", LOL_GPU_RTC_FLAGS="-ffp-contract=fast", LOL_GPU_SCHED="default", LOL_GPU_CULL="0")
     assert fenced == plain and sw == ""                            # same kernel, nothing in effect ...
-    for name in ("LOL_GPU_RTC_FLAGS", "LOL_GPU_SCHED", "LOL_GPU_LONG_BRANCH_REG"):
+    for name in ("LOL_GPU_RTC_FLAGS", "LOL_GPU_SCHED", "LOL_GPU_CULL"):
         assert f"{name} is set but LOL_GPU_TUNING=1 is not: ignored" in err      # ... and said so, once each
         assert err.count(name + " is set") == 1
     tuned, sw, err = run("tuned", LOL_GPU_TUNING="1", LOL_GPU_RTC_FLAGS="-ffp-contract=fast")
@@ -201,7 +201,9 @@ def test_small_scenes_keep_their_tables_in_lds_and_large_ones_do_not(tmp_path):
         base = str(tmp_path / ("f%d" % n))
         gpu.compile_offline(field(n).flatten(), base)
         src = open(base + ".hip").read()
-        assert ("shade_pixel<lol::SpecSdfExact, %s>" % want) in src and ("store_pixel<%s>" % want) in src, n
+        assert ("shade_pixel<lol::SpecSdfExact, %s, COUNT>" % want) in src and ("store_pixel<%s>" % want) in src, n
+        # (the pipeline with and without its step counters: two kernels for a small scene, the counting one alone for a large one)
+        assert ("lol_render_spec_steps" in src) == (field(n).flatten().n_ops <= 256), n
         assert ("stage_common" in src) == (want == "false")
 
 
@@ -221,12 +223,9 @@ def test_out_of_line_sdf_beyond_the_short_branch_range_is_compiled_correctly_or_
     getpc_ra = np.flatnonzero(words == 0xBE9E1C00)                 # s_getpc_b64 s[30:31]
     assert not any(words[i + 1] == 0x801EFF1E and words[i + 5] == 0xBE801D1E for i in getpc_ra if i + 5 < len(words))
     assert len(code) > 300_000                                     # the function really is beyond the short-branch range
-    # with LLVM's own default the pattern appears — and the library refuses the code object instead of handing out a hang
-    monkeypatch.setenv("LOL_GPU_LONG_BRANCH_REG", "1")
-    import pytest
-    with pytest.raises(gpu.GpuError) as e:
-        gpu.compile_offline(sc.flatten(), str(tmp_path / "bad"), assume_fast=True)
-    assert "return address" in str(e.value)
+    # (Rounds 4 - 5 also compiled this scene under LLVM's own default and saw the pattern appear and the library refuse the code
+    # object; with round 6's out-of-line function — one argument less — LLVM's default no longer picks s[30:31] for this scene, so
+    # the real instance is gone and the switch that kept the default reachable went with it.  The checker's own test follows.)
     # the checker itself on both code objects: clean with the workaround ...
     check = gpu.gpu_lib().lol_gpu_testing_has_return_clobbering_branch
     assert check(code, len(code)) == 0

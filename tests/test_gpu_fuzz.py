@@ -405,3 +405,27 @@ def test_both_tiers_of_mid_size_scenes_match_the_oracle(torch_cuda, monkeypatch)
         assert r.specialize_state()[0] == 2 and r.kernel_key() != key1 and "second tier" in r.specialize_log()
         check_against_oracle(g2, sc, w, h)
         r.close()
+
+
+def test_a_failed_first_tier_does_not_cost_the_scene_its_kernel(torch_cuda, monkeypatch):
+    """Round-5 advisor: when the FIRST run of a mid-size scene (the out-of-line form — the one the long-branch trip-wire and the
+    dropped-options refusal of compile_spec are about) fails, the inlined form is compiled all the same while the interpreter
+    renders; only when that fails too does the scene stay on the interpreter."""
+    import time
+    monkeypatch.setenv("LOL_GPU_CACHE_DIR", "")
+    sc = chain_scene(140, seed=int(time.time()) % 9941)
+    assert 256 < sc.flatten().n_ops <= 1024
+    w, h = 48, 28
+    r = gpu.Renderer(0)
+    r.testing_fail_first_tier(1)
+    r.prepare(sc, wait=False)
+    r.specialize_wait()
+    buf = torch_cuda.zeros((h, w), dtype=torch_cuda.int32, device="cuda")
+    r.render_into(buf.data_ptr(), w, h)
+    r.sync()
+    log = r.specialize_log()
+    assert r.kernel_name() == "lol_render_spec" and r.specialize_state()[0] == 2, (r.specialize_state(), log)
+    assert "out-of-line form of the kernel was not to be had" in log and "second tier" in log, log
+    want, _, _ = O.render(sc, w, h, threads=4)
+    assert np.array_equal(buf.cpu().numpy().view(np.uint32), want)
+    r.close()

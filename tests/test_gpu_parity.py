@@ -362,6 +362,37 @@ def test_camera_beyond_the_sane_range(torch_cuda, renderer, scenes):
     check_against_oracle(g, sc, w, h, camera=cam)
 
 
+def test_first_step_is_given_or_taken(torch_cuda, renderer, scenes):
+    """The primary march's first step, sdf(camera position), comes from the host once per camera position (lol_gpu.hip, first_step;
+    lol_kernel.h, march) — or is taken by every pixel itself where the hand-over is not provably the same bits: a component of the
+    position that is a negative zero, a first step that ends the march (camera inside an object / within 0.001 of a surface / more
+    than 100 from everything), max_steps = 0 and 1.  Distances, ids and step counts (this step included) = the oracle's in each."""
+    sc = scenes["scene4"]
+    w, h = 72, 40
+
+    def cam_at(x, y, z, dx, dy, dz, fov=90.0):
+        cam = S.Camera()
+        cam.point = S.V3(x, y, z)
+        d = np.array([dx, dy, dz], dtype=np.float32)
+        n = np.float32(1.0) / np.sqrt(np.float32(d[0] * d[0] + d[1] * d[1]) + np.float32(d[2] * d[2]), dtype=np.float32)
+        cam.direction = S.V3(*(float(np.float32(v * n)) for v in d))
+        cam.fov = float(np.float32(np.float32(fov) / np.float32(180) * np.pi))
+        return cam
+    cams = [
+        cam_at(-2.0, 6.0, 3.0, 0.2, -0.5, -1.0),          # the ordinary case: the step is given
+        cam_at(-0.0, 6.0, 3.0, 0.0, -0.5, -1.0),          # x = -0: taken per pixel
+        cam_at(0.0, 6.0, -0.0, 0.0, -0.5, -1.0),          # z = -0
+        cam_at(0.0, 1.0, -6.0, 0.0, 0.0, -1.0),           # inside the blob: the first step is negative and ends the march
+        cam_at(0.0, -0.9995, 3.0, 0.0, 0.1, -1.0),        # 0.0005 above the floor: ends on the first step too
+        cam_at(0.0, 150.0, 0.0, 0.0, -1.0, -0.01),        # 151 above the floor: the first step overshoots MAX_DIST
+        cam_at(0.0, 99.0, 0.0, 0.0, -1.0, -0.01),         # exactly 100 above it: dist == MAX_DIST after one step
+    ]
+    for cam in cams:
+        for max_steps in (256, 1, 0):
+            g = gpu_render(torch_cuda, renderer, sc, w, h, max_steps=max_steps, camera=cam)
+            check_against_oracle(g, sc, w, h, max_steps=max_steps, camera=cam)
+
+
 def test_render_host_surface(torch_cuda, renderer, scenes):
     sc = scenes["scene"]
     w, h, pitch = 50, 30, 64 * 4

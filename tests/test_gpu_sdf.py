@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from loltracer_amd import gpu
+from loltracer_amd import gpu, scene as S
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -135,37 +135,24 @@ def test_points_where_the_fast_root_has_no_proof(scenes, mode):
 
 
 @pytest.mark.gpu
-def test_shadow_division_shortcut_is_the_division(scenes, monkeypatch):
-    """fdiv_fast (lol_kernel.h) = hipcc's own division sequence minus v_div_scale / v_div_fmas / v_div_fixup: the same arithmetic
-    inside the box of operands the shadow march keeps for itself.  The device holds it against '/' over 2^32 quotients per sweep:
-    the fixed exponent corners (what a context checks before using it) and pseudo-random exponents / divisor mantissas.
-    And the fallback: a kernel compiled with an absurd lower bound for t sends every wave that marches a shadow through the
-    plain path — same frame."""
+def test_shadow_ray_that_never_moves():
+    """A shadow ray whose first sample lies EXACTLY on a surface: s = 0, 50 s / t = 0 / 0 = NaN, t stays 0, the reference's factor is
+    NaN for all 128 steps and comes out maxf(NaN, 0) = 0 (naive_renderer.c:80-89).  The specialised kernel's fast pipeline keeps the
+    running minimum with v_min_f32, which drops a NaN operand — it names this case by `t == 0` afterwards (lol_kernel.h, soft_shadow).
+    Camera on the plane y = 0 (every primary ray 'hits' at distance 0, so every shadow ray starts at the camera), light at the same
+    height: direction.y = 0 exactly, and every sample of the shadow ray has p.y - 0 = 0.  The zero-incidence skip is switched off so
+    that the lanes do march (the plane's normal is perpendicular to the light's direction); step counts and pixels = the oracle's."""
     import torch
-    r0 = gpu.Renderer(0)                                           # the default: the plain division
-    monkeypatch.setenv("LOL_GPU_SHADOW_FDIV", "1")                 # (off by default: +0.95 % on C3, below the bar for the default kernel)
-    r = gpu.Renderer(0)
-    for seed in (0, 1, 2, 20261004, 0xDEADBEEF):
-        assert r.verify_shadow_division(seed) == 0, seed
-    sc = scenes["scene4"]
-    w, h = 160, 90
-    want, _, _ = O.render(sc, w, h, threads=4)
-
-    def frame(rr):
-        rr.prepare(sc)
-        assert rr.kernel_name() == "lol_render_spec", rr.specialize_log()
-        buf = torch.zeros((h, w), dtype=torch.int32, device="cuda")
-        rr.render_into(buf.data_ptr(), w, h)
-        rr.sync()
-        return buf.cpu().numpy().view(np.uint32)
-    assert np.array_equal(frame(r), want)
-    with monkeypatch.context() as m:
-        m.delenv("LOL_GPU_SHADOW_FDIV")                            # the plain division everywhere: another kernel, the same frame
-        assert np.array_equal(frame(r0), want) and r0.kernel_key() != r.kernel_key()
-        r0.close()
-    with monkeypatch.context() as m:
-        m.setenv("LOL_GPU_RTC_FLAGS", "-DLOL_FDIV_T_MIN=64.0f")    # no march ever starts 64 units from a surface: every one falls back
-        r1 = gpu.Renderer(0)
-        assert np.array_equal(frame(r1), want) and r1.kernel_key() != r.kernel_key()
-        r1.close()
-    r.close()
+    from test_gpu_parity import check_against_oracle, gpu_render
+    text = ("materials { { shininess = 4, diffuse = (.6,.5,.4), specular = (.3,.3,.3), ambient = (.2,.1,.3) } } scene {"
+            " camera { point = (0,0,0), direction = (0,-.3,-1), fov = 90 }, plane { y = 0 }, sphere { point = (2,1,-6), radius = 1 },"
+            " point_light { point = (3,0,-2), diffuse_intensity = (2,2,2), specular_intensity = (1,1,1) },"
+            " point_light { point = (-4,6,1), diffuse_intensity = (1,1,1), specular_intensity = (1,1,1) } }")
+    sc = S.Scene.parse_string(text)
+    for mode in (1, 3, 4, 0):
+        r = gpu.Renderer(0, specialize=mode)
+        r.set_exact_skips(4 | 1)                 # settled shadows on, the zero-incidence skip off
+        g = gpu_render(torch, r, sc, 48, 20)
+        assert (g["steps"] >> 16).max() >= 128, "no shadow ray marched its 128 steps: the case this test is about did not occur"
+        check_against_oracle(g, sc, 48, 20)
+        r.close()

@@ -8,7 +8,6 @@ for w in 6,6 7,7 8,8 4,8; do run LOL_GPU_WAVES_PER_EU=$w; done
 run LOL_GPU_SMIN_SAT=0
 run LOL_GPU_SMIN_SAT=2
 run LOL_GPU_SCHED=default
-run LOL_GPU_SHADOW_FDIV=1
 run X=0
 run X=0
 for n in 1 2 3 5 0; do run LOL_GPU_SAT_CULL_MIN_PRIMS=$n; done
