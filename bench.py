@@ -477,9 +477,82 @@ def launcher_command(n: int, argv: list, port: int) -> list:
             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
-def launch_ranks(n: int, argv: list) -> int:
-    """Start the N ranks as a child process group and wait for them; returns their exit status.
-    Called before this process has made any HIP call (importing torch does not initialise the GPU)."""
+# ---------------------------------------------------------------------------------------------------------------------------
+# A run on N > 1 devices must not be able to hang, or to fail without a word (round-5 review: the first 8-GPU run this code ever
+# gets is the driver's, and a stuck collective would have sat out RCCL's default of ten minutes — the driver's whole limit —
+# and left nothing).  Three layers, each of which ends the run with ONE JSON line {"error", "stage", "rank"} on stdout and a
+# non-zero status:
+#   - every process group is created with a timeout (init_group: COLLECTIVE_TIMEOUT_S, 90 s), so a collective a rank never
+#     joins raises in the ranks that did;
+#   - every rank runs a host-side watchdog (Deadline): main() names the stage it is in, and a stage that outlives its limit —
+#     a kernel that never ends, a gather that never completes, an in-process lol_gpu_multi_sync that never returns (the
+#     watchdog is a thread of its own and ends the process with os._exit: no Python frame of the stuck thread has to run) —
+#     gets the line and exit status 3; torch.distributed.run then ends the other ranks;
+#   - the launcher of `python bench.py --gpus N` has a deadline of its own (launch_ranks: LAUNCHER_DEADLINE_S) after which it
+#     kills the ranks' whole process group.
+# Nothing here re-executes anything: children are started, or the process exits.
+COLLECTIVE_TIMEOUT_S = float(os.environ.get("LOL_BENCH_COLLECTIVE_TIMEOUT_S", "90"))
+LAUNCHER_DEADLINE_S = float(os.environ.get("LOL_BENCH_LAUNCHER_DEADLINE_S", "540"))
+STAGE_LIMITS_S = {"process group": 120, "render_prepare": 180, "set-up": 150, "warm-up": 90, "timed loop": 120,
+                  "checks": 120, "rank stats": 60, "record": 420}
+
+
+def error_line(error: str, stage: str, rank) -> str:
+    return json.dumps({"error": error, "stage": stage, "rank": rank})
+
+
+class Deadline:
+    """The host-side watchdog of one rank.  stage(name) starts the clock of a named stage (limit: STAGE_LIMITS_S, scaled by
+    LOL_BENCH_STAGE_DEADLINE_SCALE, or the `seconds` given); a stage still running at its limit ends the process: one JSON line
+    on `fd` (the saved stdout), the same on stderr, os._exit(3).  done() stops the watchdog."""
+
+    def __init__(self, rank: int, fd: int, poll_s: float = 0.25):
+        import threading
+        self.rank, self.fd, self.poll_s = rank, fd, poll_s
+        self.scale = float(os.environ.get("LOL_BENCH_STAGE_DEADLINE_SCALE", "1"))
+        self._lock = threading.Lock()
+        self._stage, self._until = None, None
+        self._thread = threading.Thread(target=self._watch, name="bench-deadline", daemon=True)
+        self._thread.start()
+
+    def stage(self, name: str, seconds: float | None = None):
+        limit = (seconds if seconds is not None else STAGE_LIMITS_S.get(name, 120)) * self.scale
+        with self._lock:
+            self._stage, self._until = name, time.monotonic() + limit
+            self._limit = limit
+
+    def done(self):
+        with self._lock:
+            self._stage, self._until = None, None
+
+    def _watch(self):
+        while True:
+            time.sleep(self.poll_s)
+            with self._lock:
+                stage, until, limit = self._stage, self._until, getattr(self, "_limit", 0)
+            if stage is not None and time.monotonic() > until:
+                line = error_line(f"stage not finished after its limit of {limit:.0f} s: the process ends itself", stage, self.rank)
+                try:
+                    os.write(self.fd, (line + "\n").encode())
+                    os.write(2, ("[bench] " + line + "\n").encode())
+                finally:
+                    os._exit(3)
+
+
+def init_group(backend: str, rank: int, world: int, device=None):
+    """dist.init_process_group with the bounded timeout every group of this file gets (a collective that a rank never joins
+    raises after COLLECTIVE_TIMEOUT_S in the ranks that did, instead of waiting out the backend's default of ten minutes or more)."""
+    from datetime import timedelta
+    kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+    dist.init_process_group(backend, rank=rank, world_size=world, timeout=timedelta(seconds=COLLECTIVE_TIMEOUT_S), **kw)
+
+
+def launch_ranks(n: int, argv: list, script: str | None = None, deadline_s: float | None = None) -> int:
+    """Start the N ranks as a child process group and wait for them — at most deadline_s (LAUNCHER_DEADLINE_S): after that
+    the whole group is killed, ONE JSON error line goes to stdout and the status is 124.  Returns the ranks' exit status.
+    Called before this process has made any HIP call (importing torch does not initialise the GPU).  `script`: what the ranks
+    run (this file; the tests of the launcher pass small rank programs of their own)."""
+    import signal
     import socket
     import subprocess
     with socket.socket() as s:
@@ -488,11 +561,32 @@ def launch_ranks(n: int, argv: list) -> int:
     env = dict(os.environ)
     env.setdefault("OMP_NUM_THREADS", "4")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL needs it on this pool
-    proc = subprocess.Popen(launcher_command(n, argv, port), env=env)   # stdout / stderr inherited: rank 0's JSON line
+    cmd = launcher_command(n, argv, port)
+    if script is not None:
+        cmd[cmd.index(os.path.abspath(__file__))] = os.path.abspath(script)
+    limit = LAUNCHER_DEADLINE_S if deadline_s is None else deadline_s
+    # a session of its own: the deadline can end torch.distributed.run AND every rank it started with one killpg of exactly that group
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)   # stdout / stderr inherited: rank 0's JSON line
     try:
-        return proc.wait()
+        return proc.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(proc.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        print(error_line(f"the {n} ranks had not finished after {limit:.0f} s: their process group was killed", "launcher deadline", None), flush=True)
+        return 124
     except KeyboardInterrupt:
-        proc.terminate()
+        try:
+            os.killpg(proc.pid, signal.SIGTERM)
+        except ProcessLookupError:
+            pass
         return proc.wait()
 
 
@@ -594,8 +688,13 @@ def run_cabi(args, record_fd):
     cfg = WORKLOADS[name]
     w, h, max_steps = cfg["w"], cfg["h"], cfg["max_steps"]
     sc = S.Scene.parse_file(os.path.join(ROOT, "tests", "golden", "scenes", cfg["scene"] + ".lol"))
+    # the watchdog (Deadline): lol_gpu_multi_sync waits for the devices without a bound of its own — a kernel or an RCCL group that
+    # never completes would hold this process for ever; the watchdog's thread ends it with the JSON error line instead
+    watchdog = Deadline(0, record_fd)
+    watchdog.stage("render_prepare")
     m = gpu.MultiRenderer(list(range(n)))
     m.prepare(sc)
+    watchdog.stage("set-up")
     torch.cuda.set_device(0)
     frames = [torch.zeros((h, w), dtype=torch.int32, device="cuda:0") for _ in range(2)]
     fc = sc.frame_camera(w, h)
@@ -621,11 +720,14 @@ def run_cabi(args, record_fd):
         best = min(zip(cands, trials), key=lambda ct: ct[1]["ms_per_frame"])[0]
     if n > 1:
         m.set_band_rows(best[0]); m.set_root_band_rows(best[1])
+    watchdog.stage("warm-up")
     run(max({"c2": 400, "c3": 100, "c4": 32}[name], gpu.TILE_TRIAL_FRAMES + 10))
     run(args.warmup)
+    watchdog.stage("timed loop")
     t0 = time.perf_counter()
     run(args.steps)
     dt = time.perf_counter() - t0
+    watchdog.stage("checks")
     # outside the timed region, by default (LOL_BENCH_CHECK=0 skips it): the frame assembled from every device's bands must
     # equal ONE launch of the whole frame on device 0
     check = None
@@ -656,6 +758,7 @@ def run_cabi(args, record_fd):
     }
     os.write(record_fd, (json.dumps(out) + "\n").encode())
     m.close()
+    watchdog.done()
     if check is False:
         raise SystemExit("bench.py: the assembled frame differs from the single-launch render (record printed above)")
 
@@ -694,6 +797,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # the watchdog (see Deadline above): for N > 1 every stage up to the record has a limit; a single rank keeps the limits of
+    # the stages that can hang on a device (there is no collective to wait for, and its legs after the timed region take minutes)
+    watchdog = Deadline(rank, record_fd)
+    watchdog.stage("process group")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start the ranks with "
                          f"`python bench.py --gpus {args.gpus}` or torch.distributed.run --nproc-per-node {args.gpus}")
@@ -709,10 +816,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearse:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        init_group("gloo" if rehearse else "nccl", rank, world, dev)
 
     emulate = args.emulate_root_of
     if emulate and (world != 1 or emulate < 2):
@@ -727,8 +831,10 @@ def main():
             startup = startup_times(sc, w, h, max_steps, local_rank)  # before this process has compiled the scene
         except Exception as e:                                    # noqa: BLE001 — an extra of the record must not cost the line
             startup = {"error": f"{type(e).__name__}: {e}"}
+    watchdog.stage("render_prepare", 300 if startup is not None else None)      # (the start-up leg above compiled the scene cold, twice)
     r = gpu.Renderer(local_rank)
     r.prepare(sc)                                     # render_prepare: flatten + upload once; waits for the scene's own kernel
+    watchdog.stage("set-up")
     # A side stream: its handle is non-NULL (NULL means "the context's own stream" in lol_gpu.h), and
     # torch.cuda.Event / the nccl gather below are ordered on whatever stream is current.
     side = torch.cuda.Stream(device=dev)
@@ -753,7 +859,7 @@ def main():
     if force_pipe and world == 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        init_group("nccl", 0, 1, dev)
     piped = (world > 1 or force_pipe) and not orbit
 
     def assembler(staging, frame, P, stream_handle):
@@ -878,12 +984,14 @@ def main():
     r.set_tile_order(want_order)
     prewarm = {"c2": 400, "c3": 100, "c4": 32 * max(world, emulate), "orbit": gpu.TILE_TRIAL_FRAMES + 10}[name]
     prewarm = max(prewarm, gpu.TILE_TRIAL_FRAMES + 10)
+    watchdog.stage("warm-up")
     for i in range(prewarm):
         step(i, False)
     fence()
     for i in range(args.warmup):
         step(i, False)
     fence()
+    watchdog.stage("timed loop")
     tile = r.tile_order()                             # everything issued so far has finished: the trials are in
     host_s = 0.0
     t0 = time.perf_counter()
@@ -900,6 +1008,7 @@ def main():
     if force_pipe and world == 1 and rank == 0:
         print("[force-pipe] 1-rank nccl gather path completed", file=sys.stderr, flush=True)
     # ---- everything below is outside the timed region ----
+    watchdog.stage("checks")
     if fif > 1:
         r.set_frames_in_flight(1)
     # Correctness of what was just timed, by default (LOL_BENCH_CHECK=0 skips it; the driver's plain `bench.py --gpus N` gets it):
@@ -953,6 +1062,7 @@ def main():
     k_avg = sum(k_ms) / max(len(k_ms), 1)
     px_per_launch = (P.rank_rows[rank] if P is not None else h) * w      # pixels this rank renders per frame
     # what every rank did: one all_gather after the timed loop (a rank's wall time is its own, before the max over ranks)
+    watchdog.stage("rank stats")
     rank_stats = gather_rank_stats({
         "rows": P.rank_rows[rank] if P is not None else h, "frames": steps,
         "kernel_ms_avg": k_avg, "kernel_ms_min": min(k_ms) if k_ms else 0.0, "kernel_ms_max": max(k_ms) if k_ms else 0.0,
@@ -966,6 +1076,7 @@ def main():
         total_px = steps * w * h
         steps_reported = steps
     value = total_px / dt / 1e6
+    watchdog.stage("record", None if world > 1 else 1500)      # (one rank: the oracle leg and the other extras of the record run here)
 
     if rank == 0:
         overlap = len(kstreams) if kstreams else (fif if orbit else 1)      # kernels that share the device: the elapsed time of one is that many frames' worth
@@ -1087,6 +1198,7 @@ def main():
     r.close()
     if dist.is_initialized():
         dist.destroy_process_group()
+    watchdog.done()
     if rank == 0 and (frame_equal is False or frames_equal is False):
         raise SystemExit("bench.py: the frames of the partitioned run differ from the single-launch render (record printed above)")
 

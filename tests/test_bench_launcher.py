@@ -206,3 +206,72 @@ def test_valu_record_describes_the_machine_and_has_no_fraction_above_one():
     # another kernel code: the issue figures are withheld, never quoted stale
     w = bench.valu_fields("lol_render_spec", rec["workload"], rec["pixels_per_launch"], "0" * 16, 7800.0, Ctr, 107.0)
     assert w["issue_frac"] is None and w["valu_instructions_per_pixel"] is None and "not quoted" in w["issue_source"]
+
+
+# ------------------------------------------------------------------ a run on N > 1 ranks cannot hang, or fail without a word
+
+RANK_PROGRAM = os.path.join(ROOT, "tests", "rank_programs", "two_ranks.py")
+
+
+def _launch(mode, deadline_s, extra_env=None):
+    """bench.launch_ranks in a process of its own (it must not have touched a GPU, and its JSON error line goes to stdout)."""
+    import time
+    code = ("import sys; sys.path.insert(0, %r); import bench; "
+            "raise SystemExit(bench.launch_ranks(2, ['--mode', %r], script=%r, deadline_s=%r))" % (ROOT, mode, RANK_PROGRAM, deadline_s))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(extra_env or {})
+    t0 = time.monotonic()
+    p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    return p, time.monotonic() - t0
+
+
+def _json_lines(text):
+    import json
+    out = []
+    for ln in text.splitlines():
+        try:
+            out.append(json.loads(ln))
+        except ValueError:
+            pass
+    return out
+
+
+def test_two_ranks_that_behave_finish_with_one_line():
+    p, dt = _launch("ok", 120)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert _json_lines(p.stdout) == [{"value": 4.0}]
+
+
+def test_a_rank_that_dies_mid_run_ends_the_run_non_zero_within_the_deadline():
+    """Rank 1 exits (status 17) while rank 0 waits for it in a collective: torch.distributed.run ends rank 0, the launcher hands
+    the failure on — long before its own deadline or the group's timeout."""
+    p, dt = _launch("die", 120)
+    assert p.returncode not in (0, 124) and dt < 90, (p.returncode, dt, p.stderr[-2000:])
+    assert not any("value" in d for d in _json_lines(p.stdout))          # no record from a failed run
+
+
+def test_a_rank_that_never_joins_a_collective_trips_the_watchdog():
+    """Rank 1 sleeps instead of joining; rank 0's stage has a 3 s limit: its watchdog writes the JSON error line (stage, rank) to
+    stdout and ends the process with status 3, which ends the run — no ten-minute wait for the backend's own timeout."""
+    p, dt = _launch("hang", 120)
+    assert p.returncode not in (0, 124) and dt < 90, (p.returncode, dt, p.stderr[-2000:])
+    errs = [d for d in _json_lines(p.stdout) if "error" in d]
+    assert len(errs) == 1 and errs[0]["stage"] == "timed loop" and errs[0]["rank"] == 0 and "3 s" in errs[0]["error"]
+
+
+def test_ranks_that_do_nothing_for_ever_are_ended_by_the_launchers_own_deadline():
+    """No rank has a watchdog and none ever exits: after its deadline the launcher kills the ranks' whole process group (its own
+    session: torch.distributed.run AND the ranks), prints the JSON error line and returns 124."""
+    p, dt = _launch("sleep", 8)
+    assert p.returncode == 124 and dt < 60, (p.returncode, dt, p.stderr[-2000:])
+    errs = [d for d in _json_lines(p.stdout) if "error" in d]
+    assert len(errs) == 1 and errs[0]["stage"] == "launcher deadline" and errs[0]["rank"] is None
+    # nothing of the group is left behind
+    left = subprocess.run(["ps", "-eo", "pid,args"], stdout=subprocess.PIPE, text=True).stdout
+    assert "two_ranks.py --mode sleep" not in left
+
+
+def test_every_process_group_of_bench_has_a_bounded_timeout():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.count("dist.init_process_group(") == 1 and "timeout=timedelta(seconds=COLLECTIVE_TIMEOUT_S)" in src
+    assert bench.COLLECTIVE_TIMEOUT_S <= 120 and bench.LAUNCHER_DEADLINE_S <= 570      # the driver's limit for a run is ten minutes

@@ -200,10 +200,12 @@ def _weighted_worker(rank, world, port, w, h, band, root, frames, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,h,band,root", [(2, 120, 8, 6), (3, 101, 8, 5), (4, 96, 4, 1)])
+@pytest.mark.parametrize("world,h,band,root", [(2, 120, 8, 6), (3, 101, 8, 5), (4, 96, 4, 1),
+                                               (8, 4320, 16, 15), (8, 4320, 12, 10)])      # BASELINE config 4's own geometry, eight ranks
 def test_unequal_parts_gather_and_assemble(world, h, band, root):
     """The root's bands are less tall than the others' (its smaller share), heights that no cycle divides: the gathered,
-    padded parts still assemble to the frame."""
+    padded parts still assemble to the frame.  The last two cases are config 4 as `bench.py --gpus 8` cuts it — 4320 rows,
+    bands of 16 (15 for rank 0) and of 12 (10) — as eight PROCESSES over gloo (round-5 review: world 8 was geometry only)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -211,6 +213,6 @@ def test_unequal_parts_gather_and_assemble(world, h, band, root):
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(240)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
