@@ -211,9 +211,9 @@ const char* lol_gpu_kernel_name(const lol_gpu* ctx);
  * the square-root variant}: everything that decides which instructions the interpreter executes.  Profiles record it
  * (profiles/pmc_traffic.json) so that a counter figure is only ever quoted for the code it was measured on. */
 const char* lol_gpu_kernel_key(const lol_gpu* ctx);
-/* The tuning switches in effect in this process, "NAME=value NAME=value ..." ("" when none).  The library has two dozen
- * LOL_GPU_* environment switches for A/B runs (INTEGRATION.md lists them) — compiler options of the scene's kernel among
- * them.  They are honoured ONLY in a process that also sets LOL_GPU_TUNING=1; one that is set without it is ignored and
+/* The tuning switches in effect in this process, "NAME=value NAME=value ..." ("" when none).  The library has ten
+ * LOL_GPU_* environment switches for A/B runs and debugging (INTEGRATION.md lists them) — the scene kernel's instruction scheduling
+ * among them.  They are honoured ONLY in a process that also sets LOL_GPU_TUNING=1; one that is set without it is ignored and
  * reported once on stderr; every one that took effect is listed here, in lol_gpu_specialize_log() and in bench.py's
  * record, so that a number can never silently come from a shell's leftovers.  (Not fenced: LOL_GPU_CACHE_DIR, LOL_GPU_ROCTX —
  * where code objects are kept, whether frames are marked: neither changes what is computed.)  The string belongs to the library
@@ -266,7 +266,7 @@ int         lol_gpu_verify_fast_paths(lol_gpu* ctx, float k, unsigned long long 
 int         lol_gpu_verify_smin_no_fixup(lol_gpu* ctx, float k, unsigned long long* mismatches);
 /* Gamma and quantisation of a colour channel — Uint8 v = powf(c, 1 / 2.2f) * 255 (naive_renderer.c:231-232, renderer.h:17-22) —
  * through a table of 256 thresholds instead of the powf (lol_kernel.h, gamma_u8_table): used by frames only after this sweep of
- * every float in [0, 1] found no difference on the context's device (it runs at the first upload; LOL_GPU_GAMMA_TABLE=0 keeps the
+ * every float in [0, 1] found no difference on the context's device (it runs at the first upload; lol_gpu_set_specialize(ctx, 3) keeps the
  * powf).  *mismatches = floats on which the two routes differ (0 = proven, ~0 = could not run); table (may be NULL): the 257
  * thresholds, T[k] = the smallest c whose channel value is >= k, T[0] = 0, T[256] = +inf. */
 int         lol_gpu_verify_gamma_table(lol_gpu* ctx, unsigned long long* mismatches, float* table);
@@ -275,7 +275,7 @@ int         lol_gpu_verify_gamma_table(lol_gpu* ctx, unsigned long long* mismatc
  * diffuse == specular == 0, shininess >= 0 and all light intensities are finite, their colour is exactly
  * clamp(ambient_color * material.ambient) whatever the normal and shadow factors are, so a wavefront whose
  * rays ALL escaped skips the normal taps and shadow marches.  On by default when the uploaded program
- * qualifies (checked on the host); set_miss_skip(ctx, 0) or LOL_GPU_MISS_SKIP=0 turn it off.  With it on,
+ * qualifies (checked on the host); set_miss_skip(ctx, 0) turns it off.  With it on,
  * lol_gpu_debug.steps reports 0 shadow steps for the skipped pixels.
  *
  * The same switch governs the per-light form: where a surface faces away from a light (diffuse incidence
@@ -298,7 +298,7 @@ int         lol_gpu_miss_skip_active(const lol_gpu* ctx);
  * Exact culling of top-level objects in the specialised kernel (lol_gpu.hip, "exact culling"): sdf() is a strict-'<'
  * minimum over the objects (naive_renderer.c:31-44), so an object that a bounding sphere PROVES farther away than the
  * running minimum is not evaluated — for a whole wavefront at a time, and only then.  Same pixels, same step counts.
- * On by default; set_cull(ctx, 0) before the upload or LOL_GPU_CULL=0 turn it off.
+ * On by default; set_cull(ctx, 0) before the upload turns it off.
  */
 int         lol_gpu_set_cull(lol_gpu* ctx, int enable);
 /*
@@ -412,8 +412,8 @@ int  lol_gpu_multi_render_device(lol_gpu_multi* m, const lol_frame_camera* cam, 
 /* What render_thread does with surf->pixels: one frame over all devices into a HOST surface; waits.  No exchange is
  * needed for this: every device copies its own bands into the surface over its own PCIe link, all devices at once —
  * one host thread per device issues that device's strided copies (one per part): a copy into pageable memory occupies
- * the thread that issues it, so N threads are what makes N links run in parallel.  set_host_via_root(m, 1) (or
- * LOL_GPU_MULTI_HOST_VIA_ROOT=1) instead assembles on the root with the RCCL exchange and copies from there. */
+ * the thread that issues it, so N threads are what makes N links run in parallel.  set_host_via_root(m, 1)
+ * instead assembles on the root with the RCCL exchange and copies from there. */
 int  lol_gpu_multi_render_host(lol_gpu_multi* m, const lol_frame_camera* cam, int w, int h, int max_steps,
                                void* host_pixels, size_t pitch_bytes);
 int  lol_gpu_multi_set_host_via_root(lol_gpu_multi* m, int enable);

@@ -91,7 +91,6 @@ struct SpecJob {
 	bool done = false, ok = false;
 	std::vector<char> code;
 	std::string log, note;
-	int shape[3] = { LOL_WAVE_W, LOL_WAVE_H, LOL_WAVES_X };
 	std::chrono::steady_clock::time_point started;
 	double compile_ms = 0;
 	/* what the run compiles — its own copies: the context may take another scene meanwhile */
@@ -197,7 +196,6 @@ struct lol_gpu {
 	float*       d_gamma = nullptr;      /* gamma thresholds (lol_kernel.h, gamma_u8_table): GAMMA_LEVELS + 1 floats */
 	int          gamma_verified = -1;    /* -1 not run, 1 the table route == the powf route for every float in [0, 1] on this device, 0 not */
 	bool         gamma_table = false;    /* frames of the current scene use it (want_fast at the last upload) */
-	int          wave_w = LOL_WAVE_W, wave_h = LOL_WAVE_H, waves_x = LOL_WAVES_X;   /* footprint of the spec kernel */
 	/* lol_gpu_set_tile_order.  AUTO: the first frames of a (scene, size, partition) alternate between the two orders, each
 	 * between two events on its launch stream; later frames collect the finished ones without waiting (tile_auto_*) */
 	struct TileAuto {
@@ -805,7 +803,6 @@ void cluster_bounds(const lol_program& P, RootBound& R) {
 	auto sane = [](double v) { return v - v == 0.0 && fabs(v) < 1e15; };
 	if (!a.ok || !b.ok || !sane(a.r) || !sane(b.r)) return;
 	if (fmax(a.r, b.r) > 0.75 * R.r) return;
-	if (const char* e = tuning_env("LOL_GPU_CULL_TWO_SPHERES")) if (e[0] == '0') return;      /* A/B runs */
 	R.clusters = { a, b };
 }
 
@@ -853,10 +850,7 @@ struct CullPlan {
 	CullTest group_test{};
 };
 
-bool culling_enabled(int want) {
-	const char* e = tuning_env("LOL_GPU_CULL");
-	return want && !(e && e[0] == '0');
-}
+bool culling_enabled(int want) { return want != 0; }      /* (lol_gpu_set_cull) */
 
 /* Objects that lie together are evaluated together, behind a test of their common bounding sphere: a k-d split of
  * the bounded objects (median cut along the widest axis of their centres, down to runs of at most three) gives the
@@ -912,8 +906,7 @@ CullPlan plan_culling(const std::vector<RootBound>& roots, bool enabled) {
 	/* LOL_GPU_CULL_CLUSTERS=0: one run of all bounded objects in scene order, no spatial clusters (for A/B runs) */
 	const char* e = tuning_env("LOL_GPU_CULL_CLUSTERS");
 	const size_t leaf_max = (e && atoi(e) == 0) ? (size_t)-1 : (e && atoi(e) > 1 ? (size_t)atoi(e) : 3);
-	uint32_t min_prims = 1;
-	if (const char* m = tuning_env("LOL_GPU_CULL_MIN_PRIMS")) min_prims = (uint32_t)std::max(1, atoi(m));
+	const uint32_t min_prims = 1;      /* every node of the tree gets its test (profiles/r2_flat_scene_ab.jsonl: tests from 1 ... 4 primitives up) */
 	kd_build(roots, bounded, 0, bounded.size(), plan.n_unbounded, plan.n_unbounded > 0, leaf_max, min_prims, plan);
 	plan.order.insert(plan.order.end(), bounded.begin(), bounded.end());
 	/* outer runs before inner ones at the same position (kd_build emits parents first; keep that order stable) */
@@ -961,19 +954,12 @@ std::vector<uint32_t> build_mops(const lol_program& P, const FastPaths* fast, co
 		}
 		m[0] |= lol::mop_smin_bits(m[0]);
 	};
-	/* LOL_GPU_INTERP_CULL_MIN_PRIMS: leave out the tests of runs with fewer primitives (measured: 1, i.e. keeping
-	 * every test, is fastest here too — a test is one turn of a scalar loop inside the rare TAIL branch). */
+	/* (every test of the plan is kept: leaving out those of runs with few primitives was measured slower here too — a test is one
+	 * turn of a scalar loop inside the rare TAIL branch) */
 	/* deep: operand stacks beyond the 4-bit slot fields — slots travel in words of their own and pops are not fused (lol_kernel.h, MOP_DEEP_FROM) */
 	const bool deep = interp_stack_class(P.max_stack) == lol::MOP_DEEP_SLOTS;
 	const bool fuse_pops = !deep && !(tuning_env("LOL_GPU_INTERP_FUSE_POPS") && tuning_env("LOL_GPU_INTERP_FUSE_POPS")[0] == '0');     /* A/B switch */
-	uint32_t min_prims = 1;
-	if (const char* e = tuning_env("LOL_GPU_INTERP_CULL_MIN_PRIMS")) min_prims = (uint32_t)std::max(1, atoi(e));
-	std::vector<CullInterval> ivs;
-	for (const CullInterval& iv : plan.intervals) {
-		uint32_t prims = 0;
-		for (size_t k = iv.begin; k < iv.end; k++) prims += roots[plan.order[k]].prims;
-		if (prims >= min_prims) ivs.push_back(iv);
-	}
+	const std::vector<CullInterval>& ivs = plan.intervals;
 	const bool group_first = plan.group && !ivs.empty() && ivs[0].begin == plan.n_unbounded && ivs[0].end == plan.order.size();
 	std::vector<size_t> at(ivs.size());              /* where each test's constants record went */
 	std::vector<uint32_t> begins(plan.order.size() + 1, 0);
@@ -1087,12 +1073,10 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 	 * again (a ray that is near the object now is near it on its next steps too): the test costs 11 VALU
 	 * instructions, and where it keeps failing that is pure overhead.  Never testing is always allowed — the
 	 * test only ever permits a skip — so this changes no result.  `cool` lives in the Sdf struct, wave-uniform. */
-	int cooldown = 3;
-	if (const char* e = tuning_env("LOL_GPU_CULL_COOLDOWN")) cooldown = atoi(e);
-	/* LOL_GPU_SMIN_SAT=0: smooth minima without the per-wave saturation shortcut (sminf_fastdiv_sat), for A/B runs */
-	const bool smin_sat = !(tuning_env("LOL_GPU_SMIN_SAT") && atoi(tuning_env("LOL_GPU_SMIN_SAT")) == 0);
-	/* LOL_GPU_NAN_FLAG=0: every sphere keeps the range tracker (A/B runs) */
-	const bool nan_flag = fast && fast->sqrt_tiny_ok && !(tuning_env("LOL_GPU_NAN_FLAG") && atoi(tuning_env("LOL_GPU_NAN_FLAG")) == 0);
+	const int cooldown = 3;
+	/* spheres of radius >= 2^-20 carry no range tracker where the device has shown the fast root harmless below its proven domain
+	 * (lol_kernel.h, sd_sphere_fast_nr): a NaN reaches the object's value instead, which is looked at once */
+	const bool nan_flag = fast && fast->sqrt_tiny_ok;
 	bool object_has_nr = false;
 	/* LOL_GPU_SAT_CULL_MIN_PRIMS: `a` operands of a smooth union with at least this many primitives get a saturation-
 	 * culling test (see emit_node below); 0 = none.  Measured (tools/tree_scene_ab.py, balanced trees of spheres at
@@ -1222,7 +1206,7 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 			if (fx[0]) object_has_nr = true;
 			/* the arithmetic shortcut only where the SDF is inlined: in the out-of-line function its four-way branching
 			 * costs more than it saves (504-op chain: 100 -> 42 Mpixels/s) */
-			const bool sat_arith = smin_sat && (!out_of_line || (tuning_env("LOL_GPU_SMIN_SAT") && atoi(tuning_env("LOL_GPU_SMIN_SAT")) == 2)) && ks > 0.f;
+			const bool sat_arith = !out_of_line && ks > 0.f;
 			const std::string kk = fbits(o.f[0]), k2 = fbits(2.0f * o.f[0]), hrk = fbits(0.5f * (1.0f / o.f[0])), kss = fbits(ks);
 			if (proven && ks > 0.f && sat_cull_min_prims > 0 && nodes[n.a].bound.ok && nodes[n.a].prims >= (uint32_t)sat_cull_min_prims) {
 				const int b = emit_node(n.b);
@@ -1340,12 +1324,8 @@ std::string generate_source(const lol_program& P, const FastPaths* fast, bool cu
 	 * (compile_spec): the more registers a wave may use, the more primitives it keeps in flight.  Measured on
 	 * MI355X (profiles/r2_large_scene_ab.jsonl): with max-ILP, scene4 (12 ops) is fastest when 8 waves per SIMD are
 	 * kept (64 VGPRs: 4640 vs 4530 Mpixels/s unconstrained), a 44-op chain at >= 6, chains of 142+ ops at >= 4
-	 * (128 VGPRs: 427 vs 400 Mpixels/s at 8).  LOL_GPU_WAVES_PER_EU="min,max" overrides. */
-	int waves_lo = P.n_ops <= 32 ? 8 : P.n_ops <= 96 ? 6 : 4, waves_hi = 8;
-	if (const char* e = tuning_env("LOL_GPU_WAVES_PER_EU")) {
-		int lo = 0, hi = 0;
-		if (sscanf(e, "%d,%d", &lo, &hi) == 2 && lo >= 1 && hi >= lo && hi <= 8) { waves_lo = lo; waves_hi = hi; }
-	}
+	 * (128 VGPRs: 427 vs 400 Mpixels/s at 8). */
+	const int waves_lo = P.n_ops <= 32 ? 8 : P.n_ops <= 96 ? 6 : 4, waves_hi = 8;
 	const std::string occupancy = " __attribute__((amdgpu_waves_per_eu(" + std::to_string(waves_lo) + ", " + std::to_string(waves_hi) + ")))";
 	if (ool) s += "struct SdfOut { float best; u32 id; u32 lo, hi; float nanacc; };\n";
 	emit_sdf(s, P, "SpecSdfExact", nullptr, ool, roots, plan, occupancy);
@@ -1541,7 +1521,7 @@ bool has_return_clobbering_branch(const void* data, size_t n_bytes) {
 bool has_return_clobbering_branch(const std::vector<char>& code) { return has_return_clobbering_branch(code.data(), code.size()); }
 
 bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string& arch, std::vector<char>& code,
-                  std::string& log, std::string* src_out = nullptr, const int* shape = nullptr, bool cull = true, int form = SPEC_BY_SIZE) {
+                  std::string& log, std::string* src_out = nullptr, bool cull = true, int form = SPEC_BY_SIZE) {
 	std::string src = generate_source(P, fast, cull, form);
 	if (src_out) *src_out = src;
 	if (const char* dump = tuning_env("LOL_GPU_DUMP_SPEC_SOURCE"))       /* debugging aid: the source as really generated on this device */
@@ -1552,14 +1532,6 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
 	 * a code object compiled under the old one) */
 	std::string arch_opt = "--offload-arch=" + arch;
 	/* -ffp-contract=off: no FMA contraction (the reference has none); the rest are hipcc's defaults made explicit */
-	std::vector<std::string> extra;                     /* LOL_GPU_RTC_FLAGS: extra hipRTC options, for tuning experiments */
-	if (const char* e = tuning_env("LOL_GPU_RTC_FLAGS")) {
-		std::string cur;
-		for (const char* c = e;; c++) {
-			if (*c == ' ' || *c == 0) { if (!cur.empty()) extra.push_back(cur); cur.clear(); if (!*c) break; }
-			else cur += *c;
-		}
-	}
 	/* -fno-slp-vectorize: the SLP pass pairs scalar f32 ops into v_pk_*_f32, which issue at half the
 	 * rate of two scalar ops on gfx950 (tools/valu_rate.hip); measured +10 % Mpixels/s without it. */
 	/* -amdgpu-sched-strategy=max-ilp: schedule for instruction-level parallelism within a wave rather than for
@@ -1567,8 +1539,7 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
 	 * registers; with max-ILP the same instructions run 1.4x faster on 142 - 1024-op scenes and 2 - 5 % faster on the
 	 * example scenes (generate_source sets the matching register budget).  Scheduling only: same instructions, same bits.
 	 * An LLVM that does not know an -mllvm option ends the PROCESS from its option parser, so the option is only
-	 * passed to hipRTC versions it was verified on (hiprtcVersion >= 9.0 = ROCm 7.x); LOL_GPU_RTC_FLAGS can add it
-	 * elsewhere, LOL_GPU_SCHED=default leaves it out. */
+	 * passed to hipRTC versions it was verified on (hiprtcVersion >= 9.0 = ROCm 7.x); LOL_GPU_SCHED=default leaves it out. */
 	std::vector<const char*> opts = { arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
 	                                  "-fno-slp-vectorize" };
 	const char* sched = tuning_env("LOL_GPU_SCHED");
@@ -1590,14 +1561,6 @@ bool compile_spec(const lol_program& P, const FastPaths* fast, const std::string
 		 * has_return_clobbering_branch() below refuses any code object that still shows the pattern. */
 		opts.push_back("-mllvm"); opts.push_back("-amdgpu-long-branch-factor=0");
 	}
-	char d0[32], d1[32], d2[32];
-	if (shape) {
-		snprintf(d0, sizeof d0, "-DLOL_WAVE_W=%d", shape[0]);
-		snprintf(d1, sizeof d1, "-DLOL_WAVE_H=%d", shape[1]);
-		snprintf(d2, sizeof d2, "-DLOL_WAVES_X=%d", shape[2]);
-		opts.push_back(d0); opts.push_back(d1); opts.push_back(d2);
-	}
-	for (auto& x : extra) opts.push_back(x.c_str());
 	/* ... and so is the compiler: which libhiprtc this process has loaded.  A Python host gets the one torch ships, a C host the
 	 * system's, a process under rocprofv3 yet another mix — the same source came out as three different code objects — and one
 	 * compiler's output must not be handed to a process that would have compiled something else.
@@ -1735,8 +1698,7 @@ void proofs_to_process(const lol_gpu* ctx) {
 
 FastPaths prove_fast_paths(lol_gpu* ctx, const lol_program& prog) {
 	FastPaths fast;
-	const char* fenv = tuning_env("LOL_GPU_FAST");
-	if (!ctx->want_fast || (fenv && fenv[0] == '0')) return fast;
+	if (!ctx->want_fast) return fast;                  /* (lol_gpu_set_specialize 0 / 3) */
 	proofs_from_process(ctx);
 	if (ctx->sqrt_verified < 0) {
 		ctx->sqrt_verified = 0;                     /* cheapest proven sequence wins */
@@ -1747,15 +1709,10 @@ FastPaths prove_fast_paths(lol_gpu* ctx, const lol_program& prog) {
 	}
 	fast.sqrt_kind = ctx->sqrt_verified;
 	fast.sqrt_tiny_ok = ctx->sqrt_tiny_ok;
-	/* gamma + quantisation through the table (lol_kernel.h); LOL_GPU_GAMMA_TABLE=0: through powf (A/B runs) */
-	{
-		const char* genv = tuning_env("LOL_GPU_GAMMA_TABLE");
-		if (!(genv && genv[0] == '0')) {
-			if (ctx->gamma_verified < 0) ctx->gamma_verified = run_verify_gamma(ctx) == 0 ? 1 : 0;
-			else if (ctx->gamma_verified == 1 && !ctx->d_gamma && !build_gamma_table(ctx)) ctx->gamma_verified = 0;      /* proven by another context of this device: only the table */
-			fast.gamma_ok = ctx->gamma_verified == 1;
-		}
-	}
+	/* gamma + quantisation through the table (lol_kernel.h) */
+	if (ctx->gamma_verified < 0) ctx->gamma_verified = run_verify_gamma(ctx) == 0 ? 1 : 0;
+	else if (ctx->gamma_verified == 1 && !ctx->d_gamma && !build_gamma_table(ctx)) ctx->gamma_verified = 0;      /* proven by another context of this device: only the table */
+	fast.gamma_ok = ctx->gamma_verified == 1;
 	for (uint32_t i = 0; i < prog.n_ops; i++) {
 		const lol_op& o = prog.ops[i];
 		if (o.op != LOL_OP_SMIN && o.op != LOL_OP_SMIN_R) continue;
@@ -1771,8 +1728,7 @@ FastPaths prove_fast_paths(lol_gpu* ctx, const lol_program& prog) {
 			ctx->div_verified.push_back({ kb, ok, nf });
 		}
 		if (ok && !fast.has(o.f[0])) fast.div_ok.push_back(o.f[0]);
-		/* LOL_GPU_SMIN_FIXUP=1: keep v_div_fixup in every blend factor (A/B runs) */
-		if (nf && !fast.has_nf(o.f[0]) && !(tuning_env("LOL_GPU_SMIN_FIXUP") && tuning_env("LOL_GPU_SMIN_FIXUP")[0] == '1')) fast.div_nf_ok.push_back(o.f[0]);
+		if (nf && !fast.has_nf(o.f[0])) fast.div_nf_ok.push_back(o.f[0]);
 	}
 	proofs_to_process(ctx);
 	return fast;
@@ -1859,13 +1815,6 @@ void start_specialise(lol_gpu* ctx, const FastPaths& fast) {
 		const std::string sw = lol_gpu_tuning_switches();
 		if (!sw.empty()) job->note += "tuning switches in effect (LOL_GPU_TUNING=1): " + sw + "\n";
 	}
-	/* tuning knobs for the pixel footprint of the specialised kernel (defaults: lol_kernel.h LOL_WAVE_W/H, LOL_WAVES_X) */
-	if (const char* e = tuning_env("LOL_GPU_WAVE_SHAPE")) {
-		int a = 0, b = 0, c = 0;
-		if (sscanf(e, "%dx%dx%d", &a, &b, &c) == 3 && a > 0 && b > 0 && a * b == 64 && c >= 1 && c <= 16) {
-			job->shape[0] = a; job->shape[1] = b; job->shape[2] = c;
-		}
-	}
 	job->cull = culling_enabled(ctx->want_cull);
 	/* Two tiers for mid-size scenes (round 5).  With its SDF inlined into the three loops a scene of 257 ... 1024 ops renders
 	 * 14 - 88 % faster than with the one out-of-line function (profiles/r5_large_scene_ab.jsonl, r5_field_inline_ab.jsonl) —
@@ -1891,7 +1840,7 @@ void launch_job(SpecJob* job) {
 		std::string log;
 		try {
 			std::lock_guard<std::mutex> rtc(g_rtc_mutex);
-			ok = compile_spec(job->prog->p, job->fast.get(), job->arch, code, log, nullptr, job->shape, job->cull, job->form);
+			ok = compile_spec(job->prog->p, job->fast.get(), job->arch, code, log, nullptr, job->cull, job->form);
 		} catch (...) { ok = false; log = "the scene compiler ran out of memory"; }
 		std::lock_guard<std::mutex> lock(job->mu);
 		job->compile_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - job->started).count();
@@ -1931,14 +1880,13 @@ bool finish_specialise(lol_gpu* ctx, bool wait) {
 		const bool second = ctx->second_tier_running;
 		ctx->second_tier_running = false;
 		changed = true;
-		/* the scene's second run (the form with the SDF inlined) behind the first: same program, proofs, shape */
+		/* the scene's second run (the form with the SDF inlined) behind the first: same program and proofs */
 		auto start_second_tier = [&]() {
 			ctx->second_tier_pending = false;
 			SpecJob* next = nullptr;
 			try {
 				next = new SpecJob;
 				next->prog = job->prog; next->fast = job->fast; next->arch = job->arch; next->cull = job->cull;
-				memcpy(next->shape, job->shape, sizeof next->shape);
 				next->form = SPEC_INLINE;
 			} catch (...) { delete next; next = nullptr; }
 			if (!next) return false;
@@ -1988,8 +1936,11 @@ bool finish_specialise(lol_gpu* ctx, bool wait) {
 			if (!wait || !ctx->job) return true;
 			continue;
 		}
-		if (hipModuleGetFunction(&steps_fn, mod, "lol_render_spec_steps") != hipSuccess) steps_fn = nullptr;      /* (one kernel: it counts) */
+		/* (a module with one kernel: that one counts.  Asked for only where it was generated — a failed look-up leaves
+		 * hipErrorNotFound behind as the thread's last error, which the host's next HIP call would trip over — and cleared anyway) */
+		if (job->prog->p.n_ops > LOL_SPEC_TWO_KERNELS_MAX_OPS || hipModuleGetFunction(&steps_fn, mod, "lol_render_spec_steps") != hipSuccess) steps_fn = nullptr;
 		if (hipModuleGetFunction(&sdf_fn, mod, "lol_sdf_spec") != hipSuccess) sdf_fn = nullptr;
+		(void)hipGetLastError();
 		if (ctx->spec_module) {
 			/* the first tier's module: frames launched through it may still be in flight, so it is only unloaded by the next
 			 * upload (which drains the device first) or with the context */
@@ -2000,7 +1951,6 @@ bool finish_specialise(lol_gpu* ctx, bool wait) {
 		ctx->spec_fn = fn;
 		ctx->spec_steps_fn = steps_fn;
 		ctx->spec_sdf_fn = sdf_fn;
-		ctx->wave_w = job->shape[0]; ctx->wave_h = job->shape[1]; ctx->waves_x = job->shape[2];
 		ctx->spec_log = (second ? ctx->spec_log + "second tier (SDF inlined): " : job->note) + job->log + (job->log.empty() || job->log.back() == '\n' ? "" : "\n");
 		snprintf(ctx->kernel_name, sizeof ctx->kernel_name, "lol_render_spec");
 		ctx->spec_key = fnv_hex(job->code.data(), job->code.size());
@@ -2096,12 +2046,10 @@ int lol_gpu_set_specialize_max_ops(lol_gpu* ctx, unsigned max_ops) {
 
 /* which of the wanted skips the uploaded program (and the environment) allows */
 static void resolve_skips(lol_gpu* ctx) {
-	const char* ms = tuning_env("LOL_GPU_MISS_SKIP");                  /* the environment switches still win */
-	const char* ss = tuning_env("LOL_GPU_SHADOW_SETTLE");
-	const unsigned want = (ms && ms[0] == '0') ? 0u : ctx->want_skips;
+	const unsigned want = ctx->want_skips;
 	ctx->miss_skip = (want & 1u) && miss_skip_ok(ctx->h_prog);
 	ctx->dark_skip = (want & 2u) && dark_skip_ok(ctx->h_prog);
-	ctx->shadow_settle = (want & 4u) && shadow_settle_ok(ctx->h_prog) && !(ss && ss[0] == '0');
+	ctx->shadow_settle = (want & 4u) && shadow_settle_ok(ctx->h_prog);
 }
 
 int lol_gpu_set_exact_skips(lol_gpu* ctx, unsigned mask) {
@@ -2199,17 +2147,7 @@ __global__ __launch_bounds__(LPT_THREADS) void lpt_identity_kernel(uint32_t* ord
  * lane_pixels[64 * slot + lane] = column | local row << 16 | LANE_PADDING; wave slot = 16 * region + k.
  */
 struct RegionShape { uint32_t w, h; };       /* multiples of 16 x 4; w * h a power of two <= 4096 (the sort's LDS) */
-static RegionShape region_shape() {
-	static const RegionShape shape = [] {
-		RegionShape r = { 64, 16 };
-		if (const char* e = tuning_env("LOL_GPU_REGION")) {      /* WxH, for A/B runs */
-			unsigned a = 0, b = 0;
-			if (sscanf(e, "%ux%u", &a, &b) == 2 && a % 16 == 0 && b % 4 == 0 && a * b >= 64 && a * b <= 4096 && ((a * b) & (a * b - 1)) == 0) r = { a, b };
-		}
-		return r;
-	}();
-	return shape;
-}
+static RegionShape region_shape() { return { 64, 16 }; }      /* (swept in round 4: profiles/r4_region_sweep.txt) */
 
 /* the first frame of a view: wave k of a region = its k-th 16x4 rectangle (what a launch without tables shades) */
 __global__ __launch_bounds__(LPT_THREADS) void deal_rectangles_kernel(uint32_t* lane_pixels, uint32_t n_lanes, uint32_t w, uint32_t n_rows, uint32_t regions_x,
@@ -2301,10 +2239,7 @@ __global__ __launch_bounds__(LPT_THREADS) void lpt_scatter_kernel(const uint32_t
 	if (i < n) order_out[lol::tile_slot(base[k] + rank, stride)] = order_in[lol::tile_slot(i, stride)];
 }
 
-static unsigned lpt_resort_period() {
-	static const unsigned period = [] { const char* e = tuning_env("LOL_GPU_LPT_RESORT"); const int v = e ? atoi(e) : 0; return v > 0 ? (unsigned)v : LPT_RESORT; }();
-	return period;
-}
+static unsigned lpt_resort_period() { return LPT_RESORT; }
 
 static void lpt_release_set(lol_gpu::TileLpt& T) {
 	for (uint32_t** p : { &T.d_order[0], &T.d_order[1], &T.d_cost, &T.d_keys, &T.d_hist, &T.d_lanes })
@@ -2788,8 +2723,7 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->frame_streams[ctx->frame_rr++ % (unsigned)ctx->n_frame_streams];
 	LOL_HIP(ctx, hipSetDevice(ctx->device));
 	finish_specialise(ctx, false);           /* the frame boundary at which a finished scene kernel takes over */
-	const bool spec = ctx->spec_fn != nullptr;
-	const int tile_w = spec ? ctx->wave_w * ctx->waves_x : lol::TILE_W, tile_h = spec ? ctx->wave_h : lol::TILE_H;
+	const int tile_w = lol::TILE_W, tile_h = lol::TILE_H;      /* both kernels: one 16 x 4 wave per block (lol_kernel.h) */
 	const int block = tile_w * tile_h;
 	dim3 grid((w + tile_w - 1) / tile_w, (n_rows + tile_h - 1) / tile_h);
 	const size_t common = (size_t)(lol::common_lds_dwords(P.n_lights, P.n_materials, P.n_roots) - lol::TILE_W * lol::TILE_H + block) * 4;
@@ -3165,7 +3099,7 @@ int lol_gpu_compile_offline(const lol_program* prog, const char* arch, const cha
 		/* on the large-stack thread, like every run of the scene compiler (BigStackThread) */
 		BigStackThread th;
 		auto work = [&]() {
-			try { std::lock_guard<std::mutex> rtc(g_rtc_mutex); ok = compile_spec(*prog, &fast, arch, code, lg, &src, nullptr, culling_enabled(1)); }
+			try { std::lock_guard<std::mutex> rtc(g_rtc_mutex); ok = compile_spec(*prog, &fast, arch, code, lg, &src, culling_enabled(1)); }
 			catch (...) { ok = false; lg = "the scene compiler ran out of memory"; }
 		};
 		bool started = false;

@@ -392,7 +392,6 @@ int lol_gpu_multi_create(const int* devices, int n, lol_gpu_multi** out) {
 		for (int s = 0; s < SLOTS && e == hipSuccess; s++) e = hipEventCreateWithFlags(&m->done[s], hipEventDisableTiming);
 		if (e != hipSuccess) return bail("event setup", hipGetErrorString(e));
 	}
-	if (const char* e = lol_gpu_internal_tuning_env("LOL_GPU_MULTI_HOST_VIA_ROOT")) m->host_via_root = e[0] == '1';
 	*out = m;
 	return LOL_GPU_OK;
 }

@@ -10,10 +10,16 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 SCENES = os.path.join(ROOT, "tests", "golden", "scenes")
 
-# The library honours its LOL_GPU_* A/B switches only beside LOL_GPU_TUNING=1 (include/lol_gpu.h, lol_gpu_tuning_switches): the
-# tests that compare code paths set such switches, so the test session opts in.  tests/test_cabi.py checks the fence itself in
-# processes that do not.
-os.environ.setdefault("LOL_GPU_TUNING", "1")
+# The library honours its LOL_GPU_* A/B switches only beside LOL_GPU_TUNING=1 (include/lol_gpu.h, lol_gpu_tuning_switches).  The test
+# session does NOT opt in (rounds 4 - 5 did, and every test ran in a process state no product host has): a test that compares
+# code paths sets LOL_GPU_TUNING=1 with monkeypatch beside the switch it sets, and the fixture below sees to it that no other does.
+os.environ.pop("LOL_GPU_TUNING", None)
+
+
+@pytest.fixture(autouse=True)
+def _fence_closed_unless_asked():
+    assert "LOL_GPU_TUNING" not in os.environ, "a test left LOL_GPU_TUNING set (use monkeypatch: it is undone after the test)"
+    yield
 
 
 def pytest_configure(config):

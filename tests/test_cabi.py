@@ -147,17 +147,18 @@ def test_code_objects_are_cached_on_disk(tmp_path, scenes):
     os.chmod(cache, 0o700)
     assert "disk cache" in run(cache)
     # the options hipRTC is given are part of the key: another flag set is another kernel
-    env_flags = dict(os.environ, LOL_GPU_CACHE_DIR=cache, LOL_GPU_RTC_FLAGS="-DLOL_SOMETHING=1")
+    env_flags = dict(os.environ, LOL_GPU_CACHE_DIR=cache, LOL_GPU_TUNING="1", LOL_GPU_SCHED="default")
     p = subprocess.run([sys.executable, "-c", code], env=env_flags, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "disk cache" not in p.stdout
     assert "disk cache" not in run("")                            # switched off: compiles, writes nothing
 
 
 def test_tuning_switches_are_fenced_and_recorded(tmp_path):
-    """Round-4 review: LOL_GPU_RTC_FLAGS=-ffp-contract=fast inherited from some shell would silently end parity.  The library's
-    A/B switches are honoured only beside LOL_GPU_TUNING=1: a plain process with the flag set compiles the SAME code object as
-    one without (and says on stderr that it ignored the switch); with LOL_GPU_TUNING=1 the flag takes effect, another code
-    object comes out, and lol_gpu_tuning_switches() names it."""
+    """Round-4 review: a switch inherited from some shell must never silently change what is compiled (the one that could end
+    parity, LOL_GPU_RTC_FLAGS, is gone since round 6; ten remain).  The library's A/B switches are honoured only beside
+    LOL_GPU_TUNING=1: a plain process with switches set compiles the SAME code object as one without (and says on stderr that it
+    ignored them); with LOL_GPU_TUNING=1 a switch takes effect, another code object comes out, and lol_gpu_tuning_switches()
+    names it."""
     import subprocess
     import sys
     code = ("import sys, hashlib; sys.path.insert(0, %r)\n"
@@ -177,13 +178,16 @@ def test_tuning_switches_are_fenced_and_recorded(tmp_path):
 
     plain, sw, err = run("plain")
     assert sw == "" and "LOL_GPU_TUNING" not in err
-    fenced, sw, err = run("fenced", LOL_GPU_RTC_FLAGS="-ffp-contract=fast", LOL_GPU_SCHED="default", LOL_GPU_CULL="0")
+    fenced, sw, err = run("fenced", LOL_GPU_SCHED="default", LOL_GPU_CULL_CLUSTERS="0", LOL_GPU_SPEC_INLINE_MAX="0")
     assert fenced == plain and sw == ""                            # same kernel, nothing in effect ...
-    for name in ("LOL_GPU_RTC_FLAGS", "LOL_GPU_SCHED", "LOL_GPU_CULL"):
+    for name in ("LOL_GPU_SCHED", "LOL_GPU_CULL_CLUSTERS", "LOL_GPU_SPEC_INLINE_MAX"):
         assert f"{name} is set but LOL_GPU_TUNING=1 is not: ignored" in err      # ... and said so, once each
         assert err.count(name + " is set") == 1
-    tuned, sw, err = run("tuned", LOL_GPU_TUNING="1", LOL_GPU_RTC_FLAGS="-ffp-contract=fast")
-    assert tuned != plain and "LOL_GPU_RTC_FLAGS=-ffp-contract=fast" in sw and "ignored" not in err
+    tuned, sw, err = run("tuned", LOL_GPU_TUNING="1", LOL_GPU_SCHED="default")
+    assert tuned != plain and "LOL_GPU_SCHED=default" in sw and "ignored" not in err
+    # a switch of rounds 2 - 5 that no longer exists does nothing, fenced or not
+    gone, sw, err = run("gone", LOL_GPU_TUNING="1", LOL_GPU_RTC_FLAGS="-ffp-contract=fast", LOL_GPU_SHADOW_FDIV="1", LOL_GPU_WAVE_SHAPE="8x8x1")
+    assert gone == plain and sw == ""
     again, sw, _ = run("again", LOL_GPU_TUNING="1")                # the opt-in alone changes nothing
     assert again == plain and sw == ""
     _, sw, _ = run("yes", LOL_GPU_TUNING="yes", LOL_GPU_SCHED="default")         # only the literal 1 opts in

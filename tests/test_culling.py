@@ -190,6 +190,7 @@ def test_many_objects_are_grouped_into_nested_clusters(tmp_path, monkeypatch):
     sc = _field_scene(64, 5)
     gpu.compile_offline(sc.flatten(), str(tmp_path / "kd"))
     kd = open(str(tmp_path / "kd.hip")).read()
+    monkeypatch.setenv("LOL_GPU_TUNING", "1")      # (the library honours A/B switches only beside this)
     monkeypatch.setenv("LOL_GPU_CULL_CLUSTERS", "0")
     gpu.compile_offline(sc.flatten(), str(tmp_path / "flat"))
     flat = open(str(tmp_path / "flat.hip")).read()
@@ -208,6 +209,7 @@ def test_fields_of_many_objects_match_the_oracle(monkeypatch, clusters):
     oracle, for each shape of the culling plan, specialised kernel and interpreter (which carries the same tests)."""
     import torch
     from test_gpu_parity import check_against_oracle, gpu_render
+    monkeypatch.setenv("LOL_GPU_TUNING", "1")      # (the library honours A/B switches only beside this)
     monkeypatch.setenv("LOL_GPU_CULL_CLUSTERS", clusters)
     for n, seed, w, h in ((10, 1, 64, 40), (40, 2, 56, 32), (120, 3, 48, 28)):
         sc = _field_scene(n, seed)
@@ -269,6 +271,7 @@ def test_big_operands_of_a_smooth_union_get_a_saturation_test(tmp_path, monkeypa
     assert tests_in(src) == 1                       # the root's `a` (32 spheres)
     exact = src[src.index("struct SpecSdfExact"):src.index("struct SpecSdfFast")]
     assert "+ 0.f;" not in exact and "sminf_fastdiv" not in exact
+    monkeypatch.setenv("LOL_GPU_TUNING", "1")      # (the library honours A/B switches only beside this)
     monkeypatch.setenv("LOL_GPU_SAT_CULL_MIN_PRIMS", "16")
     gpu.compile_offline(sc.flatten(), str(tmp_path / "s"), assume_fast=True)
     assert tests_in(open(str(tmp_path / "s.hip")).read()) == 3      # + the `a` of both 32-sphere halves
@@ -289,6 +292,7 @@ def test_saturation_culling_changes_nothing(monkeypatch, min_prims):
     import torch
     import test_gpu_fuzz as F
     from test_gpu_parity import check_against_oracle, gpu_render
+    monkeypatch.setenv("LOL_GPU_TUNING", "1")      # (the library honours A/B switches only beside this)
     monkeypatch.setenv("LOL_GPU_SAT_CULL_MIN_PRIMS", min_prims)
     r = gpu.Renderer(0)
     for depth, smooth, w, h in ((5, 0.5, 64, 36), (7, 0.5, 40, 24), (5, 2.0, 48, 28)):

@@ -186,6 +186,7 @@ def test_large_scenes_are_specialised_too(torch_cuda, monkeypatch, n_unions, inl
     """Round 1 left scenes above 128 ops to the interpreter.  Every program the library accepts is now specialised:
     the SDF inlined up to 1024 ops (256 before round 5), as one out-of-line function beyond (LOL_GPU_SPEC_INLINE_MAX) — same pixels."""
     if inline_max is not None:
+        monkeypatch.setenv("LOL_GPU_TUNING", "1")      # (the library honours A/B switches only beside this)
         monkeypatch.setenv("LOL_GPU_SPEC_INLINE_MAX", str(inline_max))
     sc = chain_scene(n_unions)
     assert sc.flatten().n_ops == 2 * n_unions + 4
@@ -224,6 +225,7 @@ def test_unions_of_unions_with_one_smoothness(torch_cuda, monkeypatch):
         sc = S.Scene.parse_string(text)
         frames = []
         for fuse in ("1", "0"):
+            monkeypatch.setenv("LOL_GPU_TUNING", "1")      # (the library honours A/B switches only beside this)
             monkeypatch.setenv("LOL_GPU_INTERP_FUSE_POPS", fuse)
             r = gpu.Renderer(0, specialize=4)
             g = gpu_render(torch_cuda, r, sc, 48, 24)
@@ -355,6 +357,7 @@ def test_operand_stack_deeper_than_the_slot_fields(torch_cuda):
 def test_very_large_scenes_stay_on_the_interpreter(torch_cuda, monkeypatch):
     """Above LOL_GPU_SPEC_MAX_OPS the scene compiler does not take a program on (minutes of hipRTC): it renders on the
     interpreter, quietly, with the reason in the log."""
+    monkeypatch.setenv("LOL_GPU_TUNING", "1")      # (the library honours A/B switches only beside this)
     monkeypatch.setenv("LOL_GPU_SPEC_MAX_OPS", "100")
     sc = S.Scene.parse_string(big_field_scene(120, 9, 1))
     r = gpu.Renderer(0)

@@ -532,6 +532,7 @@ def test_scheduling_options_do_not_change_a_bit(torch_cuda, scenes, monkeypatch)
     r = gpu.Renderer(0)
     a = gpu_render(torch_cuda, r, sc, w, h)
     r.close()
+    monkeypatch.setenv("LOL_GPU_TUNING", "1")      # (the library honours A/B switches only beside this)
     monkeypatch.setenv("LOL_GPU_SCHED", "default")
     r = gpu.Renderer(0)
     b = gpu_render(torch_cuda, r, sc, w, h)

@@ -4,7 +4,6 @@
 ops) — compile seconds and Mpixels/s of the INLINED form, scene4 (C3), a 504-op chain and fields of 120 / 250 objects, 1080p / 4K."""
 import json
 import os
-os.environ.setdefault("LOL_GPU_TUNING", "1")
 os.environ["LOL_GPU_CACHE_DIR"] = ""
 os.environ["LOL_GPU_SPEC_INLINE_MAX"] = "100000"
 import sys
@@ -59,4 +58,5 @@ def main():
 
 
 if __name__ == "__main__":
+    os.environ.setdefault("LOL_GPU_TUNING", "1")      # the library honours its A/B switches only beside this (include/lol_gpu.h); only when RUN, not when a test imports the scene builders
     main()

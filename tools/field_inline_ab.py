@@ -4,7 +4,6 @@ loops against the one out-of-line function, 1080p — the counterpart of tools/l
 decision on LOL_SPEC_INLINE_MAX_OPS.  One JSON line per field: ops, Mpixels/s and seconds of render_prepare (disk cache off)."""
 import json
 import os
-os.environ.setdefault("LOL_GPU_TUNING", "1")      # the library honours its A/B switches only beside this (include/lol_gpu.h)
 os.environ["LOL_GPU_CACHE_DIR"] = ""
 import sys
 import time
@@ -54,4 +53,5 @@ def main():
 
 
 if __name__ == "__main__":
+    os.environ.setdefault("LOL_GPU_TUNING", "1")      # the library honours its A/B switches only beside this (include/lol_gpu.h); only when RUN, not when a test imports the scene builders
     main()

@@ -6,7 +6,6 @@ Run on the GPU box:  python tools/large_scene_ab.py [--size 1920x1080]"""
 import argparse
 import json
 import os
-os.environ.setdefault("LOL_GPU_TUNING", "1")      # the library honours its A/B switches only beside this (include/lol_gpu.h)
 import sys
 import time
 
@@ -79,4 +78,5 @@ def main():
 
 
 if __name__ == "__main__":
+    os.environ.setdefault("LOL_GPU_TUNING", "1")      # the library honours its A/B switches only beside this (include/lol_gpu.h); only when RUN, not when a test imports the scene builders
     main()

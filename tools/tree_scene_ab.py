@@ -6,7 +6,6 @@ Run on the GPU box:  python tools/tree_scene_ab.py [--size 1920x1080] [--depths 
 import argparse
 import json
 import os
-os.environ.setdefault("LOL_GPU_TUNING", "1")      # the library honours its A/B switches only beside this (include/lol_gpu.h)
 import sys
 
 import numpy as np
@@ -88,4 +87,5 @@ def main():
 
 
 if __name__ == "__main__":
+    os.environ.setdefault("LOL_GPU_TUNING", "1")      # the library honours its A/B switches only beside this (include/lol_gpu.h); only when RUN, not when a test imports the scene builders
     main()

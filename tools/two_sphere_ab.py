@@ -3,8 +3,9 @@
 groups of spheres `gap` apart over a plane, 1920x1080.  Run twice: LOL_GPU_CULL_TWO_SPHERES=1 / =0.  Prints Mpixels/s per gap."""
 import json
 import os
-os.environ.setdefault("LOL_GPU_TUNING", "1")      # the library honours its A/B switches only beside this (include/lol_gpu.h)
 import sys
+if __name__ == "__main__":
+    os.environ.setdefault("LOL_GPU_TUNING", "1")      # the library honours its A/B switches only beside this (include/lol_gpu.h)
 
 import torch
 

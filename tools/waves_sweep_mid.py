@@ -4,7 +4,6 @@ chains only and before culling clusters, saturation shortcuts and pixel dealing 
 objects, 1080p, LOL_GPU_WAVES_PER_EU = 2,8 / 3,8 / 4,8 (default above 96 ops) / 6,8 / 8,8."""
 import json
 import os
-os.environ.setdefault("LOL_GPU_TUNING", "1")
 os.environ["LOL_GPU_CACHE_DIR"] = ""
 os.environ["LOL_GPU_SPEC_INLINE_MAX"] = "100000"
 import sys
@@ -50,4 +49,5 @@ def main():
 
 
 if __name__ == "__main__":
+    os.environ.setdefault("LOL_GPU_TUNING", "1")      # the library honours its A/B switches only beside this (include/lol_gpu.h); only when RUN, not when a test imports the scene builders
     main()
