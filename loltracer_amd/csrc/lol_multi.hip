@@ -45,8 +45,6 @@
 #include <new>
 #include <thread>
 
-/* lol_gpu.hip: an A/B switch from the environment, honoured only beside LOL_GPU_TUNING=1 and recorded when it is */
-const char* lol_gpu_internal_tuning_env(const char* name);
 
 namespace {
 
