@@ -35,10 +35,11 @@ extern "C" {
  * Version of this binary interface.  It changes whenever an entry point changes its arguments or a structure its layout
  * (4: lol_program carries pointers + counts instead of fixed-capacity arrays; lol_gpu_render_host_end takes the surface's
  * size; lol_gpu_rows is {band, cycle, offset}.  5: lol_gpu_set_frames_in_flight / lol_gpu_next_stream; render_host_begin
- * takes up to four frames; lol_gpu_tuning_switches).  A host compiled against another version must not run: hip_renderer.c
+ * takes up to four frames; lol_gpu_tuning_switches.  6: lol_gpu_verify_shadow_division is gone with the shortcut it
+ * proved; lol::Launch carries the march's first step).  A host compiled against another version must not run: hip_renderer.c
  * and the Python mirror compare lol_gpu_abi_version() of the library they loaded with the macro they were built with.
  */
-#define LOL_GPU_ABI_VERSION 5
+#define LOL_GPU_ABI_VERSION 6
 int lol_gpu_abi_version(void);
 
 typedef struct lol_gpu lol_gpu;      /* one renderer context = one device + one scene */
@@ -232,7 +233,12 @@ long lol_gpu_roctx_ranges(void);
  * are rendered by the ahead-of-time interpreter kernel instead — same bits either way.
  */
 /* enable: 0 = interpreter, plain arithmetic; 1 = specialise, with the proven-exact shortcuts (default);
- * 3 = specialise without them; 4 = interpreter with them.  Takes effect at the next lol_gpu_upload_program. */
+ * 3 = specialise without them; 4 = interpreter with them; 5 = like 1, but a scene of 257 ... 1024 ops keeps its first kernel
+ * (the SDF as one out-of-line function) and nothing is compiled behind it.  Takes effect at the next lol_gpu_upload_program.
+ * What a host should know about the scene compiler: it runs on a thread of its own and cannot be interrupted; lol_gpu_destroy and
+ * the next lol_gpu_upload_program wait for a run that is still at work — up to about 3 s for a first run, and for the SECOND run
+ * of a mid-size scene (the form with the SDF inlined, 14 - 88 % faster) 2 - 18 s.  A host that would rather exit or switch
+ * scenes promptly than have that kernel asks for 5. */
 int         lol_gpu_set_specialize(lol_gpu* ctx, int enable);
 /* The largest program (ops) the scene compiler takes on; larger scenes render on the interpreter, which reads them as data.
  * hipRTC cannot be interrupted once it runs — lol_gpu_destroy and the next upload's compile wait for it — and takes about
@@ -311,7 +317,7 @@ int         lol_gpu_set_cull(lol_gpu* ctx, int enable);
  *     waves of the following frames out longest first — scheduling with costs that are exact, because nothing moved.  Only
  *     the schedule is reused: every pixel is computed from scratch in every frame, and comes out the same.  scene4 at 4K
  *     +24 % over the better of the two fixed orders, scene.lol at 1080p +40 %, the bands of an 8-way split of the 8K frame
- *     +34 %.  A frame whose
+ *     +34 % (LABNOTES.md §3.9).  A frame whose
  *     camera differs from its predecessor's is launched in the better fixed order (as LOL_GPU_TILES_AUTO finds it), with
  *     no table, cost or sort: stale costs are worse than no costs (the reference's arrow keys turn the camera 5.7 degrees
  *     a frame).  The tables live on the stream the first such frame was launched on; frames of the same geometry on

@@ -31,7 +31,7 @@ std::string fbits(float v) {
  *   smooth_union(a, b, k>0): value >= min(a, b) - k/4   (h(1-h) <= 1/4 on the clamped h) → sphere enclosing both + k/4
  *   plane, k <= 0, non-finite or absurdly large fields:                                 no bound — never skipped
  * so value(p) >= |p-C| - R in exact arithmetic.  The kernel's binary32 evaluation differs from that by a few ulps
- * of the magnitudes involved (<= 2^-19 relative to |p-C| + R), which the test below swallows:
+ * of the magnitudes involved (<= 2^-19 relative to |p-C| + R, LABNOTES.md §3.6), which the test below swallows:
  *   R' = R (1 + 2^-10) + (|C|_max + 1) 2^-20, rounded up;   u = (best + R') (1 + 2^-12);
  *   skip  iff  u > 0  and  |p-C|^2 > u^2      (all in binary32; any NaN makes the comparisons false = no skip)
  * which implies |p-C| > (best + R')(1 + 2^-14), hence value(p) > best.  The decision is taken per WAVE: the

@@ -340,7 +340,7 @@ void start_specialise(lol_gpu* ctx, const FastPaths& fast) {
 	 * and takes hipRTC 3 - 18 s instead of 0.4 - 3 s.  So such a scene gets the out-of-line kernel first and the inlined one
 	 * when that is ready: interpreter -> out-of-line kernel -> inlined kernel, each swap at a frame boundary, same pixels on
 	 * all three.  (LOL_GPU_SPEC_INLINE_MAX, a tuning switch, pins ONE form by size as before.) */
-	ctx->second_tier_pending = !tuning_env("LOL_GPU_SPEC_INLINE_MAX") && ctx->h_prog.n_ops > LOL_SPEC_FIRST_TIER_INLINE_MAX_OPS &&
+	ctx->second_tier_pending = ctx->want_second_tier && !tuning_env("LOL_GPU_SPEC_INLINE_MAX") && ctx->h_prog.n_ops > LOL_SPEC_FIRST_TIER_INLINE_MAX_OPS &&
 	                           ctx->h_prog.n_ops <= LOL_SPEC_INLINE_MAX_OPS;
 	ctx->second_tier_running = false;
 	job->form = ctx->second_tier_pending ? SPEC_OUT_OF_LINE : SPEC_BY_SIZE;
@@ -550,9 +550,12 @@ int lol_gpu_device(const lol_gpu* ctx) { return ctx ? ctx->device : -1; }
 
 int lol_gpu_set_specialize(lol_gpu* ctx, int enable) {
 	if (!ctx) return LOL_GPU_ERR_ARG;
-	/* 0 interpreter, plain | 1 specialised + proven fast paths (default) | 3 specialised, plain | 4 interpreter + fast paths */
-	ctx->want_spec = (enable == 1 || enable == 3) ? 1 : 0;
-	ctx->want_fast = (enable == 1 || enable == 4) ? 1 : 0;
+	/* 0 interpreter, plain | 1 specialised + proven fast paths (default) | 3 specialised, plain | 4 interpreter + fast paths |
+	 * 5 = 1 without the second tier of a mid-size scene (the out-of-line kernel stays: nothing compiles behind it) */
+	if (enable < 0 || enable == 2 || enable > 5) return LOL_GPU_ERR_ARG;
+	ctx->want_spec = (enable == 1 || enable == 3 || enable == 5) ? 1 : 0;
+	ctx->want_fast = (enable == 1 || enable == 4 || enable == 5) ? 1 : 0;
+	ctx->want_second_tier = enable != 5;
 	return LOL_GPU_OK;
 }
 
@@ -836,6 +839,7 @@ int lol_gpu_render_device(lol_gpu* ctx, const lol_frame_camera* cam, int w, int 
 	}
 	if (g_roctx.pop) g_roctx.pop();
 	if (e != hipSuccess) return fail(ctx, LOL_GPU_ERR_HIP, "kernel launch", e);
+	if (table) lpt_frame_queued(ctx, s);
 	if (trial >= 0) LOL_HIP(ctx, hipEventRecord(ctx->tiles.ev[2 * trial + 1], s));
 	return LOL_GPU_OK;
 }
@@ -914,7 +918,7 @@ int lol_gpu_render_host(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h,
  * frame in flight.
  *
  * Round 5: and the KERNELS of consecutive frames go to different streams.  A frame is one launch that ends with its slowest
- * waves on half-empty SIMDs; the reference's loop cannot start frame i+1 before frame i has been shown
+ * waves on half-empty SIMDs (LABNOTES.md §3.9); the reference's loop cannot start frame i+1 before frame i has been shown
  * (main.c:189-194), but a host that has handed over the next camera already can: frame i+1's first waves fill frame i's
  * tail (tools/stream_overlap_ab.py: +9 % C3, +13 % the orbit, +67 % scene.lol at 1080p).  That is what helps a camera that
  * MOVES, whose frames cannot be scheduled by their predecessors' costs; a camera that stands still keeps its schedule as

@@ -171,6 +171,7 @@ struct lol_gpu {
 	lol_frame_camera pipe_last_cam{};
 	int          pipe_last_geom[3] = { 0, 0, 0 };
 	int          want_spec = 1;
+	bool         want_second_tier = true; /* lol_gpu_set_specialize(ctx, 5) says no */
 	uint32_t     spec_max_ops = 0;       /* lol_gpu_set_specialize_max_ops: 0 = LOL_SPEC_MAX_OPS */
 	hipModule_t  spec_module = nullptr;
 	hipFunction_t spec_fn = nullptr;
@@ -259,6 +260,8 @@ struct lol_gpu {
 		                                      * waited for: before the tables are freed, or change hands) */
 		unsigned long long stamp = 0;        /* when the set was last used (the least recently used one makes room for a fifth stream) */
 		lol_frame_camera cam_epoch{};        /* the view the tables' costs belong to */
+		hipEvent_t done = nullptr;           /* recorded behind every frame queued through these tables (lpt_frame_queued) */
+		bool     done_recorded = false;
 	};
 	static constexpr int LPT_SETS = 4;
 	TileLpt      lpt[LPT_SETS];
@@ -347,5 +350,6 @@ void lpt_release(lol_gpu* ctx);
 bool lpt_table_for_frame(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h, int max_steps, const lol_gpu_rows* R, int n_rows,
                          int block, hipStream_t s, FrameTables* out);
 int tile_order_for_frame(lol_gpu* ctx, int w, int h, int max_steps, const lol_gpu_rows* R, bool diagnostics, int* trial);
+void lpt_frame_queued(lol_gpu* ctx, hipStream_t s);
 
 #pragma GCC visibility pop

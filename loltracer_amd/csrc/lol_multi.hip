@@ -139,7 +139,7 @@ struct Device {
 	hipStream_t  render = nullptr, xchg = nullptr;
 	hipStream_t  render2 = nullptr;      /* the kernels of the frames in slot 1 (round 5): consecutive frames' kernels overlap — a device's
 	                                      * launch of its bands is a small launch whose ramp and tail the next frame's fills
-	                                      * (rank 0 of an 8-way C4 frame emulated on one GPU: 0.462 -> 0.442 ms per frame) */
+	                                      * (rank 0 of an 8-way C4 frame emulated on one GPU: 0.462 -> 0.442 ms per frame, LABNOTES.md §4) */
 	ncclComm_t   comm = nullptr;
 	uint32_t*    part[SLOTS] = { nullptr, nullptr };
 	size_t       part_bytes = 0;

@@ -167,8 +167,23 @@ static void lpt_release_set(lol_gpu::TileLpt& T) {
 	if (T.d_pixel_cost) { (void)hipFree(T.d_pixel_cost); T.d_pixel_cost = nullptr; }
 	T.cap = 0; T.lanes_cap = 0; T.pixels_cap = 0; T.n_tiles = 0; T.key[0] = 0;
 }
+/* The frame that lpt_table_for_frame has just handed tables to has been queued on `s`: an event of the set's own marks the point
+ * up to which its tables are in use.  What later has to wait for a set — another stream taking it over, a handle that may belong
+ * to a stream created after the set's own was destroyed — waits for THAT event (events belong to the context; round-5 advisor:
+ * a caller's stream handle may be dead, and must not be handed to the runtime again). */
+void lpt_frame_queued(lol_gpu* ctx, hipStream_t s) {
+	if (ctx->lpt_last_set < 0) return;
+	lol_gpu::TileLpt& T = ctx->lpt[ctx->lpt_last_set];
+	if (!T.done && hipEventCreateWithFlags(&T.done, hipEventDisableTiming) != hipSuccess) { T.done = nullptr; (void)hipGetLastError(); return; }
+	if (hipEventRecord(T.done, s) != hipSuccess) (void)hipGetLastError();
+	T.done_recorded = true;
+}
 void lpt_release(lol_gpu* ctx) {
-	for (lol_gpu::TileLpt& T : ctx->lpt) { lpt_release_set(T); T.home = nullptr; T.launched = false; }
+	for (lol_gpu::TileLpt& T : ctx->lpt) {
+		lpt_release_set(T); T.home = nullptr; T.launched = false;
+		if (T.done) { (void)hipEventDestroy(T.done); T.done = nullptr; }
+		T.done_recorded = false;
+	}
 }
 
 /* The table for the frame about to be launched on `s` (device current), or nullptr: a launch in one of the fixed orders.
@@ -214,13 +229,16 @@ bool lpt_table_for_frame(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h
 	if (!Tp) {
 		if (++ctx->lpt_homeless < 2) return false;
 		for (lol_gpu::TileLpt& P : ctx->lpt) if (!Tp || P.stamp < Tp->stamp) Tp = &P;
-		/* (a caller's stream may have been destroyed since: then whatever it still had queued is waited for with the device) */
-		if (!ok(hipStreamSynchronize(Tp->home)) && !ok(hipDeviceSynchronize())) return false;
+		/* (its stream may be a caller's and may be gone: the set's own event says when the last frame through it has finished) */
+		if (Tp->done_recorded ? !ok(hipEventSynchronize(Tp->done)) : (Tp->launched && !ok(hipDeviceSynchronize()))) return false;
 		Tp->launched = false;
 		Tp->key[0] = 0;                                  /* whatever it knew was another stream's schedule */
 	}
 	ctx->lpt_homeless = 0;
 	lol_gpu::TileLpt& T = *Tp;
+	/* `s` carries the handle the set lives on — normally the very stream, where this wait costs nothing; a stream created at the
+	 * address of a destroyed one (whose last frames and table kernels may still be running) is ordered behind them by it */
+	if (T.done_recorded && !ok(hipStreamWaitEvent(s, T.done, 0))) return false;
 	T.home = s;
 	T.stamp = ++ctx->lpt_clock;
 	const bool new_key = memcmp(key, T.key, sizeof key) != 0;

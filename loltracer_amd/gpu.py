@@ -16,7 +16,7 @@ import os
 from . import scene as S
 
 LOL_GPU_OK = 0
-LOL_GPU_ABI_VERSION = 5          # include/lol_gpu.h
+LOL_GPU_ABI_VERSION = 6          # include/lol_gpu.h
 _STATUS = {0: "ok", -1: "no HIP device", -2: "HIP runtime error", -3: "bad argument",
            -4: "no scene program uploaded", -5: "unsupported"}
 

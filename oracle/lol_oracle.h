@@ -7,7 +7,7 @@
  * bench.py's `cpu_baseline` leg may load it; the product (loltracer_amd/,
  * include/lol_gpu.h) never links or calls anything in oracle/.
  *
- * Pinning (details and honest limits in DESIGN.md §5): the reference ships no tests or golden
+ * Pinning (details and honest limits in LABNOTES.md §5): the reference ships no tests or golden
  * images, and naive_renderer.c itself cannot be compiled in this image (it
  * includes <SDL.h> through renderer.h; SDL2 is absent).  The restatement is pinned by
  *  (1) oracle/_ref — the reference's own SDL-free headers (float.h, vec.h, sdf.h) and scene.c

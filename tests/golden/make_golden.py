@@ -416,7 +416,7 @@ class RefPipeline:
                 if res < f32(-1.0) or dist > f32(light_dist):
                     break
         shadow = self.ref.ref_maxf(C.c_float(float(res)), C.c_float(0.0))
-        # what the renderer's early exit rests on, here with the reference's own minf / maxf: a factor that was
+        # what the renderer's early exit rests on (LABNOTES.md §3.7), here with the reference's own minf / maxf: a factor that was
         # <= 0 once comes out 0
         assert not settled or shadow == 0.0, "a settled shadow factor came back"
         self.last_settled_steps = settled or steps

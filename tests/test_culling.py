@@ -1,4 +1,4 @@
-"""Exact culling of top-level objects (lol_gpu.hip "exact culling").
+"""Exact culling of top-level objects (lol_gpu.hip "exact culling", LABNOTES.md §3.6).
 
 CPU part — the proof obligation behind the skip: for every object with a bound (C, R'), the object's distance
 value(p) >= |p - C| - R' at every point.  Checked with the oracle's SDF on thousands of random points around random

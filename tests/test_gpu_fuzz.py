@@ -432,3 +432,25 @@ def test_a_failed_first_tier_does_not_cost_the_scene_its_kernel(torch_cuda, monk
     want, _, _ = O.render(sc, w, h, threads=4)
     assert np.array_equal(buf.cpu().numpy().view(np.uint32), want)
     r.close()
+
+
+def test_a_host_may_decline_the_second_tier(torch_cuda, monkeypatch):
+    """lol_gpu_set_specialize(ctx, 5): a mid-size scene keeps its first (out-of-line) kernel and nothing is compiled behind it —
+    for a host that would rather exit or switch scenes promptly (the scene compiler cannot be interrupted; lol_gpu_destroy
+    waits for it).  Same pixels."""
+    import time
+    monkeypatch.setenv("LOL_GPU_CACHE_DIR", "")
+    sc = chain_scene(140, seed=int(time.time()) % 9929)
+    assert 256 < sc.flatten().n_ops <= 1024
+    w, h = 48, 28
+    r = gpu.Renderer(0, specialize=5)
+    r.prepare(sc)                                                    # (waits for the scene compiler: there is only one run to wait for)
+    buf = torch_cuda.zeros((h, w), dtype=torch_cuda.int32, device="cuda")
+    r.render_into(buf.data_ptr(), w, h)
+    r.sync()
+    assert r.kernel_name() == "lol_render_spec" and r.specialize_state()[0] == 2 and "second tier" not in r.specialize_log()
+    want, _, _ = O.render(sc, w, h, threads=4)
+    assert np.array_equal(buf.cpu().numpy().view(np.uint32), want)
+    t0 = time.perf_counter()
+    r.close()
+    assert time.perf_counter() - t0 < 1.0                            # nothing to wait for

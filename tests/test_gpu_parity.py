@@ -6,6 +6,7 @@ count and shadow step count of every pixel are EQUAL to the oracle's — and the
 differs by at most 1 LSB in any channel (powf is the only non-bit-exact operation).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -498,6 +499,23 @@ def test_baseline_configs_2_and_4_at_full_size(torch_cuda, scenes):
         check_against_oracle(sub, sc, w, h, y0=y, y1=y + 1)
     full = g["xrgb"]
     del g
+    # ... and EVERY pixel of both frames as a product host gets them (round-5 review): no diagnostics buffers (the kernel without
+    # step counters), the fifth frame of a view that repeats (scheduled: waves longest first, pixels dealt by cost), against the
+    # oracle's whole frame (all host cores: C4's 33 Mpixels take ~9 s on the GPU box's 16)
+    import torch
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4
+    for name, fw, fh, steps in (("scene", 1920, 1080, 128), ("scene4", 7680, 4320, 256)):
+        fsc = scenes[name]
+        r.prepare(fsc)
+        buf = torch.zeros((fh, fw), dtype=torch.int32, device="cuda")
+        for _ in range(5):
+            r.render_into(buf.data_ptr(), fw, fh, steps)
+        r.sync()
+        assert r.tile_order()["order"] == "lpt"                    # the fifth frame went through the library's tables
+        want, _, _ = O.render(fsc, fw, fh, steps, threads=threads)
+        got = buf.cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, want), f"{name} {fw}x{fh}: {(got != want).sum()} pixels differ from the oracle"
+        del buf, want, got
     from loltracer_amd import multi
     band, n_parts = multi.choose_band_rows(h, 8), 8
     for part in (0, 5):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Can a frame with a NEW camera be dealt by cost too?  The repeated view deals a region's pixels to waves by the evaluation
-counts of the frame before.  For a new camera the only exact knowledge about a frame comes from the frame
+counts of the frame before (LABNOTES.md §3.9).  For a new camera the only exact knowledge about a frame comes from the frame
 itself, so: render every 4th pixel of every 4th row first (1/16 of the pixels; in a 64x16 region exactly one wave), predict
 the cost of the other 15/16 from the samples around them (nearest / bilinear / maximum of the four), deal those by the
 prediction.  CPU model on the oracle's per-pixel step counts (test infrastructure), evaluations a frame executes as in

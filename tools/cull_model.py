@@ -40,7 +40,7 @@ def main():
 
     def blob(p):
         d = [np.sqrt(((p - c) ** 2).sum(-1)) - r for c, r in spheres]
-        return smin(smin(d[0], d[1], k), smin(d[4], smin(d[2], d[3], k), k), k)      # scene4's tree
+        return smin(smin(d[0], d[1], k), smin(d[4], smin(d[2], d[3], k), k), k)      # scene4's tree (LABNOTES.md §3.1)
 
     def sdf(p):
         pl = p[..., 1] - plane_y

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Round 5 experiment: the plain (fallback) SDF out of line where the fast SDF is inlined (LOL_GPU_EXACT_OOL=N: for programs above N
-(the library hunk that read LOL_GPU_EXACT_OOL is not kept: DESIGN.md §8)
+(the library hunk that read LOL_GPU_EXACT_OOL is not kept: LABNOTES.md §8)
 ops) — compile seconds and Mpixels/s of the INLINED form, scene4 (C3), a 504-op chain and fields of 120 / 250 objects, 1080p / 4K."""
 import json
 import os

@@ -85,12 +85,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", default="1920x1080")
     ap.add_argument("--objects", default="4,16,64,150,250")
-    ap.add_argument("--min-prims", default=None)
     ap.add_argument("--leaves", default="3", help="k-d leaf sizes to try (LOL_GPU_CULL_CLUSTERS), comma separated")
     a = ap.parse_args()
     w, h = (int(x) for x in a.size.split("x"))
-    if a.min_prims:
-        os.environ["LOL_GPU_CULL_MIN_PRIMS"] = a.min_prims
     for n in (int(x) for x in a.objects.split(",")):
         sc = field_scene(n)
         prog = sc.flatten()

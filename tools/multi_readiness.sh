@@ -21,7 +21,7 @@ for flags in "" "--pipeline" "--devices 0"; do
 	timeout -k 10 120 $H 8 $S --size 3840x2160 --frames 60 --orbit --wait-kernel $flags > $O/headless_$n.log 2>&1 || exit 1
 	grep Median $O/headless_$n.log
 done
-# ... and the same host with a camera that stands still (the scheduled frame)
+# ... and the same host with a camera that stands still (the scheduled frame, LABNOTES.md §3.9)
 for flags in "" "--pipeline"; do
 	n=$(echo "still$flags" | tr -d ' -')
 	timeout -k 10 120 $H 8 $S --size 3840x2160 --frames 60 --wait-kernel $flags > $O/headless_$n.log 2>&1 || exit 1

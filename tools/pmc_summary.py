@@ -9,7 +9,7 @@ Every CSV is one rocprofv3 pass (one counter group per pass, as MI355X_MICROARCH
 WRITE_SIZE do not fit one pass).  Rows of the named kernel are averaged per counter over its dispatches.
 Traffic per launch = WRITE_SIZE + 2 x FETCH_SIZE in bytes (both are reported in KiB; on gfx950 FETCH_SIZE counts
 128-byte requests as 64 bytes, hence the factor 2 — same guide, HBM section).  Also derives the issue view used in
-DESIGN.md §3.4: cycles per XCD (GRBM_GUI_ACTIVE / 8), clock, cycles per VALU wave-instruction per SIMD.
+LABNOTES.md §3.4: cycles per XCD (GRBM_GUI_ACTIVE / 8), clock, cycles per VALU wave-instruction per SIMD.
 """
 import argparse
 import collections

@@ -26,5 +26,5 @@ import json, glob
 for p in sorted(glob.glob("$O/${TAG}_*.json")):
     d = json.load(open(p))
     print(p.split("/")[-1], d["value"], d["unit"], "equal:", d.get("frame_equal_to_single_launch", d.get("frames_equal_to_rank0_render")),
-          "kernel_ms:", d.get("kernel_ms"), "gather_exposed_ms:", d.get("gather_exposed_ms"))
+          "kernel_ms:", d.get("kernel_ms"), "gather_exposed_ms:", d.get("gather_exposed_ms", d.get("gather_exposed_ms_estimated")))
 PY

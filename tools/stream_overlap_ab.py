@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Do consecutive frames gain from being launched on more than one stream?  A frame is ONE launch of 129,600 one-wave blocks
-whose tail leaves SIMDs half empty (6.2 of 8 waves resident on average); on one stream the next frame's first
+whose tail leaves SIMDs half empty (6.2 of 8 waves resident on average, LABNOTES.md §8); on one stream the next frame's first
 waves wait for the last one's to finish.  Frames of a stream of frames are independent (naive_renderer.c:216), so with two
 destination buffers they may overlap.  Times N frames issued round-robin over 1, 2, 3 streams (same kernel, same frames).
     python tools/stream_overlap_ab.py [--workload c3|c2|c4|orbit|band]"""
