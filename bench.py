@@ -258,18 +258,24 @@ def per_rank_fields(stats: list, ms_per_step: float, overlap: int = 1) -> dict:
                 round(ms_per_step / max(max(k) / overlap, 1e-9), 4)}
 
 
-def cpu_baseline(sc: S.Scene, cfg: dict, target_s: float = 15.0, gpu_frame=None):
-    """Time the CPU oracle on all host cores over a bounded, evenly spread row sample of the frame."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as O
-    w, h, ms = cfg["w"], cfg["h"], cfg["max_steps"]
+def host_cores() -> int:
+    """The host cores this process may really use: its affinity mask, cut to the container's CPU quota when it has one."""
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:                                              # a container's CPU quota, when it has one
+    try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
         if quota != "max":
             cores = max(1, min(cores, int(math.ceil(int(quota) / int(period)))))
     except (OSError, ValueError):
         pass
+    return cores
+
+
+def cpu_baseline(sc: S.Scene, cfg: dict, target_s: float = 15.0, gpu_frame=None):
+    """Time the CPU oracle on all host cores over a bounded, evenly spread row sample of the frame."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    w, h, ms = cfg["w"], cfg["h"], cfg["max_steps"]
+    cores = host_cores()
     lib = O.lib()
     buf = np.zeros((h, w), dtype=np.uint32)
 
@@ -318,7 +324,7 @@ def orbit_parity(r, sc, cfg, timed, stream) -> dict:
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     w, h, ms = cfg["w"], cfg["h"], cfg["max_steps"]
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     frames, seq_equal = [], True
     probe = torch.zeros((h, w), dtype=torch.int32, device="cuda")
     extra = cfg["frames"] // 2 + 1                                  # a camera on the far side of the orbit

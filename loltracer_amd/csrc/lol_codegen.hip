@@ -437,9 +437,19 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 		         "\t__device__ __forceinline__ void loop_done() { %s }\n", name, fast ? "true" : "false", cool_decl,
 		         plan.intervals.empty() ? "" : "cool[0] = 0u;");
 		s += line;
-		s += "\t__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id) {\n";
 	}
-	s += "\t\tbest = __builtin_inff(); best_id = 0u;\n";
+	/* The body twice where it is inlined: eval() — distance and object id — for the primary march and the normal taps, and
+	 * eval_dist() — the distance alone — for the shadow marches, which never look at the id.  There an object joins the running
+	 * minimum with ONE v_min_f32 instead of the compare(s) and selects of the strict-'<' / lower-id-wins rule: the two agree on the
+	 * value except for the sign of a zero (two objects at distance -0 and +0 of the same point), and a shadow march's results —
+	 * its factor maxf(res, 0) and its step count — are the same for s = -0 and s = +0: t + s, 50 s / t compared with 0, and
+	 * maxf(+-0, 0) = +0 all are (lol_kernel.h, soft_shadow).  A NaN value is dropped by either form. */
+	for (int pass = 0; pass < (out_of_line ? 1 : 2); pass++) {
+	const bool dist_only = pass == 1;
+	if (!out_of_line)
+		s += dist_only ? "\t__device__ __forceinline__ void eval_dist(V3 p, float& best) {\n"
+		               : "\t__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id) {\n";
+	s += dist_only ? "\t\tbest = __builtin_inff();\n" : "\t\tbest = __builtin_inff(); best_id = 0u;\n";
 	int t = 0, n_tests = 0;
 	/* After a test that did not allow the skip, the next `cooldown` evaluations of this SDF object do not test
 	 * again (a ray that is near the object now is near it on its next steps too): the test costs 11 VALU
@@ -626,7 +636,9 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 			snprintf(line, sizeof line, "\t\tnanacc = __builtin_fmaf(t%d, 0.f, nanacc);\n", d);
 			s += line;
 		}
-		if (R.id < max_id_seen)      /* evaluated after an object that follows it in the file: ties go to the lower id */
+		if (dist_only)
+			snprintf(line, sizeof line, "\t\tbest = vmin_(t%d, best);\n", d);
+		else if (R.id < max_id_seen)      /* evaluated after an object that follows it in the file: ties go to the lower id */
 			snprintf(line, sizeof line, "\t\tif (t%d < best || (t%d == best && best_id > %uu)) { best = t%d; best_id = %uu; }\n", d, d, R.id, d, R.id);
 		else
 			snprintf(line, sizeof line, "\t\tif (t%d < best) { best = t%d; best_id = %uu; }\n", d, d, R.id);
@@ -634,16 +646,19 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 		if (R.id > max_id_seen) max_id_seen = R.id;
 		for (uint32_t k = 0; k < runs_ending[oi + 1]; k++) s += "\t\t} }\n";               /* every run that ends here */
 	}
+	if (!out_of_line) s += "\t}\n";
+	}      /* pass */
 	if (out_of_line) {
 		s += "\t\treturn { best, best_id, rg.lo, rg.hi, nanacc };\n}\n";
 		snprintf(line, sizeof line, "struct %s {\n\tstatic constexpr bool ASSUME_SETTLED = %s;\n\tRange rg;\n\tfloat nanacc = 0.f;\n"
 		         "\t__device__ __forceinline__ void loop_done() {}\n"
 		         "\t__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id) {\n"
 		         "\t\tconst SdfOut o = %s_fn(p.x, p.y, p.z, rg.lo, rg.hi);\n"
-		         "\t\tbest = o.best; best_id = o.id; rg.lo = o.lo; rg.hi = o.hi; nanacc += o.nanacc;\n\t}\n};\n", name, fast ? "true" : "false", name);
+		         "\t\tbest = o.best; best_id = o.id; rg.lo = o.lo; rg.hi = o.hi; nanacc += o.nanacc;\n\t}\n"
+		         "\t__device__ __forceinline__ void eval_dist(V3 p, float& best) { u32 unused; eval(p, best, unused); }\n};\n", name, fast ? "true" : "false", name);
 		s += line;
 	} else {
-		s += "\t}\n};\n";
+		s += "};\n";
 	}
 }
 bool spec_out_of_line(const lol_program& P, int form) {

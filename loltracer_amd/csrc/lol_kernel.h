@@ -653,6 +653,14 @@ struct Interp {
 
 	/* Inlined into the march / normal / shadow loops: as a real (noinline) function it was 8 % slower — arguments
 	 * travel in VGPRs and need v_readfirstlane, plus call / return and the callee's register shuffling. */
+	/* eval_dist: the distance alone, for the shadow marches, which never look at the id: a finished object joins the running minimum
+	 * with ONE v_min_f32 and no test of MOP_TIE.  Same value as the strict-'<' / lower-id-wins rule except for the sign of a zero,
+	 * which no result of a shadow march depends on (soft_shadow: t + s, 50 s / t against 0, maxf(+-0, 0) = +0).  Round 6: the
+	 * interpreter +4.3 ... 5.6 %, the specialised kernel +0.8 % (C3) ... +8.6 % (C2: four flat objects); profiles/r6_ab_eval_dist.txt.
+	 * (The primary march on the distance alone too, its id asked for once at the point of its last step — built, exact, C2 +3.6 %
+	 * more but C3 -0.8 %: not kept; profiles/r6_ab_id_asked_once.txt.) */
+	__device__ __forceinline__ void eval_dist(V3 p, float& best_out) { u32 unused; eval<false>(p, best_out, unused); }
+	template <bool WITH_ID = true>
 	__device__ __forceinline__ void eval(V3 p, float& best_out, u32& id_out) {
 		/* everything the loop carries is a local: the trip count and the list pointer must stay provably
 		 * wave-uniform (scalar loop, scalar loads, scalar branches), which they do not when they live behind
@@ -755,11 +763,15 @@ struct Interp {
 				}
 				if (hdr & MOP_TOP) {                                    /* (tests only follow finished objects) */
 					LOL_KEEP_BRANCH();
-					const u32 id = w1;
-					bool take = x < best;
-					/* (no short circuit: `take || (eq && gt)` became exec juggling around the second compare; +1.5 % as three plain compares) */
-					if (hdr & MOP_TIE) { LOL_KEEP_BRANCH(); take = take | ((x == best) & (best_id > id)); }
-					if (take) { best = x; best_id = id; }
+					if constexpr (WITH_ID) {
+						const u32 id = w1;
+						bool take = x < best;
+						/* (no short circuit: `take || (eq && gt)` became exec juggling around the second compare; +1.5 % as three plain compares) */
+						if (hdr & MOP_TIE) { LOL_KEEP_BRANCH(); take = take | ((x == best) & (best_id > id)); }
+						if (take) { best = x; best_id = id; }
+					} else {
+						best = vmin_(x, best);
+					}
 					if (hdr & MOPB_CULL_NEXT) {                             /* the run of all bounded objects: the test that cools down */
 						LOL_KEEP_BRANCH();
 						rec += MOP_DWORDS;                                  /* the constants record is consumed either way */
@@ -895,8 +907,8 @@ __device__ __forceinline__ float soft_shadow(Sdf& sdf, V3 p, V3 dir, float max_d
 	if (needed) {
 		for (int i = 0; i < 128; i++) {
 			V3 q = add(ro, scale(dir, t));
-			float s; u32 sid;
-			sdf.eval(q, s, sid);
+			float s;
+			sdf.eval_dist(q, s);                         /* (the distance alone: see Interp::eval_dist / lol_codegen.hip, emit_sdf) */
 			const float v = 50.f * s / t;
 			res = VMIN ? vmin_(res, v) : minf_(res, v);
 			t += s;

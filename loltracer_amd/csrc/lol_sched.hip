@@ -238,7 +238,11 @@ bool lpt_table_for_frame(lol_gpu* ctx, const lol_frame_camera* cam, int w, int h
 	lol_gpu::TileLpt& T = *Tp;
 	/* `s` carries the handle the set lives on — normally the very stream, where this wait costs nothing; a stream created at the
 	 * address of a destroyed one (whose last frames and table kernels may still be running) is ordered behind them by it */
-	if (T.done_recorded && !ok(hipStreamWaitEvent(s, T.done, 0))) return false;
+	/* (not for HIP's two special handles — the legacy default stream and the per-thread one: they name no stream OBJECT that could
+	 * have been destroyed and created again, and this HIP's hipStreamWaitEvent dereferences the handle it is given: a crash, found
+	 * by the GPU suite, whose frames run on the legacy default stream) */
+	const bool special = s == hipStreamLegacy || s == hipStreamPerThread || s == nullptr;
+	if (T.done_recorded && !special && !ok(hipStreamWaitEvent(s, T.done, 0))) return false;
 	T.home = s;
 	T.stamp = ++ctx->lpt_clock;
 	const bool new_key = memcmp(key, T.key, sizeof key) != 0;

@@ -1,8 +1,8 @@
 export LOL_GPU_TUNING=1   # the library honours its A/B switches only beside this (include/lol_gpu.h)
 # Round profile on the GPU box: kernel-trace stats + PMC passes of the default bench (C3) for BOTH kernels, the
 # other BASELINE workloads, and the summaries.  Everything lands under gpurun_out/prof_final; copy what is to be
-# judged into profiles/ (see profiles/README.md).   usage: bash tools/final_profile.sh [round-tag, default r5]
-TAG=${1:-r5}
+# judged into profiles/ (see profiles/README.md).   usage: bash tools/final_profile.sh [round-tag, default r6]
+TAG=${1:-r6}
 export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}; O=$R/gpurun_out/prof_final
 rm -rf "$O"; mkdir -p "$O"; cd /tmp
 export LOL_BENCH_HOST_SURFACE=0                     # the PMC passes time kernels; the host-surface leg has its own record
@@ -66,5 +66,5 @@ done
 cd $R
 unset LOL_BENCH_STARTUP LOL_BENCH_SCHEDULING LOL_BENCH_HOST_SURFACE LOL_BENCH_FRAMES_IN_FLIGHT_LEG
 python3 bench.py 2> /dev/null | grep -o '^{.*' > $O/${TAG}_spec_c3_plain_bench.json
-for w in c2 c4 orbit; do python3 bench.py --no-cpu-baseline --workload $w 2> /dev/null | grep -o '^{.*' > $O/${TAG}_spec_${w}_1gpu_bench.json; done
+for w in c2 c4 orbit; do python3 bench.py --workload $w 2> /dev/null | grep -o '^{.*' > $O/${TAG}_spec_${w}_1gpu_bench.json; done
 ls $O | grep -v "^spec_\|^interp_\|^stats$"
