@@ -239,9 +239,11 @@ def _json_lines(text):
     out = []
     for ln in text.splitlines():
         try:
-            out.append(json.loads(ln))
+            d = json.loads(ln)
         except ValueError:
-            pass
+            continue
+        if isinstance(d, dict):
+            out.append(d)
     return out
 
 

@@ -97,7 +97,9 @@ def test_scene_specialised_kernel_compiles_without_a_device(tmp_path, scenes):
         assert "lol_render_spec" in src and "sd_sphere" in src
         assert os.path.getsize(base + ".co") > 1000
     src4 = open(str(tmp_path / "scene4") + ".hip").read()
-    assert src4.count("sminf_(") == 4 and src4.count("sd_sphere(") == 5 and "best_id = 2u" in src4
+    # (the body twice: eval() with the object id, eval_dist() — the distance alone — for the shadow marches)
+    assert src4.count("sminf_(") == 2 * 4 and src4.count("sd_sphere(") == 2 * 5 and "best_id = 2u" in src4
+    assert src4.count("void eval(") == 1 and src4.count("void eval_dist(") == 1 and src4.count("best = vmin_(") == 2
     # constants are emitted as exact bit patterns: sphere radius 0.5 and smoothness 3
     assert "0x3f000000u" in src4 and "0x40400000u" in src4
 

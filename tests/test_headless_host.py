@@ -95,7 +95,7 @@ def test_dump_kernel_flag_is_the_jitdump_counterpart(tmp_path):
                        capture_output=True, text=True, timeout=120)
     assert p.returncode == 0
     src = open(str(base) + ".hip").read()
-    assert "lol_render_spec" in src and src.count("sd_sphere(") == 5
+    assert "lol_render_spec" in src and src.count("sd_sphere(") == 2 * 5      # (eval and eval_dist)
     assert os.path.getsize(str(base) + ".co") > 1000
 
 
