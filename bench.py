@@ -1135,7 +1135,8 @@ def main():
                                        if P is not None else ", one kernel launch per frame")
                                       + ", STILL CAMERA: the same view frame after frame (every pixel computed again in every frame; the "
                                         "library schedules a frame by what the frame before it cost — `value_new_view` is the rate of a frame "
-                                        "whose camera has just moved)"),
+                                        "whose camera has just moved; frames stay on the device — `value_through_render_thread_as_main_c_calls_it` "
+                                        "is what a host gets through the reference's unmodified protocol, one frame at a time into a host surface)"),
                        "width": w, "height": h, "max_steps": max_steps, "band_rows": band, "frames_in_flight": fif,
                        "kernel_streams": len(kstreams) if kstreams else 1,
                        "camera": "moving (orbit)" if orbit else "still (repeated view)",
@@ -1237,6 +1238,11 @@ def main():
                 torch.cuda.synchronize()
                 hs_cams = [orbit_camera(i, 256) for i in range(0, 256, 16)] if orbit else None
                 out["host_surface"] = host_surface_rates(r, sc, cfg, hs_cams)
+                # beside `value` (frames that stay on the device), at the top level: what a host gets through the reference's UNMODIFIED
+                # protocol — render_thread as main.c:189-194 calls it: one frame at a time, into a host surface, kernel and PCIe copy in
+                # series — and with --pipeline (frame i - 1 reaches the surface while frame i renders)
+                out["value_through_render_thread_as_main_c_calls_it"] = out["host_surface"]["sync_mpixels_per_s"]
+                out["value_through_render_thread_pipelined"] = out["host_surface"]["pipelined_mpixels_per_s"]
             leg("host_surface", host_leg)
         sys.stdout.flush()
         os.write(record_fd, (json.dumps(out) + "\n").encode())
