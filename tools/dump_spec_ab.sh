@@ -4,7 +4,7 @@ export LOL_GPU_TUNING=1   # the library honours its A/B switches only beside thi
 # usage on the GPU box: bash tools/dump_spec_ab.sh [c2|c3]   → gpurun_out/specsrc/<lib>.<workload>.hip
 R=${GRAFT_REPO_ROOT:?run on the GPU box}; cd $R; W=${1:-c2}; mkdir -p gpurun_out/specsrc
 for lib in loltracer_amd/lib/liblol_gpu.so tools/ab/*.so; do n=$(basename $lib .so)
-	LOL_GPU_LIB=$R/$lib LOL_GPU_CACHE=0 LOL_GPU_DUMP_SPEC_SOURCE=$R/gpurun_out/specsrc/$n.$W.hip LOL_BENCH_HOST_SURFACE=0 \
+	LOL_GPU_LIB=$R/$lib LOL_GPU_CACHE_DIR= LOL_GPU_DUMP_SPEC_SOURCE=$R/gpurun_out/specsrc/$n.$W.hip LOL_BENCH_HOST_SURFACE=0 \
 		python3 bench.py --no-cpu-baseline --steps 3 --workload $W 2> gpurun_out/specsrc/$n.err |
 		python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$n', d['value'], d['config']['kernel_key'])"
 done
