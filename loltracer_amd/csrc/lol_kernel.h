@@ -910,19 +910,19 @@ __device__ __forceinline__ float soft_shadow(Sdf& sdf, V3 p, V3 dir, float max_d
 			float s;
 			sdf.eval_dist(q, s);                         /* (the distance alone: see Interp::eval_dist / lol_codegen.hip, emit_sdf) */
 			/* The quotient 50 s / t (11 instructions, one of them v_rcp) is only needed where it can lower the minimum.  In the fast
-			 * pipeline (VMIN: every lane still marching has 0 < res <= 1, never NaN, and 0 <= t < 10^17): with a = 50 s and
-			 * c = fma(fl(res t), K, 2^-125), K = 1 + 2^-21,
-			 *   a > c  =>  a >= res t  =>  a / t >= res  =>  fl(a / t) >= res       (rounding is monotone, res is a float)
-			 * and v_min leaves res as it is.  The first step: where b = fl(res t) is a normal number it is within 2^-24 of res t, and
-			 * c >= b K (1 - 2^-24) >= b (1 + 2^-22) >= res t; where it is not (res t < 2^-126, t = 0 included: the quotient is +inf
-			 * then) c >= 2^-125 (1 - 2^-24) > res t.  (The fma is this bound's own arithmetic, not the reference's.)  Taken per wave,
-			 * when EVERY lane still marching has a > c (a NaN fails it): a multiply, an fma, a compare and a scalar branch where it
-			 * does not apply.  Round 6, six repetitions per library on one box (profiles/r6_ab_division_skip.txt): C3 +4.2 % (new
-			 * view +3.2 %), C4 +4.0 %, C2 -3.3 % (rays skimming a plane keep v == res: they divide every step and pay for the test);
-			 * a cool-down after a step that did divide made all three worse.  (Round 3 measured a form of this at -1.2 % in the
-			 * wave-uniform loops of the time, where lanes that had finished took part in the vote.) */
+			 * pipeline (VMIN: every lane still marching has 0 < res <= 1, never NaN, and 0 <= t < 10^17), with a = 50 s and
+			 * b = fl(res t):
+			 *   a > b  =>  a >= the float above b  >  b + ulp(b) / 2  >=  res t      (b is res t rounded to nearest: off by at most half
+			 *                                                                          a spacing — denormal b and b = 0 included)
+			 *          =>  a / t > res  =>  fl(a / t) >= res                           (rounding is monotone, res is a float; t = 0: +inf)
+			 * and v_min leaves res as it is.  Taken per wave, when EVERY lane still marching has a > b (a NaN fails it): one multiply,
+			 * a compare and a scalar branch where it does not apply.  Round 6, six repetitions per library on one box
+			 * (profiles/r6_ab_division_skip.txt): C3 +4.2 % (new view +3.2 %), C4 +4.0 %, C2 -3.3 % (rays skimming a plane keep
+			 * v == res: they divide every step and pay for the test); a cool-down after a step that did divide made all three worse.
+			 * (Round 3 measured a form of this at -1.2 % in the wave-uniform loops of the time, where lanes that had finished took part
+			 * in the vote.)  tests/test_shadow_division_bound.py checks the implication in exact rational arithmetic. */
 			const float a = 50.f * s;
-			if (!VMIN || vote(!(a > __builtin_fmaf(res * t, 0x1.000008p+0f, 0x1p-125f))) != 0) {
+			if (!VMIN || vote(!(a > res * t)) != 0) {
 				asm volatile("");                        /* keep the branch */
 				const float v = a / t;
 				res = VMIN ? vmin_(res, v) : minf_(res, v);
