@@ -433,8 +433,11 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 	} else {
 		/* ASSUME_SETTLED: the fast pipeline only runs under FLAG_SHADOW_SETTLED (generate_source; lol_kernel.h, soft_shadow).
 		 * loop_done(): what the wave-uniform cool-down counter is after a loop that lanes leave one by one (lol_kernel.h, Interp) */
-		snprintf(line, sizeof line, "struct %s {\n\tstatic constexpr bool ASSUME_SETTLED = %s;\n\tRange rg;\n\tfloat nanacc = 0.f;\n%s"
-		         "\t__device__ __forceinline__ void loop_done() { %s }\n", name, fast ? "true" : "false", cool_decl,
+		/* ASK_ID_ONCE: the primary march evaluates the distance alone and asks for the id of its last step once (lol_kernel.h,
+		 * march) — from three top-level objects on, where a v_min per object and step outweighs the one evaluation more per pixel
+		 * (measured: scene.lol's four objects +3.6 %, scene4's two -0.8 %; profiles/r6_ab_id_asked_once.txt) */
+		snprintf(line, sizeof line, "struct %s {\n\tstatic constexpr bool ASSUME_SETTLED = %s;\n\tstatic constexpr bool ASK_ID_ONCE = %s;\n\tRange rg;\n\tfloat nanacc = 0.f;\n%s"
+		         "\t__device__ __forceinline__ void loop_done() { %s }\n", name, fast ? "true" : "false", P.n_roots >= 3 ? "true" : "false", cool_decl,
 		         plan.intervals.empty() ? "" : "cool[0] = 0u;");
 		s += line;
 	}
@@ -650,7 +653,7 @@ void emit_sdf(std::string& s, const lol_program& P, const char* name, const Fast
 	}      /* pass */
 	if (out_of_line) {
 		s += "\t\treturn { best, best_id, rg.lo, rg.hi, nanacc };\n}\n";
-		snprintf(line, sizeof line, "struct %s {\n\tstatic constexpr bool ASSUME_SETTLED = %s;\n\tRange rg;\n\tfloat nanacc = 0.f;\n"
+		snprintf(line, sizeof line, "struct %s {\n\tstatic constexpr bool ASSUME_SETTLED = %s;\n\tstatic constexpr bool ASK_ID_ONCE = false;\n\tRange rg;\n\tfloat nanacc = 0.f;\n"
 		         "\t__device__ __forceinline__ void loop_done() {}\n"
 		         "\t__device__ __forceinline__ void eval(V3 p, float& best, u32& best_id) {\n"
 		         "\t\tconst SdfOut o = %s_fn(p.x, p.y, p.z, rg.lo, rg.hi);\n"

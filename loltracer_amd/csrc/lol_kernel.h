@@ -646,6 +646,7 @@ struct Interp {
 	float      nanacc = 0.f;  /* (the specialised SDF's "an object's value went NaN" accumulator; never set here) */
 	/* the fast pipeline of the SPECIALISED kernel takes FLAG_SHADOW_SETTLED for granted (soft_shadow); this one reads the flag */
 	static constexpr bool ASSUME_SETTLED = false;
+	static constexpr bool ASK_ID_ONCE = false;           /* (march(): measured a loss for this kernel on scene4, profiles/r6_ab_id_asked_once.txt) */
 	/* `cool` is wave-uniform state that the march / shadow loops change while lanes leave them one by one: what comes out of
 	 * such a loop counts as per-lane for the compiler (it would travel in a VGPR and every later test of it would be a
 	 * per-lane branch).  The loops end by calling this: never testing — and testing at once — are both always allowed. */
@@ -657,8 +658,7 @@ struct Interp {
 	 * with ONE v_min_f32 and no test of MOP_TIE.  Same value as the strict-'<' / lower-id-wins rule except for the sign of a zero,
 	 * which no result of a shadow march depends on (soft_shadow: t + s, 50 s / t against 0, maxf(+-0, 0) = +0).  Round 6: the
 	 * interpreter +4.3 ... 5.6 %, the specialised kernel +0.8 % (C3) ... +8.6 % (C2: four flat objects); profiles/r6_ab_eval_dist.txt.
-	 * (The primary march on the distance alone too, its id asked for once at the point of its last step — built, exact, C2 +3.6 %
-	 * more but C3 -0.8 %: not kept; profiles/r6_ab_id_asked_once.txt.) */
+	 * (The primary march on the distance alone too, its id asked for once: a loss for this kernel on scene4 — march(), ASK_ID_ONCE.) */
 	__device__ __forceinline__ void eval_dist(V3 p, float& best_out) { u32 unused; eval<false>(p, best_out, unused); }
 	template <bool WITH_ID = true>
 	__device__ __forceinline__ void eval(V3 p, float& best_out, u32& id_out) {
@@ -835,6 +835,10 @@ __device__ __forceinline__ bool unproven(const Sdf& sdf) { return (vote(sdf.rg.o
 /* --------------------------------------------------------------- the pipeline */
 
 struct Hit { float dist; u32 id; u32 steps; };
+/* what march() hands on: the distance marched, the distance BEFORE its last step (the point that step evaluated), the step count,
+ * and the object id as far as it is known without asking — `ask`: this lane's id is that of the object nearest to the point of
+ * its last step, which normal_and_id() asks for (Sdf::ASK_ID_ONCE) */
+struct Marched { float dist, prev; u32 steps; u32 id; bool ask; };
 
 /* get_intersection, naive_renderer.c:48-69.
  *
@@ -853,26 +857,51 @@ struct Hit { float dist; u32 id; u32 steps; };
  * Round 6: +1.9 % on C3, +1.2 % for a new view, +4 % with two frames in flight (profiles/r6_ab4.txt).
  *
  * COUNT = false compiles the step counters out (Hit::steps stays 0): only the diagnostics and the one frame of a view that
- * records what its pixels cost read them (+1.3 %, profiles/r6_ab1.txt). */
+ * records what its pixels cost read them (+1.3 %, profiles/r6_ab1.txt).
+ *
+ * Sdf::ASK_ID_ONCE (a property of the scene's own kernel: lol_codegen.hip sets it for scenes of three or more top-level objects):
+ * the march evaluates the scene's DISTANCE alone (eval_dist), like the shadow marches.  The reference carries the id of the
+ * nearest object through every step (id = d.id, naive_renderer.c:60) and uses the LAST one — unless the ray escaped (dist >=
+ * MAX_DIST: id = 0, :65-66).  So the id is asked for once, at the point the last step evaluated (ro + rd * prev, the same
+ * expression: the same bits), by one more turn of normal_and_id()'s evaluation loop, and per step an object joins the minimum
+ * with one v_min_f32 instead of a compare and two selects.  The distance-only minimum differs from the strict-'<' one in the
+ * sign of a zero at most, and nothing here looks at that: dist + (+-0), (+-0) < EPSILON.  Which lanes must ask: those whose march
+ * took at least one turn of the loop (wave-uniform: every lane takes the first turn of a loop that runs at all) and did not escape.
+ * Round 6 (profiles/r6_ab_id_asked_once.txt): scene.lol's four flat objects +3.6 % (C2), scene4's two -0.8 % (C3) — the extra
+ * evaluation per pixel against 8 cycles per object and step — hence per scene; the interpreter -0.4 ... -0.9 % / +2.5 %: it keeps
+ * the id in its march. */
 template <bool COUNT, class Sdf>
-__device__ __forceinline__ Hit march(Sdf& sdf, V3 ro, V3 rd, int max_steps, bool first_given, float first_dist, u32 first_id) {
+__device__ __forceinline__ Marched march(Sdf& sdf, V3 ro, V3 rd, int max_steps, bool first_given, float first_dist, u32 first_id) {
 	const float EPSILON = 0.001f, MAX_DIST = 100.f;
 	/* (a NaN or infinite component makes the squared length NaN or inf) */
 	const bool skip_first = first_given && vote(!(len2(rd) < 4.f)) == 0;
-	float dist = skip_first ? first_dist : 0.f;
+	float dist = skip_first ? first_dist : 0.f, prev = 0.f;
 	u32 id = skip_first ? first_id : 0u, steps = skip_first ? 1u : 0u;
-	for (int i = skip_first ? 1 : 0; i < max_steps; i++) {
+	const int first_turn = skip_first ? 1 : 0;
+	for (int i = first_turn; i < max_steps; i++) {
 		V3 p = add(ro, scale(rd, dist));
-		float d; u32 did;
-		sdf.eval(p, d, did);
+		float d;
+		if constexpr (Sdf::ASK_ID_ONCE) {
+			sdf.eval_dist(p, d);
+			prev = dist;
+		} else {
+			u32 did;
+			sdf.eval(p, d, did);
+			id = did;
+		}
 		dist += d;
-		id = did;
 		if (COUNT) steps++;
 		if (d < EPSILON || dist > MAX_DIST) break;
 	}
 	sdf.loop_done();
-	if (dist >= MAX_DIST) id = 0;
-	return { dist, id, steps };
+	const bool far = dist >= MAX_DIST;
+	if (far) id = 0;
+	if constexpr (Sdf::ASK_ID_ONCE) {
+		const bool ran = first_turn < max_steps;
+		if (ran) id = 0;                                 /* (asked for below, unless the ray escaped) */
+		return { dist, prev, steps, id, ran && !far };
+	}
+	return { dist, prev, steps, id, false };
 }
 
 /* in_shadow + softshadow, naive_renderer.c:73-100.  dir/light_dist come from the caller,
@@ -940,23 +969,39 @@ __device__ __forceinline__ float soft_shadow(Sdf& sdf, V3 p, V3 dir, float max_d
 /* get_normal, naive_renderer.c:114-125: k0=(1,-1,-1) k1=(-1,-1,1) k2=(-1,1,-1) k3=(1,1,1);
  * n = normalize(k0*s0 + (k1*s1 + (k2*s2 + k3*s3))), s_i = sdf(p + k_i*h).  The taps run as a rolled loop from
  * k3 down to k0 (one copy of the SDF code instead of four; + is commutative, so adding each new term on the
- * left of the running sum reproduces the reference's association). */
+ * left of the running sum reproduces the reference's association).
+ *
+ * ... and the hit's object id where the march left it open (Sdf::ASK_ID_ONCE, march()): where a lane of the wave has to ask,
+ * the loop takes one turn more, FIRST, at the point its march's last step evaluated — the same copy of the SDF code.  Then the
+ * wave knows whether anything was hit at all: `lit` = false is FLAG_MISS_SKIP's "every ray of this wave escaped: no normal, no
+ * shadows" (shade_pixel), and the taps are not taken. */
 template <class Sdf>
-__device__ __forceinline__ V3 normal_at(Sdf& sdf, V3 p, float dist) {
-	const float h = dist / 100.f;
+__device__ __forceinline__ V3 normal_and_id(Sdf& sdf, V3 ro, V3 rd, const Marched& hit, V3 p, bool miss_skip, u32& id, bool& lit) {
+	const float h = hit.dist / 100.f;
 	const float nh = -1.f * h;       /* v3scale(k, h) multiplies; -1*h == -h bit for bit */
 	V3 acc = { 0.f, 0.f, 0.f };
+	const bool any_ask = Sdf::ASK_ID_ONCE && vote(hit.ask) != 0;
+	id = hit.id;
+	lit = true;
+	if (!any_ask && miss_skip && vote(id != 0u) == 0) { lit = false; return acc; }
 #pragma unroll 1      /* (unrolled — four independent evaluations in flight — it is 0.8 % slower within the 64-VGPR budget) */
-	for (int k = 3; k >= 0; k--) {
+	for (int k = any_ask ? 4 : 3; k >= 0; k--) {
 		/* sign pattern of tap k, wave-uniform: x is + for k0,k3; y is + for k2,k3; z is + for k1,k3 */
-		const bool px = k == 0 || k == 3, py = k >= 2, pz = k == 1 || k == 3;
-		float s; u32 unused;
-		sdf.eval({ p.x + (px ? h : nh), p.y + (py ? h : nh), p.z + (pz ? h : nh) }, s, unused);
+		const bool ask = Sdf::ASK_ID_ONCE && k == 4, px = k == 0 || k == 3, py = k >= 2, pz = k == 1 || k == 3;
+		V3 q = { p.x + (px ? h : nh), p.y + (py ? h : nh), p.z + (pz ? h : nh) };
+		if (ask) q = add(ro, scale(rd, hit.prev));
+		float s; u32 did;
+		sdf.eval(q, s, did);
+		if (ask) {
+			if (hit.ask) id = did;
+			if (miss_skip && vote(id != 0u) == 0) { lit = false; break; }
+			continue;
+		}
 		const float ns = -s;          /* -1.f * s */
 		V3 term = { px ? s : ns, py ? s : ns, pz ? s : ns };
 		acc = k == 3 ? term : add(term, acc);
 	}
-	return normalize(acc);
+	return lit ? normalize(acc) : acc;
 }
 
 __device__ __forceinline__ V3 lds_v3(const u32* base) {
@@ -1030,13 +1075,7 @@ __device__ __forceinline__ Pixel shade_pixel(const Launch& L, Sdf& sdf, const u3
 	V3 rd = add(scale(v3(L.cam.right), vx * L.cam.width), scale(v3(L.cam.up), vy * L.cam.height));
 	rd = normalize(add(rd, cdir));
 
-	Hit hit = march<COUNT>(sdf, ro, rd, L.max_steps, (L.flags & FLAG_FIRST_STEP) != 0u, L.first_dist, L.first_id);
-
-	/* get_material, naive_renderer.c:103-112 (per-lane table lookups) */
-	u32 mid = hit.id ? l_rootm[hit.id - 1] : 0u;
-	const float* m = reinterpret_cast<const float*>(l_mat + mid * MATERIAL_DWORDS);
-	const float shininess = m[0];
-	const V3 m_diff = { m[1], m[2], m[3] }, m_spec = { m[4], m[5], m[6] }, m_amb = { m[7], m[8], m[9] };
+	const Marched marched = march<COUNT>(sdf, ro, rd, L.max_steps, (L.flags & FLAG_FIRST_STEP) != 0u, L.first_dist, L.first_id);
 
 	/*
 	 * A ray that escaped is shaded with material #0 (naive_renderer.c:103-112).  When the host has checked
@@ -1047,14 +1086,21 @@ __device__ __forceinline__ Pixel shade_pixel(const Launch& L, Sdf& sdf, const u3
 	 * and the shadow marches (about 13 % of all SDF evaluations on scene4) and falls through to the same
 	 * `0 + ambient*mat.ambient` expression; a wave with at least one hit runs everything for all its lanes.
 	 */
-	const bool lit = !((L.flags & FLAG_MISS_SKIP) && vote(hit.id != 0u) == 0);
+	const V3 p = add(ro, scale(rd, marched.dist));
+	bool lit;
+	Hit hit = { marched.dist, 0u, marched.steps };
+	const V3 n = normal_and_id(sdf, ro, rd, marched, p, (L.flags & FLAG_MISS_SKIP) != 0u, hit.id, lit);
+
+	/* get_material, naive_renderer.c:103-112 (per-lane table lookups) */
+	u32 mid = hit.id ? l_rootm[hit.id - 1] : 0u;
+	const float* m = reinterpret_cast<const float*>(l_mat + mid * MATERIAL_DWORDS);
+	const float shininess = m[0];
+	const V3 m_diff = { m[1], m[2], m[3] }, m_spec = { m[4], m[5], m[6] }, m_amb = { m[7], m[8], m[9] };
 
 	/* get_light, naive_renderer.c:129-175 */
 	V3 total = { 0.f, 0.f, 0.f };
 	u32 shadow_steps = 0;
 	if (lit) {
-		V3 p = add(ro, scale(rd, hit.dist));
-		V3 n = normal_at(sdf, p, hit.dist);
 		const V3 camera_dir = normalize(sub(ro, p));
 		for (u32 li = 0; li < L.n_lights; li++) {
 			const u32* lp = l_light + li * LIGHT_DWORDS;
