@@ -4,7 +4,7 @@
 # not rehearsed: a GPU box admits at most 6 processes on its card at once (the pool's process guard), and the launcher side holds one more handle: 6 ranks were killed by it.  Also the orbit over
 # 4 ranks and the in-process transport.  Records land under gpurun_out/rehearse; copy what is to be judged into profiles/.
 # usage (on the GPU box): bash tools/rehearse_worlds.sh [tag, default r4]
-TAG=${1:-r4}
+TAG=${1:-r6}
 R=${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}
 O=$R/gpurun_out/rehearse; mkdir -p $O; cd $R
 rec() { grep -o '^{.*' | tail -1; }
