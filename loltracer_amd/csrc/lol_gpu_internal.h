@@ -14,6 +14,7 @@
  */
 #pragma once
 #include "lol_gpu.h"
+#include "lol_gpu_diag.h"
 #include "lol_gpu_testing.h"
 #include "lol_kernel.h"
 

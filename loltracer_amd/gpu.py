@@ -265,24 +265,27 @@ def gpu_lib() -> C.CDLL:
 TESTING_SYMBOLS = ["lol_gpu_testing_fail_uploads", "lol_gpu_testing_fail_first_tier", "lol_gpu_testing_has_return_clobbering_branch", "lol_gpu_multi_testing_root_stride",
                    "lol_gpu_multi_testing_force_copier_threads"]          # include/lol_gpu_testing.h
 
-EXPORTED_SYMBOLS = [
-    "lol_gpu_abi_version", "lol_gpu_device_count", "lol_gpu_create", "lol_gpu_destroy", "lol_gpu_error", "lol_gpu_upload_program",
-    "lol_gpu_part_rows", "lol_gpu_render_device", "lol_gpu_render_host", "lol_gpu_sync", "lol_gpu_malloc",
-    "lol_gpu_free", "lol_gpu_memcpy_d2h", "lol_gpu_kernel_name", "lol_gpu_set_specialize",
-    "lol_gpu_specialize_log", "lol_gpu_specialize_wait", "lol_gpu_specialize_state", "lol_gpu_multi_specialize_wait", "lol_gpu_compile_offline", "lol_gpu_verify_fast_paths", "lol_gpu_verify_smin_no_fixup", "lol_gpu_verify_gamma_table", "lol_gpu_set_miss_skip",
-    "lol_gpu_miss_skip_active", "lol_gpu_set_exact_skips", "lol_gpu_powf_batch", "lol_gpu_device", "lol_gpu_sdf_batch", "lol_gpu_set_cull", "lol_gpu_set_tile_order", "lol_gpu_tile_order", "lol_gpu_cull_bounds", "lol_gpu_cull_bounds_clusters",
-    "lol_gpu_render_host_begin", "lol_gpu_render_host_end", "lol_gpu_render_host_pending",
-    "lol_gpu_multi_create", "lol_gpu_multi_destroy", "lol_gpu_multi_error", "lol_gpu_multi_device_count",
-    "lol_gpu_multi_context", "lol_gpu_multi_upload_program", "lol_gpu_choose_band_rows", "lol_gpu_multi_set_band_rows",
-    "lol_gpu_part_frame_row", "lol_gpu_multi_render_device", "lol_gpu_multi_render_host", "lol_gpu_multi_sync",
-    "lol_gpu_multi_malloc", "lol_gpu_multi_free", "lol_gpu_multi_memcpy_d2h", "lol_gpu_assemble_parts",
-    "lol_gpu_multi_set_parts_per_device", "lol_gpu_multi_set_host_via_root",
-    "lol_gpu_set_pixel_format",
-    "lol_gpu_render_host_pending_size", "lol_gpu_render_host_discard", "lol_gpu_kernel_key", "lol_gpu_roctx_ranges",
-    "lol_gpu_assemble_parts_at", "lol_gpu_split_rows", "lol_gpu_multi_set_root_band_rows",
-    "lol_gpu_multi_set_pixel_format", "lol_gpu_multi_set_tile_order",
-    "lol_gpu_set_frames_in_flight", "lol_gpu_frames_in_flight", "lol_gpu_next_stream", "lol_gpu_tuning_switches",
-    "lol_gpu_set_specialize_max_ops",
+EXPORTED_SYMBOLS = [                                                    # include/lol_gpu.h
+    "lol_gpu_abi_version", "lol_gpu_device_count", "lol_gpu_create", "lol_gpu_destroy", "lol_gpu_error",
+    "lol_gpu_upload_program", "lol_gpu_part_rows", "lol_gpu_render_device", "lol_gpu_render_host", "lol_gpu_sync",
+    "lol_gpu_malloc", "lol_gpu_free", "lol_gpu_memcpy_d2h", "lol_gpu_kernel_name", "lol_gpu_set_specialize",
+    "lol_gpu_specialize_log", "lol_gpu_specialize_wait", "lol_gpu_specialize_state", "lol_gpu_multi_specialize_wait",
+    "lol_gpu_compile_offline", "lol_gpu_set_miss_skip", "lol_gpu_miss_skip_active", "lol_gpu_set_exact_skips", "lol_gpu_device",
+    "lol_gpu_set_cull", "lol_gpu_set_tile_order", "lol_gpu_tile_order", "lol_gpu_render_host_begin", "lol_gpu_render_host_end",
+    "lol_gpu_render_host_pending", "lol_gpu_multi_create", "lol_gpu_multi_destroy", "lol_gpu_multi_error",
+    "lol_gpu_multi_device_count", "lol_gpu_multi_context", "lol_gpu_multi_upload_program", "lol_gpu_choose_band_rows",
+    "lol_gpu_multi_set_band_rows", "lol_gpu_part_frame_row", "lol_gpu_multi_render_device", "lol_gpu_multi_render_host",
+    "lol_gpu_multi_sync", "lol_gpu_multi_malloc", "lol_gpu_multi_free", "lol_gpu_multi_memcpy_d2h", "lol_gpu_assemble_parts",
+    "lol_gpu_multi_set_parts_per_device", "lol_gpu_multi_set_host_via_root", "lol_gpu_set_pixel_format",
+    "lol_gpu_render_host_pending_size", "lol_gpu_render_host_discard", "lol_gpu_kernel_key", "lol_gpu_assemble_parts_at",
+    "lol_gpu_split_rows", "lol_gpu_multi_set_root_band_rows", "lol_gpu_multi_set_pixel_format", "lol_gpu_multi_set_tile_order",
+    "lol_gpu_set_frames_in_flight", "lol_gpu_frames_in_flight", "lol_gpu_next_stream", "lol_gpu_set_specialize_max_ops",
+]
+
+DIAG_SYMBOLS = [                                                        # include/lol_gpu_diag.h
+    "lol_gpu_tuning_switches", "lol_gpu_roctx_ranges", "lol_gpu_verify_fast_paths", "lol_gpu_verify_smin_no_fixup",
+    "lol_gpu_verify_gamma_table", "lol_gpu_cull_bounds", "lol_gpu_cull_bounds_clusters", "lol_gpu_powf_batch",
+    "lol_gpu_sdf_batch",
 ]
 
 

@@ -24,6 +24,18 @@ def test_lol_gpu_exports_every_declared_symbol():
         assert getattr(lib, n) is not None
 
 
+def test_lol_gpu_diag_header_is_exported_too():
+    """The proofs, bounds and probes live in a header of their own, so that lol_gpu.h is what a host reads."""
+    lib = C.CDLL(os.path.join(S.LIB_DIR, "liblol_gpu.so"))
+    names = declared("lol_gpu_diag.h")
+    assert set(names) == set(gpu.DIAG_SYMBOLS)
+    for n in names:
+        assert getattr(lib, n) is not None
+    for host in ("hip_renderer.c", "lol_headless.c"):
+        text = open(os.path.join(ROOT, "integration", host)).read()
+        assert "lol_gpu_diag.h" not in text and not any(n + "(" in text for n in names), host
+
+
 def test_lol_gpu_testing_header_is_exported_too():
     lib = C.CDLL(os.path.join(S.LIB_DIR, "liblol_gpu.so"))
     names = declared("lol_gpu_testing.h")

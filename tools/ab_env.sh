@@ -1,4 +1,4 @@
-export LOL_GPU_TUNING=1   # the library honours its A/B switches only beside this (include/lol_gpu.h)
+export LOL_GPU_TUNING=1   # the library honours its A/B switches only beside this (include/lol_gpu.h, "The environment")
 # A/B of environment switches on one box: `bash tools/ab_env.sh "A=1" "A=0" ...` times C3 (default kernel) under each setting, twice.
 R=${GRAFT_REPO_ROOT:?run on the GPU box}; cd $R
 for rep in 1 2; do for kv in "$@"; do

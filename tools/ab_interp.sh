@@ -1,4 +1,4 @@
-export LOL_GPU_TUNING=1   # the library honours its A/B switches only beside this (include/lol_gpu.h)
+export LOL_GPU_TUNING=1   # the library honours its A/B switches only beside this (include/lol_gpu.h, "The environment")
 # A/B of interpreter builds on one box: every library under tools/ab/ (and the in-tree one) times C3 on render_interp.
 R=${GRAFT_REPO_ROOT:?run on the GPU box}; cd $R
 for rep in 1 2; do

@@ -1,4 +1,4 @@
-export LOL_GPU_TUNING=1   # the library honours its A/B switches only beside this (include/lol_gpu.h)
+export LOL_GPU_TUNING=1   # the library honours its A/B switches only beside this (include/lol_gpu.h, "The environment")
 # Round 5: PAIR records in the interpreter — an experiment that lives in commit 470c9f6 only (two spheres under one smooth union as ONE
 # record; reverted: scene4 +4 %, scene.lol -4 %, the bar was +10 %).  This is the recipe that measured it: the in-tree library with and
 # without pairs (same code, other lists) against the library built before the pair body existed (tools/ab/base.so), twice, one box.

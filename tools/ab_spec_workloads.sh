@@ -1,4 +1,4 @@
-export LOL_GPU_TUNING=1   # the library honours its A/B switches only beside this (include/lol_gpu.h)
+export LOL_GPU_TUNING=1   # the library honours its A/B switches only beside this (include/lol_gpu.h, "The environment")
 # A/B of library builds on the specialised kernel over the BASELINE workloads on one box: every library under tools/ab/ and the in-tree one.
 R=${GRAFT_REPO_ROOT:?run on the GPU box}; cd $R
 for rep in 1 2 3; do for lib in loltracer_amd/lib/liblol_gpu.so tools/ab/*.so; do for w in c2 c3; do

@@ -1,4 +1,4 @@
-export LOL_GPU_TUNING=1   # the library honours its A/B switches only beside this (include/lol_gpu.h)
+export LOL_GPU_TUNING=1   # the library honours its A/B switches only beside this (include/lol_gpu.h, "The environment")
 # The specialised kernel's GENERATED source of two library builds (in-tree and tools/ab/*.so), for one workload: to find out whether a
 # change of speed comes from the generated part or from lol_kernel.h (compile both offline with hipcc -S and diff: LABNOTES.md §3.1).
 # usage on the GPU box: bash tools/dump_spec_ab.sh [c2|c3]   → gpurun_out/specsrc/<lib>.<workload>.hip

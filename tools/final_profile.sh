@@ -1,4 +1,4 @@
-export LOL_GPU_TUNING=1   # the library honours its A/B switches only beside this (include/lol_gpu.h)
+export LOL_GPU_TUNING=1   # the library honours its A/B switches only beside this (include/lol_gpu.h, "The environment")
 # Round profile on the GPU box: kernel-trace stats + PMC passes of the default bench (C3) for BOTH kernels, the
 # other BASELINE workloads, and the summaries.  Everything lands under gpurun_out/prof_final; copy what is to be
 # judged into profiles/ (see profiles/README.md).   usage: bash tools/final_profile.sh [round-tag, default r6]

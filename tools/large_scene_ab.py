@@ -78,5 +78,5 @@ def main():
 
 
 if __name__ == "__main__":
-    os.environ.setdefault("LOL_GPU_TUNING", "1")      # the library honours its A/B switches only beside this (include/lol_gpu.h); only when RUN, not when a test imports the scene builders
+    os.environ.setdefault("LOL_GPU_TUNING", "1")      # the library honours its A/B switches only beside this (include/lol_gpu.h, "The environment"); only when RUN, not when a test imports the scene builders
     main()

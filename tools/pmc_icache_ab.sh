@@ -1,4 +1,4 @@
-export LOL_GPU_TUNING=1   # the library honours its A/B switches only beside this (include/lol_gpu.h)
+export LOL_GPU_TUNING=1   # the library honours its A/B switches only beside this (include/lol_gpu.h, "The environment")
 # Instruction-cache view of interpreter builds (tools/ab/*.so and the in-tree library): SQC_ICACHE_* per render_interp dispatch on C3.
 export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:?run on the GPU box}; O=$R/gpurun_out/pmc_icache; rm -rf "$O"; mkdir -p $O; cd /tmp
 export LOL_GPU_SPECIALIZE=0 LOL_BENCH_HOST_SURFACE=0

@@ -1,4 +1,4 @@
-export LOL_GPU_TUNING=1   # the library honours its A/B switches only beside this (include/lol_gpu.h)
+export LOL_GPU_TUNING=1   # the library honours its A/B switches only beside this (include/lol_gpu.h, "The environment")
 # PMC passes of the interpreter kernel on C3 (LOL_GPU_SPECIALIZE=0 makes bench.py time render_interp); outputs under gpurun_out/<name>
 export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:?run on the GPU box}; O=$R/gpurun_out/${1:-pmc_interp2}; mkdir -p $O; cd /tmp
 export LOL_GPU_SPECIALIZE=0
